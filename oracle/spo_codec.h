@@ -1,0 +1,141 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see spo_model.h for the parity note).
+//
+// CPU restatement of the ScreenPressor frame codec: ScreenCodec /
+// CScreenCapt<UseANS> (screencap.h, screencap.cpp), RansMTCoder (ransmt.h) and
+// the byte-wise rANS primitives (rans_byte.h).  Citations are relative to
+// /root/reference.
+#pragma once
+#include <stdint.h>
+#include <vector>
+#include "spo_model.h"
+
+namespace spo {
+
+struct Params {  // CodecParameters, screencap.h:49-55, plus the worker count
+  uint32_t width, height;
+  uint32_t bits_per_pixel;  // 16, 24, 32
+  uint32_t red_mask, green_mask, blue_mask;
+  uint32_t high_range_x, high_range_y, low_range_x, low_range_y;
+  uint32_t loss;
+  uint32_t workers;  // size of the reference's CSquad pool; bitstream-visible for I-frames
+  uint32_t version;  // 4 (default) or 3; encoder side only
+};
+
+enum { kRansL = 1u << 23, kBlockEntries = 128 * 1024 };  // rans_byte.h:47, ransmt.h:38
+
+// rANS primitives, restated (rans_byte.h:59-146).
+struct RansEnc {
+  uint32_t x;
+  static inline void put(uint32_t& x, uint8_t*& p, uint32_t start, uint32_t freq) {
+    uint32_t x_max = ((kRansL >> kProbBits) << 8) * freq;
+    while (x >= x_max) {
+      *--p = (uint8_t)(x & 0xff);
+      x >>= 8;
+    }
+    x = ((x / freq) << kProbBits) + (x % freq) + start;
+  }
+};
+
+// All model tables of one codec instance (screencap.h:436-443).
+struct Models {
+  ColourCtx colour[3][4096];
+  FixedModel run_len[6];   // ntab
+  FixedModel blk_run;      // ntab2
+  FixedModel blk_type;     // bttab
+  FixedModel rect[4];      // sxytab
+  FixedModel motion[2];    // mvtab
+  FixedModel pix_type[6];  // ptypetab
+  FixedModel blk_index;    // xxtab
+  void reset();            // RenewI, screencap.cpp:178-198
+};
+
+struct RunRec {  // debugging tap: one pixel run as classified
+  uint8_t type;
+  uint8_t rgb[3];
+  uint16_t n;
+};
+
+class FrameCodec {  // CScreenCapt<UseANS>
+ public:
+  FrameCodec(const Params& p, int version);
+  int compress(uint8_t* src, uint8_t* dst, int dst_len, int& ftype);
+  int decompress(const uint8_t* src, int src_len, uint8_t* dst, int ftype);
+  void set_loss(int loss);
+
+  // debugging taps (stage-level known-answer tests)
+  std::vector<Ivl> last_entries;     // every coder entry of the last compressed frame
+  std::vector<uint8_t> last_records; // I: run records; P: per-block run records
+  std::vector<uint8_t> blk_types;    // bts
+  std::vector<int> rect_xy[4];       // sxy
+  std::vector<int> mv[2];            // mvs
+  const uint8_t* prev_plane() const { return prev_.data(); }
+  int stride() const { return stride_; }
+
+ private:
+  int W, H, stride_, nbx, nby, version_, f0_, workers_;
+  uint32_t far_x, far_y, near_x, near_y;
+  uint32_t frames_ = 0;
+  int loss_mask_ = -1, corr_mask_ = 0;
+  bool last_flat_ = false;
+  uint8_t last_flat_rgb_[4] = {0, 0, 0, 0};
+  std::vector<uint8_t> prev_;
+  Models* m_;
+  uint32_t cx_ = 0, cx1_ = 0;
+
+  // encoder
+  std::vector<Ivl> out_;
+  std::vector<uint32_t> band_start_, band_size_;  // tls[]
+  void put(Ivl e) { out_.push_back(e); }
+  void put_colour(int plane, uint8_t c);
+  void put_rgb(const uint8_t* px);           // EncodeRGB
+  void put_pixel(int t, int last_t, const uint8_t* px);  // WritePixel
+  void apply_loss(uint8_t* src);
+  bool is_flat(const uint8_t* src) const;
+  void classify_intra(int worker, int y0, int ysize, const uint8_t* src);
+  void decide_blocks(const uint8_t* src, int& bx1, int& bx2, int& by1, int& by2);
+  bool find_motion(const uint8_t* src, int bi, int& lmx, int& lmy, int upper);
+  bool same_rect(const uint8_t* src, int is, int ip, int wbytes, int h) const;
+  int encode_intra(uint8_t* src, uint8_t* dst);
+  int encode_inter(uint8_t* src, uint8_t* dst);
+  uint8_t* flush_entries(uint8_t* dst);
+
+  // decoder
+  const uint8_t* in_ = nullptr;
+  uint32_t rx_ = 0;
+  int n_dec_ = 0;
+  void dec_begin(const uint8_t* p);
+  void dec_count();
+  int get_fixed(FixedModel& m);
+  int get_colour(int plane);
+  void get_rgb(int& r, int& g, int& b);
+  bool get_bool();
+  int decode_intra(const uint8_t* src, uint8_t* dst);
+  int decode_inter(const uint8_t* src, uint8_t* dst);
+
+ public:
+  ~FrameCodec();
+};
+
+class ScreenCodec {  // screencap.h:519-541, screencap.cpp:1560-1743
+ public:
+  ScreenCodec() {}
+  ~ScreenCodec() { deinit(); }
+  void init(const Params& p);
+  void deinit();
+  // returns compressed size; 0 when refused; negative on parameter errors
+  int compress_frame(uint8_t* src, uint8_t* dst, int dst_len, int* ftype, int loss);
+  int decompress_frame(const uint8_t* src, int src_len, uint8_t* dst, int pitch, int ftype);
+  void crash_happened() { crashed_ = true; }
+  FrameCodec* inner() { return fc_; }
+
+ private:
+  void create(int version);
+  Params p_{};
+  FrameCodec* fc_ = nullptr;
+  bool rgb32_ = false, rgb16_ = false, crashed_ = false;
+  uint32_t W = 0, H = 0, stride_ = 0, bpp_ = 0;
+  int rs_ = 0, gs_ = 0, bs_ = 0, last_loss_ = 0;
+  std::vector<uint8_t> buf_;
+};
+
+}  // namespace spo
