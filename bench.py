@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""bench.py — MPix/s encode+decode on the BASELINE.json workload.
+
+  python bench.py --gpus N --steps K --warmup W
+
+Workload (config.workload): 1920x1080 RGB32, every frame a key frame, 300 frames per
+GPU (BASELINE.json configs[1]).  One step = one pass of the hot path over the batch:
+compress the 300 frames (resident in HBM) to packets in HBM, then decompress them back
+to RGB32 in HBM.  value = pixels of all ranks / max-over-ranks step time, i.e. the
+combined figure W*H*N/(t_enc+t_dec) of SURVEY.md §8d.  Multi-GPU: frames are sharded
+across ranks (weak scaling, one process per GPU); every step ends with the gather of the
+compressed chunks to rank 0 over RCCL.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=300)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--cpu-frames", type=int, default=24, help="frames of the same workload timed on the host CPU (oracle)")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from screenpressor_amd.codec import ScreenCodec
+    from screenpressor_amd.synth import DesktopSequence
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    W, H, N = args.width, args.height, args.frames
+
+    # synthetic input, resident in HBM before the timed region (rank r: its own seed/shard)
+    seq = DesktopSequence(W, H, seed=1 + rank)
+    frames = torch.empty((N, H * W * 4), dtype=torch.uint8, device=dev)
+    for t in range(N):
+        frames[t] = torch.from_numpy(seq.frame(t).reshape(-1)).to(dev)
+    codec_e = ScreenCodec(local_rank).Init(W, H, 32)
+    codec_d = ScreenCodec(local_rank).Init(W, H, 32)
+    packets = torch.empty(max(256 << 20, N * W * H // 2), dtype=torch.uint8, device=dev)
+    decoded = torch.empty(N * H * W * 4, dtype=torch.uint8, device=dev)
+    ftypes = [0] * N
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    stage_acc, t_enc_acc, t_dec_acc, comp_bytes = {}, 0.0, 0.0, 0
+
+    def step(timed):
+        nonlocal t_enc_acc, t_dec_acc, comp_bytes
+        codec_e.Deinit(); codec_e.Init(W, H, 32)
+        codec_d.Deinit(); codec_d.Init(W, H, 32)
+        t0 = time.perf_counter()
+        out, sizes, ft = codec_e.CompressBatch(frames, ftypes, out=packets)
+        t1 = time.perf_counter()
+        te, se = codec_e.last_timing()
+        r, dec = codec_d.DecompressBatch(out, sizes, ft, out=decoded)
+        t2 = time.perf_counter()
+        td, sd = codec_d.last_timing()
+        assert r == N
+        if world > 1:  # exchange step: compressed chunks to rank 0 (sizes first, then padded payloads)
+            tot = torch.tensor([out.numel()], device=dev, dtype=torch.int64)
+            alls = [torch.zeros_like(tot) for _ in range(world)]
+            dist.all_gather(alls, tot)
+            mx = int(max(int(a.item()) for a in alls))
+            pad = torch.zeros(mx, dtype=torch.uint8, device=dev)
+            pad[:out.numel()] = out
+            gl = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
+            dist.gather(pad, gl, dst=0)
+        if timed:
+            t_enc_acc += t1 - t0
+            t_dec_acc += t2 - t1
+            comp_bytes = int(out.numel())
+            for k, v in list(se.items()) + list(sd.items()):
+                if v > 0:
+                    stage_acc[k] = stage_acc.get(k, 0.0) + v
+        return out, sizes, dec
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out, sizes, dec = step(True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    lossless = bool(torch.equal(dec.reshape(N, -1), frames))
+
+    tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * N * W * H / 1e6 / (elapsed / args.steps)
+
+    if rank == 0:
+        # dominant kernel stage by device time (HIP events on the codec's stream, scpr_last_timing)
+        per_step = {k: v / args.steps for k, v in stage_acc.items()}
+        dom = max(per_step, key=per_step.get)
+        raw = N * W * H * 4
+        # algorithmic bytes per SURVEY.md §8(d): encode I = raw + c, decode I = c + raw, per frame
+        alg_bytes = raw + comp_bytes
+        dom_ms = per_step[dom]
+        achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "launch_ms": round(dom_ms, 3),
+                    "algorithmic_bytes_per_launch": alg_bytes}
+        cpu = None
+        if not args.no_cpu:
+            import oracle_api as O
+            nf = min(args.cpu_frames, N)
+            sample = np.stack([seq.frame(t) for t in range(nf)]).reshape(nf, -1)
+            r = O.time_stream(sample, W, H, 32, key_interval=1)
+            assert r["bad"] == 0
+            cpu = {"value": round(nf * W * H / 1e6 / (r["t_enc"] + r["t_dec"]), 2), "unit": "MPix/s", "cores": 1, "kind": "port",
+                   "sample": f"first {nf} frames of the same workload, encode+decode, oracle/libspo.so (single thread)",
+                   "enc_MPix_s": round(nf * W * H / 1e6 / r["t_enc"], 2), "dec_MPix_s": round(nf * W * H / 1e6 / r["t_dec"], 2)}
+        line = {
+            "metric": "MPix/s encode+decode, 1080p RGB32; bitstream byte-identical to ref", "value": round(value, 2), "unit": "MPix/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"{W}x{H} RGB32 key-frame-only (I-frames), {N} frames per GPU, synthetic desktop seed 1+rank",
+                       "frames_per_gpu": N, "parallelism": f"frame-sharded x{world}", "lossless_roundtrip": lossless,
+                       "compressed_bytes_per_gpu": comp_bytes,
+                       "enc_MPix_s_rank0": round(N * W * H / 1e6 / (t_enc_acc / args.steps), 2),
+                       "dec_MPix_s_rank0": round(N * W * H / 1e6 / (t_dec_acc / args.steps), 2),
+                       "stage_ms_per_step": {k: round(v, 3) for k, v in per_step.items()}},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,107 @@
+/* scpr_amd.h — C ABI of the MI355X-native ScreenPressor v4 encode/decode path.
+ *
+ * Drop-in boundary: the reference's `class ScreenCodec` (screencap.h:519-541 in
+ * the reference tree), which CodecInst owns by value (screenpressor.h:15) and
+ * drives from Compress/Decompress (screenpressor.cpp:392-439, :591-638).
+ * Every entry point below names the member it replaces.  No C++ types, no
+ * exceptions and no torch types cross this boundary.
+ *
+ * The library is GPU-only: there is no CPU fallback.  Every call fails with
+ * SCPR_E_DEVICE when no gfx950 device is usable.
+ */
+#ifndef SCPR_AMD_H
+#define SCPR_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* CodecParameters (screencap.h:49-55) + `workers`.
+ * `workers` is the size of the reference's CSquad pool (= CPU count of the
+ * capture machine, screencap.cpp:1459-1461).  It is bitstream-visible: key
+ * frames cut their pixel runs at the start of each of `workers` row bands
+ * (screencap.cpp:365-388, squad.cpp:16-31).  1 is the canonical value.
+ * P-frames are always produced in the canonical (single worker) block order. */
+typedef struct scpr_params {
+    uint32_t width, height;
+    uint32_t bits_per_pixel;              /* 16, 24 or 32 */
+    uint32_t red_mask, green_mask, blue_mask; /* RGB16 only, e.g. 0x7C00,0x3E0,0x1F */
+    uint32_t high_range_x, high_range_y;  /* motion search, far window (256,256) */
+    uint32_t low_range_x, low_range_y;    /* near window (8,8) */
+    uint32_t loss;                        /* 0..5 bits dropped per channel */
+    uint32_t workers;                     /* >= 1 */
+} scpr_params;
+
+typedef struct scpr_codec scpr_codec;
+
+enum {
+    SCPR_OK = 0,
+    SCPR_E_DEVICE = -1,      /* no usable gfx950 device / HIP error */
+    SCPR_E_PARAM = -2,       /* bad argument */
+    SCPR_E_BAD_VERSION = -3, /* BadVersionException (screencap.h:86-90): stream version not 3/4 or bpp not 16/24/32 */
+    SCPR_E_CAPACITY = -4,    /* destination too small */
+    SCPR_E_STREAM = -5       /* corrupt stream detected by the decoder */
+};
+
+/* ScreenCodec::ScreenCodec() (screencap.cpp:1560).  `device` = HIP ordinal. */
+scpr_codec* scpr_create(int device);
+/* ScreenCodec::~ScreenCodec() (screencap.h:535) */
+void scpr_destroy(scpr_codec* c);
+/* ScreenCodec::Init (screencap.cpp:1565-1584) */
+int scpr_init(scpr_codec* c, const scpr_params* p);
+/* ScreenCodec::Deinit (screencap.cpp:1619-1629) */
+void scpr_deinit(scpr_codec* c);
+/* ScreenCodec::CrashHappened (screencap.h:540) */
+void scpr_crash_happened(scpr_codec* c);
+
+/* ScreenCodec::CompressFrame (screencap.cpp:1632-1692).  Host pointers.
+ * src: RGB32 rows of width*4 bytes, or RGB24/RGB16 rows padded to 4 bytes.
+ * *ftype in: 0 = key frame wanted, 1 = P allowed; out: type produced.
+ * Returns the compressed size, 0 when refused (crashed), < 0 on error. */
+int scpr_compress_frame(scpr_codec* c, const void* src, void* dst, int dst_len, int* ftype, int loss);
+
+/* ScreenCodec::DecompressFrame (screencap.cpp:1695-1743).  Host pointers.
+ * Returns 1 on success, 0 when refused, < 0 on error. */
+int scpr_decompress_frame(scpr_codec* c, const void* src, int src_len, void* dst, int pitch, int ftype);
+
+/* ---- batch entry points (an addition: many frames per call, data resident in
+ * HBM).  Semantics are exactly those of calling the per-frame functions on the
+ * frames in order, including all cross-frame state. -------------------------- */
+
+/* d_frames: nframes frames back to back in device memory (same layout as src
+ *           above).
+ * ftypes:   host array, in/out as *ftype above.
+ * d_out:    device buffer receiving the packets back to back in frame order.
+ * sizes:    host array receiving each packet's size.
+ * Returns the total number of bytes written, or < 0. */
+int64_t scpr_compress_batch(scpr_codec* c, const void* d_frames, int nframes, int* ftypes, int loss,
+                            void* d_out, size_t out_capacity, uint32_t* sizes);
+
+/* d_packets: the packets back to back in device memory; sizes/ftypes: host
+ * arrays.  d_frames_out: nframes frames of `pitch`-byte rows in device
+ * memory.  Returns the number of frames decoded, or < 0. */
+int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* sizes, const int* ftypes,
+                          int nframes, void* d_frames_out, int pitch);
+
+/* ---- instrumentation ------------------------------------------------------ */
+/* Kernel time of the last batch call, measured with HIP events on the codec's
+ * own stream: total milliseconds and, per stage, milliseconds in `stage_ms`
+ * (up to `cap` entries, names via scpr_stage_name).  Returns the number of
+ * stages. */
+int scpr_last_timing(scpr_codec* c, float* total_ms, float* stage_ms, int cap);
+const char* scpr_stage_name(int stage);
+
+/* Debug taps on the last compress call (tests only): copies up to cap coder
+ * entries ({freq, cum} uint16 pairs, stream order, all frames of the batch)
+ * to host memory; returns the entry count. */
+int64_t scpr_debug_entries(scpr_codec* c, uint16_t* out, int64_t cap);
+
+const char* scpr_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCPR_AMD_H */

@@ -60,6 +60,13 @@ int spo_tap_entries(void* h, uint16_t* out, int cap_entries) {
   }
   return n;
 }
+int spo_tap_tags(void* h, uint16_t* out, int cap) {
+  FrameCodec* f = ((ScreenCodec*)h)->inner();
+  if (!f) return -1;
+  int n = (int)f->last_tags.size();
+  for (int i = 0; i < n && i < cap; i++) out[i] = f->last_tags[i];
+  return n;
+}
 int spo_tap_blocks(void* h, uint8_t* types, int32_t* rect4, int32_t* mv2, int nblocks) {
   FrameCodec* f = ((ScreenCodec*)h)->inner();
   if (!f || (int)f->blk_types.size() != nblocks) return -1;

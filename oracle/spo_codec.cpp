@@ -106,7 +106,7 @@ void FrameCodec::put_colour(int plane, uint8_t c) {  // UseANS::encodeC, screenc
     e.freq = 0;
     e.cum = c;
   }
-  put(e);
+  put(e, plane * 4096 + (int)(cx_ + cx1_));
 }
 
 #define SPO_NEXT_CX(v)            \
@@ -123,7 +123,7 @@ void FrameCodec::put_rgb(const uint8_t* px) {  // EncodeRGB, :631-643
 }
 
 void FrameCodec::put_pixel(int t, int last_t, const uint8_t* px) {  // WritePixel, :609-627
-  put(m_->pix_type[last_t].encode(t));
+  put(m_->pix_type[last_t].encode(t), 12294 + last_t);
   if (t) return;
   put_colour(0, px[0]);
   SPO_NEXT_CX(px[0]);
@@ -159,6 +159,7 @@ uint8_t* FrameCodec::flush_entries(uint8_t* dst) {
     dst += sz;
   }
   last_entries = out_;
+  last_tags = tags_;
   return dst;
 }
 
@@ -248,6 +249,7 @@ int FrameCodec::encode_intra(uint8_t* src, uint8_t* dst) {  // CompressI, :319-4
     classify_intra(k, y0, ys, src);
   }
   out_.clear();
+  tags_.clear();
   m_->reset();
   put_rgb(src);
 
@@ -257,13 +259,13 @@ int FrameCodec::encode_intra(uint8_t* src, uint8_t* dst) {  // CompressI, :319-4
     if (eq3(src + i, src + lasti) && n < 255)
       n++;
     else {
-      put(m_->run_len[0].encode(n));
+      put(m_->run_len[0].encode(n), 12288);
       put_rgb(src + i);
       n = 1;
     }
     lasti = i;
   }
-  put(m_->run_len[0].encode(n));
+  put(m_->run_len[0].encode(n), 12288);
   int x = 0, y = 1;
   const uint8_t* rec = last_records.data();
   for (int band = 0; band < workers_; band++) {
@@ -276,7 +278,7 @@ int FrameCodec::encode_intra(uint8_t* src, uint8_t* dst) {  // CompressI, :319-4
       last_t = t;
       if (!t) j += 3;
       n = rec[j + 1];
-      put(m_->run_len[t].encode(n));
+      put(m_->run_len[t].encode(n), 12288 + t);
       j += 2;
       x += n;
       while (x >= W) {
@@ -509,27 +511,28 @@ int FrameCodec::encode_inter(uint8_t* src, uint8_t* dst0) {  // CompressP, :1091
   }
   *dst++ = 1;
   out_.clear();
+  tags_.clear();
   int bx1, bx2, by1, by2;
   decide_blocks(src, bx1, bx2, by1, by2);
 
   int xx1 = by1 * nbx + bx1, xx2 = by2 * nbx + bx2;
-  put(m_->blk_index.encode(xx1 & 255));
-  put(m_->blk_index.encode((xx1 >> 8) & 255));
-  put(m_->blk_index.encode(xx2 & 255));
-  put(m_->blk_index.encode((xx2 >> 8) & 255));
+  put(m_->blk_index.encode(xx1 & 255), 12300);
+  put(m_->blk_index.encode((xx1 >> 8) & 255), 12300);
+  put(m_->blk_index.encode(xx2 & 255), 12300);
+  put(m_->blk_index.encode((xx2 >> 8) & 255), 12300);
 
   int oldt = -1, n = -1;
   for (int b = xx1; b <= xx2; b++) {  // block-type RLE, :1155-1169
     if (blk_types[b] == oldt && n < 255)
       n++;
     else {
-      if (n > 0) put(m_->blk_run.encode(n));
-      put(m_->blk_type.encode(blk_types[b]));
+      if (n > 0) put(m_->blk_run.encode(n), 12301);
+      put(m_->blk_type.encode(blk_types[b]), 12302);
       oldt = blk_types[b];
       n = 1;
     }
   }
-  put(m_->blk_run.encode(n));
+  put(m_->blk_run.encode(n), 12301);
 
   cx_ = cx1_ = 0;
   int lastmx = 0, lastmy = 0;
@@ -541,20 +544,20 @@ int FrameCodec::encode_inter(uint8_t* src, uint8_t* dst0) {  // CompressP, :1091
       if (!bt) continue;
       int x1 = rect_xy[0][bi], x2 = rect_xy[2][bi], y1 = rect_xy[1][bi], y2 = rect_xy[3][bi];
       if ((bt - 1) & 1) {
-        put(m_->rect[0].encode(x1 - bx * 16));
-        put(m_->rect[1].encode(y1 - by * 16));
-        put(m_->rect[2].encode(x2 - 1 - bx * 16));
-        put(m_->rect[3].encode(y2 - 1 - by * 16));
+        put(m_->rect[0].encode(x1 - bx * 16), 12303);
+        put(m_->rect[1].encode(y1 - by * 16), 12304);
+        put(m_->rect[2].encode(x2 - 1 - bx * 16), 12305);
+        put(m_->rect[3].encode(y2 - 1 - by * 16), 12306);
       }
       if ((bt - 1) & 2) {  // motion vector, :1199-1214
         if (bi > 0 && mv[0][bi] == lastmx && mv[1][bi] == lastmy) {
           Ivl e = {kProbScale / 2, kProbScale / 2};
-          put(e);
+          put(e, 12309);
         } else {
           Ivl e = {kProbScale / 2, 0};
-          put(e);
-          put(m_->motion[0].encode(mv[0][bi] + (int)far_x));
-          put(m_->motion[1].encode(mv[1][bi] + (int)far_y));
+          put(e, 12309);
+          put(m_->motion[0].encode(mv[0][bi] + (int)far_x), 12307);
+          put(m_->motion[1].encode(mv[1][bi] + (int)far_y), 12308);
           lastmx = mv[0][bi];
           lastmy = mv[1][bi];
         }
@@ -566,7 +569,7 @@ int FrameCodec::encode_inter(uint8_t* src, uint8_t* dst0) {  // CompressP, :1091
           int i = y * stride_ + x * 3;
           put_pixel(t, last_t, src + i);
           last_t = t;
-          put(m_->run_len[t].encode(rn));
+          put(m_->run_len[t].encode(rn), 12288 + t);
           if (rn > 1) {
             int q = x - x1 + rn - 1;
             x = q % (x2 - x1) + x1;

@@ -64,6 +64,7 @@ class FrameCodec {  // CScreenCapt<UseANS>
 
   // debugging taps (stage-level known-answer tests)
   std::vector<Ivl> last_entries;     // every coder entry of the last compressed frame
+  std::vector<uint16_t> last_tags;   // model id of each entry: plane*4096+ctx, or 12288+fixed id
   std::vector<uint8_t> last_records; // I: run records; P: per-block run records
   std::vector<uint8_t> blk_types;    // bts
   std::vector<int> rect_xy[4];       // sxy
@@ -85,7 +86,11 @@ class FrameCodec {  // CScreenCapt<UseANS>
   // encoder
   std::vector<Ivl> out_;
   std::vector<uint32_t> band_start_, band_size_;  // tls[]
-  void put(Ivl e) { out_.push_back(e); }
+  std::vector<uint16_t> tags_;
+  void put(Ivl e, int tag) {
+    out_.push_back(e);
+    tags_.push_back((uint16_t)tag);
+  }
   void put_colour(int plane, uint8_t c);
   void put_rgb(const uint8_t* px);           // EncodeRGB
   void put_pixel(int t, int last_t, const uint8_t* px);  // WritePixel

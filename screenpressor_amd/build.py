@@ -1,0 +1,55 @@
+"""Build steps (explicit hipcc / g++ commands, in-tree outputs).
+
+    python -m screenpressor_amd.build            # everything
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+LIB = os.path.join(PKG, "libscpr_amd.so")
+HIP_SRC = os.path.join(PKG, "csrc", "scpr_amd.hip")
+HIP_DEPS = [HIP_SRC, os.path.join(PKG, "csrc", "scpr_kernels.hpp"), os.path.join(PKG, "csrc", "scpr_model.hpp"),
+            os.path.join(ROOT, "include", "scpr_amd.h")]
+
+
+def _stale(out: str, deps: list[str]) -> bool:
+    return not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps)
+
+
+def build_hip(force: bool = False) -> str:
+    """hand-written HIP kernels + C ABI -> screenpressor_amd/libscpr_amd.so (gfx950)"""
+    if force or _stale(LIB, HIP_DEPS):
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result",
+               "-o", LIB, HIP_SRC]
+        subprocess.check_call(cmd)
+    return LIB
+
+
+def build_oracle() -> None:
+    """test infrastructure: the CPU restatement and (where /root/reference exists) oracle/_ref"""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "all"], stdout=subprocess.DEVNULL)
+
+
+def build_host_harness() -> str:
+    """test infrastructure: the kernels' model header compiled for the host"""
+    out = os.path.join(ROOT, "tests", "libhostmodel.so")
+    src = os.path.join(ROOT, "tests", "host_model_harness.cpp")
+    if _stale(out, [src, os.path.join(PKG, "csrc", "scpr_model.hpp")]):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I", os.path.join(PKG, "csrc"), "-o", out, src])
+    return out
+
+
+def build_all(force: bool = False) -> None:
+    build_hip(force)
+    build_oracle()
+    build_host_harness()
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv)
+    print("built", LIB)

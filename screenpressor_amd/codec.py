@@ -1,0 +1,177 @@
+"""Host-side mirror of the reference's ScreenCodec (screencap.h:519-541) over the
+C ABI in include/scpr_amd.h.  Same method names, argument meaning and return
+conventions; device memory is held in torch tensors (plumbing only).
+
+There is no CPU implementation behind this class: if the HIP library is missing
+or no GPU is visible, construction raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_PKG, "libscpr_amd.so")
+
+SCPR_OK, SCPR_E_DEVICE, SCPR_E_PARAM, SCPR_E_BAD_VERSION, SCPR_E_CAPACITY, SCPR_E_STREAM = 0, -1, -2, -3, -4, -5
+EXPORTS = ["scpr_create", "scpr_destroy", "scpr_init", "scpr_deinit", "scpr_crash_happened", "scpr_compress_frame",
+           "scpr_decompress_frame", "scpr_compress_batch", "scpr_decompress_batch", "scpr_last_timing", "scpr_stage_name",
+           "scpr_debug_entries", "scpr_version"]
+
+
+class ScprParams(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in (
+        "width", "height", "bits_per_pixel", "red_mask", "green_mask", "blue_mask",
+        "high_range_x", "high_range_y", "low_range_x", "low_range_y", "loss", "workers")]
+
+
+class BadVersionException(Exception):
+    """screencap.h:86-90"""
+
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise RuntimeError(f"{_LIB_PATH} is missing: build it with `python -m screenpressor_amd.build` "
+                               "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        # torch ships its own libamdhip64.so.7; it must be the one HIP runtime of the process, so it is
+        # loaded first and the library's DT_NEEDED entry binds to it (two runtimes cannot share the GPU).
+        import torch  # noqa: F401
+        L = C.CDLL(_LIB_PATH)
+        L.scpr_create.restype = C.c_void_p
+        L.scpr_create.argtypes = [C.c_int]
+        L.scpr_destroy.argtypes = [C.c_void_p]
+        L.scpr_init.argtypes = [C.c_void_p, C.POINTER(ScprParams)]
+        L.scpr_deinit.argtypes = [C.c_void_p]
+        L.scpr_crash_happened.argtypes = [C.c_void_p]
+        L.scpr_compress_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_int]
+        L.scpr_decompress_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int]
+        L.scpr_compress_batch.restype = C.c_int64
+        L.scpr_compress_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32)]
+        L.scpr_decompress_batch.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_int), C.c_int, C.c_void_p, C.c_int]
+        L.scpr_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int]
+        L.scpr_stage_name.restype = C.c_char_p
+        L.scpr_stage_name.argtypes = [C.c_int]
+        L.scpr_debug_entries.restype = C.c_int64
+        L.scpr_debug_entries.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        L.scpr_version.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+class ScreenCodec:
+    def __init__(self, device: int = 0):
+        self._L = load_library()
+        self._h = self._L.scpr_create(device)
+        if not self._h:
+            raise RuntimeError("scpr_create failed: no usable MI355X/HIP device (this codec has no CPU path)")
+        self.device = device
+        self.params = None
+
+    # ScreenCodec::Init
+    def Init(self, width, height, bits_per_pixel=32, loss=0, workers=1, masks=(0x7C00, 0x3E0, 0x1F),
+             high_range=(256, 256), low_range=(8, 8)):
+        self.params = ScprParams(width, height, bits_per_pixel, masks[0], masks[1], masks[2],
+                                 high_range[0], high_range[1], low_range[0], low_range[1], loss, workers)
+        rc = self._L.scpr_init(self._h, C.byref(self.params))
+        if rc != SCPR_OK:
+            raise ValueError(f"scpr_init failed: {rc}")
+        self.width, self.height, self.bpp, self.loss = width, height, bits_per_pixel, loss
+        self.pitch = width * 4 if bits_per_pixel == 32 else ((width * (bits_per_pixel // 8) + 3) & ~3)
+        self.frame_bytes = self.pitch * height
+        self.max_packet = width * height * 6 + 64  # CompressGetSize, screenpressor.cpp:386-388
+        return self
+
+    def Deinit(self):
+        self._L.scpr_deinit(self._h)
+
+    def CrashHappened(self):
+        self._L.scpr_crash_happened(self._h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.scpr_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _check(rc):
+        if rc == SCPR_E_BAD_VERSION:
+            raise BadVersionException(rc)
+        if rc < 0:
+            raise RuntimeError(f"scpr error {rc}")
+        return rc
+
+    # ScreenCodec::CompressFrame: (bytes, ftype_out); ftype_in 0 = key frame wanted, 1 = P allowed
+    def CompressFrame(self, frame: np.ndarray, ftype: int = 1, loss: int | None = None):
+        src = np.ascontiguousarray(frame, dtype=np.uint8).reshape(-1)
+        assert src.size == self.frame_bytes, (src.size, self.frame_bytes)
+        dst = np.empty(self.max_packet, dtype=np.uint8)
+        ft = C.c_int(ftype)
+        n = self._check(self._L.scpr_compress_frame(self._h, src.ctypes.data_as(C.c_void_p), dst.ctypes.data_as(C.c_void_p),
+                                                    dst.size, C.byref(ft), self.loss if loss is None else loss))
+        return bytes(dst[:n]), ft.value
+
+    # ScreenCodec::DecompressFrame: (ret, frame bytes)
+    def DecompressFrame(self, data: bytes, ftype: int, pitch: int | None = None):
+        pitch = self.pitch if pitch is None else pitch
+        out = np.zeros(pitch * self.height, dtype=np.uint8)
+        buf = np.frombuffer(bytes(data), dtype=np.uint8)
+        r = self._check(self._L.scpr_decompress_frame(self._h, buf.ctypes.data_as(C.c_void_p), len(data),
+                                                      out.ctypes.data_as(C.c_void_p), pitch, ftype))
+        return r, out
+
+    # batch entry points: torch uint8 CUDA tensors in, out
+    def CompressBatch(self, frames, ftypes, loss: int | None = None, out=None):
+        import torch
+        n = frames.shape[0]
+        assert frames.is_cuda and frames.dtype == torch.uint8 and frames.is_contiguous() and frames.numel() == n * self.frame_bytes
+        if out is None:
+            out = torch.empty(min(n * self.max_packet, max(64 << 20, n * self.frame_bytes // 2)), dtype=torch.uint8, device=frames.device)
+        ft = (C.c_int * n)(*[int(x) for x in ftypes])
+        sizes = (C.c_uint32 * n)()
+        torch.cuda.synchronize(frames.device)
+        total = self._check(self._L.scpr_compress_batch(self._h, C.c_void_p(frames.data_ptr()), n, ft, self.loss if loss is None else loss,
+                                                        C.c_void_p(out.data_ptr()), out.numel(), sizes))
+        return out[:total], np.frombuffer(sizes, dtype=np.uint32).copy(), list(ft)
+
+    def DecompressBatch(self, packets, sizes, ftypes, pitch: int | None = None, out=None):
+        import torch
+        n = len(sizes)
+        pitch = self.pitch if pitch is None else pitch
+        total = int(np.sum(sizes))
+        if packets.numel() < total + 16:  # the decoder may read a few bytes past the last packet
+            pad = torch.zeros(total + 16, dtype=torch.uint8, device=packets.device)
+            pad[:total] = packets[:total]
+            packets = pad
+        if out is None:
+            out = torch.empty(n * pitch * self.height, dtype=torch.uint8, device=packets.device)
+        sz = (C.c_uint32 * n)(*[int(x) for x in sizes])
+        ft = (C.c_int * n)(*[int(x) for x in ftypes])
+        torch.cuda.synchronize(packets.device)
+        r = self._check(self._L.scpr_decompress_batch(self._h, C.c_void_p(packets.data_ptr()), sz, ft, n, C.c_void_p(out.data_ptr()), pitch))
+        return r, out
+
+    def last_timing(self):
+        tot = C.c_float()
+        st = (C.c_float * 32)()
+        k = self._L.scpr_last_timing(self._h, C.byref(tot), st, 32)
+        return tot.value, {self._L.scpr_stage_name(i).decode(): st[i] for i in range(k)}
+
+    def debug_entries(self):
+        n = self._L.scpr_debug_entries(self._h, None, 0)
+        out = np.zeros((max(n, 0), 2), dtype=np.uint16)
+        if n > 0:
+            self._L.scpr_debug_entries(self._h, out.ctypes.data_as(C.c_void_p), n)
+        return out

@@ -1,0 +1,957 @@
+// HIP kernels of the MI355X-native ScreenPressor path (gfx950, wave64).
+//
+// Encoder pipeline for a batch of frames resident in HBM:
+//   k_pack*           RGB32/24/16 -> packed RGB24 planes, flat-frame detection     (screencap.cpp:1652-1678, :1436-1444)
+//   k_tiles<false>    per 1024-pixel tile: predictor type + "fits" bitmaps via
+//                     wave ballots, greedy-run successor of every pixel, pointer
+//                     doubling in LDS -> exit map for every possible entry       (ClassifyPixelsI, :876-919)
+//   k_entries         chase the tile entries through the exit maps (one wave/frame)
+//   k_tiles<true>     same tiles again, mark the run starts on the real path, emit run records
+//   k_header          runs of the first row + pixel (0,1)                           (CompressI, :344-362)
+//   k_scan_tiles / k_bases   prefix sums -> run / symbol / colour-symbol offsets
+//   k_symbols         unified run list + (context,value,position) of every colour symbol   (WritePixel/EncodeRGB, :609-643)
+//   (rocPRIM)         stable radix sort of colour symbols by (generation, plane, context)
+//   k_fixed_chain     one wave per fixed-alphabet context: epoch-parallel lookups,
+//                     LDS-resident table, wave prefix-scan rebuilds                  (FixedSizeRansCtx, ans_contexts.h:1054-1132)
+//   k_colour_chain    one lane per colour context: the 7-kind state machine         (Context, ans_contexts.cpp:34-50)
+//   k_rans            one lane per 131072-entry block: byte-wise rANS, reverse order (ransmt.h:116-134, rans_byte.h:59-102)
+//   k_offsets/k_gather  packet assembly
+// Decoder: k_decode_intra (one wave per key frame, serial symbol chain) + k_unpack*.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "scpr_model.hpp"
+
+namespace scpr {
+
+typedef uint8_t u8;
+typedef uint16_t u16;
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+constexpr int TILE = 1024;      // pixels per classification tile
+constexpr int HALO = 255;       // a run is at most 255 pixels
+constexpr int EXITED = 2047;    // successor beyond the frame end
+constexpr int NCOLCTX = 3 * 4096;
+constexpr int NFIXED_I = 12;    // pixel-type[6] + run-length[6]
+constexpr int RANS_SCRATCH = 2 * kBlockEntries + 8;
+
+struct Geom {
+  int W, H, S, NP;   // width, height, RGB24 stride, pixels
+  int p0;            // first classified raster pixel: (1,1)
+  int ntiles;
+  int workers;
+  u32 plane_stride;  // bytes between planes (H*S rounded up + slack)
+};
+
+// run record of the unified run list
+//   bits 0-2 type, 3-5 previous type, 8-15 n, 31 header run (no pixel-type symbol)
+__device__ __forceinline__ u32 make_run(int type, int lastt, int n, bool hdr) {
+  return (u32)type | ((u32)lastt << 3) | ((u32)n << 8) | (hdr ? 0x80000000u : 0u);
+}
+
+__device__ __forceinline__ u32 ld3(const u8* p) {  // three bytes, little endian
+  u32 v;
+  __builtin_memcpy(&v, p, 4);
+  return v & 0xFFFFFFu;
+}
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ u64 lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+
+// ------------------------------------------------------------------ pack ---
+// RGB32 -> RGB24 plane (alpha dropped), 4 pixels (16 B in, 12 B out) per lane.
+// flat[f] is set when any pixel differs from pixel 0; first[f] = pixel 0.
+__global__ __launch_bounds__(256) void k_pack32(const u8* __restrict__ src, u8* __restrict__ planes, Geom g, u32* flat, u32* first) {
+  const int f = blockIdx.y, G = (g.W + 3) >> 2;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= g.H * G) return;
+  const int y = idx / G, gx = idx - y * G;
+  const u32* s = (const u32*)(src + (size_t)f * g.W * g.H * 4 + (size_t)y * g.W * 4) + gx * 4;
+  const u32 px0 = *(const u32*)(src + (size_t)f * g.W * g.H * 4) & 0xFFFFFFu;
+  const int nv = min(4, g.W - gx * 4);
+  u32 a = s[0] & 0xFFFFFFu, b = nv > 1 ? s[1] & 0xFFFFFFu : 0, c = nv > 2 ? s[2] & 0xFFFFFFu : 0, d = nv > 3 ? s[3] & 0xFFFFFFu : 0;
+  bool diff = a != px0 || (nv > 1 && b != px0) || (nv > 2 && c != px0) || (nv > 3 && d != px0);
+  if (diff && flat[f] == 0) atomicOr(&flat[f], 1u);
+  if (idx == 0) first[f] = px0;
+  u32* o = (u32*)(planes + (size_t)f * g.plane_stride + (size_t)y * g.S) + gx * 3;
+  const int room = g.S - gx * 12;  // bytes left in the row: 4, 8 or >= 12
+  o[0] = a | (b << 24);
+  if (room > 4) o[1] = (b >> 8) | (c << 16);
+  if (room > 8) o[2] = (c >> 16) | (d << 8);
+}
+
+// RGB24 rows (pitch = S) -> plane copy with zeroed row padding
+__global__ __launch_bounds__(256) void k_pack24(const u8* __restrict__ src, u8* __restrict__ planes, Geom g, u32* flat, u32* first) {
+  const int f = blockIdx.y, G = g.S >> 2;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= g.H * G) return;
+  const int y = idx / G, gx = idx - y * G;
+  const u8* row = src + (size_t)f * g.S * g.H + (size_t)y * g.S;
+  u32 v = ((const u32*)row)[gx];
+  const int valid = g.W * 3 - gx * 4;  // bytes of this dword that are pixel data
+  if (valid < 4) v &= (valid <= 0) ? 0u : ((1u << (8 * valid)) - 1u);
+  const u8* p0 = src + (size_t)f * g.S * g.H;
+  bool diff = false;
+  for (int k = 0; k < 4 && k < valid; k++) {
+    int byte = gx * 4 + k;
+    diff |= (u8)(v >> (8 * k)) != p0[byte % 3];
+  }
+  if (diff && flat[f] == 0) atomicOr(&flat[f], 1u);
+  if (idx == 0) first[f] = ld3(p0);
+  ((u32*)(planes + (size_t)f * g.plane_stride + (size_t)y * g.S))[gx] = v;
+}
+
+// RGB16 -> plane through the caller's channel masks (screencap.cpp:1665-1678)
+__global__ __launch_bounds__(256) void k_pack16(const u8* __restrict__ src, u8* __restrict__ planes, Geom g, u32* flat, u32* first,
+                                                u32 rm, u32 gm, u32 bm, int rs, int gs, int bs) {
+  const int f = blockIdx.y;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= g.H * g.W) return;
+  const int y = idx / g.W, x = idx - y * g.W;
+  const int pitch = (g.W * 2 + 3) & ~3;
+  const u8* fr = src + (size_t)f * pitch * g.H;
+  auto conv = [&](u32 w) { return ((w & rm) >> rs) | (((w & gm) >> gs) << 8) | (((w & bm) >> bs) << 16); };
+  u32 w = *(const u16*)(fr + (size_t)y * pitch + x * 2);
+  u32 v = conv(w) & 0xFFFFFFu, v0 = conv(*(const u16*)fr) & 0xFFFFFFu;
+  if (v != v0 && flat[f] == 0) atomicOr(&flat[f], 1u);
+  if (idx == 0) first[f] = v0;
+  u8* o = planes + (size_t)f * g.plane_stride + (size_t)y * g.S + x * 3;
+  o[0] = (u8)v;
+  o[1] = (u8)(v >> 8);
+  o[2] = (u8)(v >> 16);
+  if (x == g.W - 1)
+    for (int k = g.W * 3; k < g.S; k++) (planes + (size_t)f * g.plane_stride + (size_t)y * g.S)[k] = 0;
+}
+
+// lossy pre-quantisation on the plane's dwords, then padding back to zero
+// (DoLoss, screencap.cpp:201-220, :852-861)
+__global__ __launch_bounds__(256) void k_loss(u8* planes, Geom g, const int* slots, u32 loss_mask, u32 corr_mask) {
+  const int slot = slots[blockIdx.y], G = g.S >> 2;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= g.H * G) return;
+  const int y = idx / G, gx = idx - y * G;
+  u32* row = (u32*)(planes + (size_t)slot * g.plane_stride + (size_t)y * g.S);
+  u32 v = (row[gx] & loss_mask) | corr_mask;
+  const int valid = g.W * 3 - gx * 4;
+  if (valid < 4) v &= (valid <= 0) ? 0u : ((1u << (8 * valid)) - 1u);
+  row[gx] = v;
+}
+
+// plane -> RGB32 with alpha 255 (screencap.cpp:1711-1725), 4 pixels per lane
+__global__ __launch_bounds__(256) void k_unpack32(const u8* __restrict__ planes, u8* __restrict__ dst, Geom g, int pitch) {
+  const int f = blockIdx.y, G = (g.W + 3) >> 2;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= g.H * G) return;
+  const int y = idx / G, gx = idx - y * G;
+  const u32* s = (const u32*)(planes + (size_t)f * g.plane_stride + (size_t)y * g.S) + gx * 3;
+  const int room = g.S - gx * 12;
+  u32 w0 = s[0], w1 = room > 4 ? s[1] : 0, w2 = room > 8 ? s[2] : 0;
+  u32* o = (u32*)(dst + (size_t)f * pitch * g.H + (size_t)y * pitch) + gx * 4;
+  const int nv = min(4, g.W - gx * 4);
+  o[0] = (w0 & 0xFFFFFFu) | 0xFF000000u;
+  if (nv > 1) o[1] = ((w0 >> 24) | ((w1 & 0xFFFFu) << 8)) | 0xFF000000u;
+  if (nv > 2) o[2] = ((w1 >> 16) | ((w2 & 0xFFu) << 16)) | 0xFF000000u;
+  if (nv > 3) o[3] = (w2 >> 8) | 0xFF000000u;
+}
+// plane -> RGB24 rows with the caller's pitch / RGB16 (screencap.cpp:1726-1737)
+__global__ __launch_bounds__(256) void k_unpack_rows(const u8* __restrict__ planes, u8* __restrict__ dst, Geom g, int pitch, int bpp, int rs, int gs, int bs) {
+  const int f = blockIdx.y;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= g.H * g.W) return;
+  const int y = idx / g.W, x = idx - y * g.W;
+  const u8* s = planes + (size_t)f * g.plane_stride + (size_t)y * g.S + x * 3;
+  u8* o = dst + (size_t)f * pitch * g.H + (size_t)y * pitch;
+  if (bpp == 3) {
+    o[x * 3] = s[0];
+    o[x * 3 + 1] = s[1];
+    o[x * 3 + 2] = s[2];
+  } else {
+    *(u16*)(o + x * 2) = (u16)((s[0] << rs) + (s[1] << gs) + (s[2] << bs));
+  }
+}
+
+// ------------------------------------------------------- classification ---
+// Predictor type of raster pixel p (priority 1,5,2,4,0 - GetPixelType,
+// screencap.cpp:502-521) and the set of predictors that fit it
+// (PixelTypeFits, :560-574): bit0 previous pixel (types 0/1), bit1 top (2),
+// bit2 gradient (4), bit3 top-left (5).
+__device__ __forceinline__ void classify_pixel(const u8* plane, const Geom& g, int p, int& type, int& fits) {
+  const int y = p / g.W, x = p - y * g.W;
+  const u8* c = plane + (size_t)y * g.S + x * 3;
+  const u8* l = x > 0 ? c - 3 : plane + (size_t)(y - 1) * g.S + (g.W - 1) * 3;
+  const u32 vc = ld3(c), vl = ld3(l), vt = ld3(c - g.S), vtl = ld3(c - g.S - 3);
+  const bool e_l = vc == vl, e_t = vc == vt, e_tl = vc == vtl;
+  bool gr = true;
+#pragma unroll
+  for (int k = 0; k < 24; k += 8) gr &= (int)((vc >> k) & 255) == (int)((vl >> k) & 255) + (int)((vt >> k) & 255) - (int)((vtl >> k) & 255);
+  fits = (e_l ? 1 : 0) | (e_t ? 2 : 0) | (gr ? 4 : 0) | (e_tl ? 8 : 0);
+  type = e_l ? 1 : e_tl ? 5 : e_t ? 2 : gr ? 4 : 0;
+  // a row band of the reference's worker pool starts a new run (screencap.cpp:365-388)
+  if (x == 0 && g.workers > 1) {
+    int k = (int)(((long long)y * g.workers + g.H - 1) / g.H);
+    if (k > 0 && k < g.workers && (int)((long long)g.H * k / g.workers) == y) fits = 0;
+  }
+}
+__device__ __forceinline__ int fit_bit_of_type(int t) { return t == 2 ? 1 : t == 4 ? 2 : t == 5 ? 3 : 0; }
+
+// number of consecutive set bits starting at bit `start`, at most cap
+__device__ __forceinline__ int ones_from(const u64* row, int start, int cap) {
+  int w = start >> 6, o = start & 63;
+  u64 inv = ~(row[w] >> o);
+  int z = inv ? __builtin_ctzll(inv) : 64;
+  if (z < 64 - o) return min(z, cap);
+  int cnt = 64 - o;
+  w++;
+  while (cnt < cap) {
+    u64 m = ~row[w];
+    if (m) {
+      cnt += __builtin_ctzll(m);
+      break;
+    }
+    cnt += 64;
+    w++;
+  }
+  return min(cnt, cap);
+}
+
+// block-wide exclusive scan of one int per thread (256 threads); total via *tot
+__device__ __forceinline__ int block_excl_scan(int v, int* tot, int* wsum /*shared[5]*/) {
+  const int lane = lane_id(), wave = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    int t = __shfl_up(inc, d);
+    if (lane >= d) inc += t;
+  }
+  __syncthreads();
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  int base = 0;
+  for (int k = 0; k < wave; k++) base += wsum[k];
+  if (tot) *tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  return base + inc - v;
+}
+
+// exit map row: for every entry offset e < 255: [2e] = offset at which the path
+// leaves into the next tile, [2e+1] = type of the run that crosses the border.
+// tilecnt: {runs, literal runs} per tile.   runrec: rel_start | type<<10 | n<<16
+template <bool MARK>
+__global__ __launch_bounds__(256) void k_tiles(const u8* __restrict__ planes, Geom g, const int* __restrict__ slots, u8* __restrict__ exitmap,
+                                               const u8* __restrict__ entry, u32* __restrict__ runrec, u32* __restrict__ tilecnt) {
+  __shared__ u64 fm[4][24];
+  __shared__ u8 ty[TILE];
+  __shared__ u16 lv[MARK ? 10 : 2][TILE];
+  __shared__ u16 ln[MARK ? 1 : 2][MARK ? 1 : TILE];
+  __shared__ u8 mk[MARK ? TILE : 1];
+  __shared__ int wsum[5];
+  const int slot = slots[blockIdx.y], tile = blockIdx.x, tid = threadIdx.x;
+  const u8* plane = planes + (size_t)slot * g.plane_stride;
+  const int tstart = g.p0 + tile * TILE;
+  if (tid < 4 * 24) ((u64*)fm)[tid] = 0;
+  __syncthreads();
+  for (int k = 0; k < 5; k++) {
+    const int r = k * 256 + tid, p = tstart + r;
+    int type = 0, fits = 0;
+    if (r < TILE + HALO && p < g.NP) classify_pixel(plane, g, p, type, fits);
+    if (r < TILE) ty[r] = (u8)type;
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+      u64 m = __ballot((fits >> b) & 1);
+      if (lane_id() == 0) fm[b][r >> 6] = m;
+    }
+  }
+  __syncthreads();
+  for (int k = 0; k < 4; k++) {
+    const int r = k * 256 + tid, p = tstart + r;
+    int j = EXITED;
+    if (p < g.NP) {
+      int n = ones_from(fm[fit_bit_of_type(ty[r])], r + 1, HALO - 1);
+      j = (p + 1 + n >= g.NP) ? EXITED : r + 1 + n;
+    }
+    lv[0][r] = (u16)j;
+    if (!MARK) ln[0][r] = (u16)r;
+  }
+  __syncthreads();
+  if (!MARK) {
+    int cur = 0;
+    for (int it = 0; it < 10; it++) {
+      for (int k = 0; k < 4; k++) {
+        const int r = k * 256 + tid;
+        int j = lv[cur][r], nj = j, nl = ln[cur][r];
+        if (j < TILE) {
+          nj = lv[cur][j];
+          nl = ln[cur][j];
+        }
+        lv[cur ^ 1][r] = (u16)nj;
+        ln[cur ^ 1][r] = (u16)nl;
+      }
+      __syncthreads();
+      cur ^= 1;
+    }
+    if (tid < HALO) {
+      int j = lv[cur][tid];
+      u8* row = exitmap + ((size_t)slot * g.ntiles + tile) * 512;
+      row[2 * tid] = (u8)(j == EXITED ? 255 : j - TILE);  // 255: the path ended inside this tile (frame end)
+      row[2 * tid + 1] = ty[ln[cur][tid]];
+    }
+  } else {
+    for (int lvl = 0; lvl < 9; lvl++) {
+      for (int k = 0; k < 4; k++) {
+        const int r = k * 256 + tid;
+        int j = lv[lvl][r];
+        lv[lvl + 1][r] = (u16)(j < TILE ? lv[lvl][j] : EXITED);
+      }
+      __syncthreads();
+    }
+    const int e = entry[((size_t)slot * g.ntiles + tile) * 2];
+    for (int k = 0; k < 4; k++) mk[k * 256 + tid] = 0;
+    __syncthreads();
+    if (tid == 0 && e < HALO) mk[e] = 1;  // e == 255: a run from an earlier tile already reached the frame end
+    __syncthreads();
+    for (int lvl = 9; lvl >= 0; lvl--) {
+      for (int k = 0; k < 4; k++) {
+        const int r = k * 256 + tid;
+        if (mk[r]) {
+          int j = lv[lvl][r];
+          if (j < TILE) mk[j] = 1;
+        }
+      }
+      __syncthreads();
+    }
+    // emit: thread t owns pixels 4t..4t+3 so that records come out in raster order
+    int cnt = 0, lit = 0;
+    for (int k = 0; k < 4; k++) {
+      const int r = tid * 4 + k;
+      if (mk[r] && tstart + r < g.NP) {
+        cnt++;
+        lit += ty[r] == 0;
+      }
+    }
+    int tot = 0, totlit = 0;
+    int off = block_excl_scan(cnt, &tot, wsum);
+    __syncthreads();
+    block_excl_scan(lit, &totlit, wsum);
+    u32* rec = runrec + ((size_t)slot * g.ntiles + tile) * TILE;
+    for (int k = 0; k < 4; k++) {
+      const int r = tid * 4 + k;
+      if (mk[r] && tstart + r < g.NP) {
+        int j = lv[0][r];
+        int n = (j == EXITED) ? g.NP - (tstart + r) : j - r;
+        rec[off++] = (u32)r | ((u32)ty[r] << 10) | ((u32)n << 16);
+      }
+    }
+    if (tid == 0) {
+      tilecnt[((size_t)slot * g.ntiles + tile) * 2] = (u32)tot;
+      tilecnt[((size_t)slot * g.ntiles + tile) * 2 + 1] = (u32)totlit;
+    }
+  }
+}
+
+// one wave per frame walks its tiles: entry[tile] = {offset of the first run
+// start inside the tile, type of the run active when the tile begins}
+__global__ __launch_bounds__(64) void k_entries(const u8* __restrict__ exitmap, u8* __restrict__ entry, Geom g, const int* __restrict__ slots) {
+  __shared__ u32 buf[64 * 128];
+  const int slot = slots[blockIdx.x], lane = threadIdx.x;
+  int e = 0, tin = 0;
+  for (int base = 0; base < g.ntiles; base += 64) {
+    const int n = min(64, g.ntiles - base);
+    const u32* srcw = (const u32*)(exitmap + ((size_t)slot * g.ntiles + base) * 512);
+    for (int i = lane; i < n * 128; i += 64) buf[i] = srcw[i];
+    __syncthreads();
+    if (lane == 0) {
+      const u8* b8 = (const u8*)buf;
+      for (int k = 0; k < n; k++) {
+        u8* o = entry + ((size_t)slot * g.ntiles + base + k) * 2;
+        o[0] = (u8)e;
+        o[1] = (u8)tin;
+        if (e < HALO) {
+          int ne = b8[k * 512 + 2 * e], nt = b8[k * 512 + 2 * e + 1];
+          e = ne;
+          tin = nt;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// runs of identical pixels over raster pixels 0..W (first row and pixel (0,1)):
+// hdrrec[j] = start | n<<16  (CompressI, screencap.cpp:346-362)
+__global__ __launch_bounds__(64) void k_header(const u8* __restrict__ planes, Geom g, const int* __restrict__ slots, u32* __restrict__ hdrrec, u32* __restrict__ hdrcnt) {
+  __shared__ u64 nq[80];
+  const int slot = slots[blockIdx.x], lane = threadIdx.x;
+  const u8* plane = planes + (size_t)slot * g.plane_stride;
+  const int n = g.W + 1, words = (n + 63) >> 6;
+  for (int w = 0; w < words; w++) {
+    int k = w * 64 + lane;
+    bool ne = false;
+    if (k >= 1 && k < n) {
+      const u8* a = k < g.W ? plane + k * 3 : plane + g.S;
+      const u8* b = plane + (k - 1) * 3;
+      ne = ld3(a) != ld3(b);
+    }
+    u64 m = __ballot(ne);
+    if (lane == 0) nq[w] = m;
+  }
+  __syncthreads();
+  if (lane == 0) {
+    u32* rec = hdrrec + (size_t)slot * (g.W + 2);
+    int start = 0, cnt = 0;
+    while (start < n) {
+      // next position > start with a differing pixel, or start+255
+      int lim = min(n, start + 255), k = start + 1, nxt = lim;
+      while (k < lim) {
+        u64 m = nq[k >> 6] >> (k & 63);
+        if (m) {
+          int z = k + __builtin_ctzll(m);
+          if (z < lim) nxt = z;
+          break;
+        }
+        k = (k | 63) + 1;
+      }
+      rec[cnt++] = (u32)start | ((u32)(nxt - start) << 16);
+      start = nxt;
+    }
+    hdrcnt[slot] = (u32)cnt;
+  }
+}
+
+// per frame: exclusive scans of {runs, literals} over its tiles
+__global__ __launch_bounds__(256) void k_scan_tiles(const u32* __restrict__ tilecnt, u32* __restrict__ tileoff, u32* __restrict__ frametot, Geom g, const int* __restrict__ slots) {
+  __shared__ int wsum[5];
+  const int slot = slots[blockIdx.x], tid = threadIdx.x;
+  int run_base = 0, lit_base = 0;
+  for (int base = 0; base < g.ntiles; base += 256) {
+    int t = base + tid;
+    int r = t < g.ntiles ? (int)tilecnt[((size_t)slot * g.ntiles + t) * 2] : 0;
+    int l = t < g.ntiles ? (int)tilecnt[((size_t)slot * g.ntiles + t) * 2 + 1] : 0;
+    int tr = 0, tl = 0;
+    int ro = block_excl_scan(r, &tr, wsum);
+    __syncthreads();
+    int lo = block_excl_scan(l, &tl, wsum);
+    __syncthreads();
+    if (t < g.ntiles) {
+      tileoff[((size_t)slot * g.ntiles + t) * 2] = (u32)(run_base + ro);
+      tileoff[((size_t)slot * g.ntiles + t) * 2 + 1] = (u32)(lit_base + lo);
+    }
+    run_base += tr;
+    lit_base += tl;
+  }
+  if (tid == 0) {
+    frametot[slot * 2] = (u32)run_base;
+    frametot[slot * 2 + 1] = (u32)lit_base;
+  }
+}
+
+// per batch: frame bases (one small block).  bases[f] = {run_base, sym_base, col_base, nsyms}
+struct FrameBase {
+  u32 run_base, sym_base, col_base, nsyms, nruns, ncol, pad0, pad1;
+};
+__global__ void k_bases(const u32* __restrict__ frametot, const u32* __restrict__ hdrcnt, const int* __restrict__ slots, int nfr, FrameBase* __restrict__ bases, u32* __restrict__ totals) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  u32 rb = 0, sb = 0, cb = 0;
+  for (int i = 0; i < nfr; i++) {
+    int slot = slots[i];
+    u32 R = frametot[slot * 2], L = frametot[slot * 2 + 1], Hr = hdrcnt[slot];
+    FrameBase b;
+    b.run_base = rb;
+    b.sym_base = sb;
+    b.col_base = cb;
+    b.nruns = Hr + R;
+    b.nsyms = 4 * Hr + 2 * R + 3 * L;
+    b.ncol = 3 * (Hr + L);
+    b.pad0 = Hr;
+    b.pad1 = 0;
+    bases[i] = b;
+    rb += b.nruns;
+    sb += b.nsyms;
+    cb += b.ncol;
+  }
+  totals[0] = rb;
+  totals[1] = sb;
+  totals[2] = cb;
+}
+
+// colour context ids from the two previous bytes (SC_CXSHIFT = 2, MAKECX1,
+// screencap.h:35-36; WritePixel/EncodeRGB, screencap.cpp:609-643)
+__device__ __forceinline__ void emit_colour(u32 gen, u32 pix, u32 prev_g, u32 prev_b, u32 pos, u32 idx, u32* __restrict__ keys, u32* __restrict__ vals, u32* __restrict__ hist) {
+  const u32 c0 = pix & 255, c1 = (pix >> 8) & 255, c2 = (pix >> 16) & 255;
+  const u32 cx0 = (prev_b >> 2) | ((prev_g >> 2) << 6);
+  const u32 cx1 = (c0 >> 2) | ((prev_b >> 2) << 6);
+  const u32 cx2 = (c1 >> 2) | ((c0 >> 2) << 6);
+  const u32 k0 = cx0, k1 = 4096 + cx1, k2 = 8192 + cx2;
+  keys[idx] = (gen << 22) | (k0 << 8) | c0;
+  keys[idx + 1] = (gen << 22) | (k1 << 8) | c1;
+  keys[idx + 2] = (gen << 22) | (k2 << 8) | c2;
+  vals[idx] = pos;
+  vals[idx + 1] = pos + 1;
+  vals[idx + 2] = pos + 2;
+  atomicAdd(&hist[gen * NCOLCTX + k0], 1u);
+  atomicAdd(&hist[gen * NCOLCTX + k1], 1u);
+  atomicAdd(&hist[gen * NCOLCTX + k2], 1u);
+}
+
+// unified run list + colour symbols.  grid = (ntiles + 1, frames); the extra
+// block handles the header runs.
+__global__ __launch_bounds__(256) void k_symbols(const u8* __restrict__ planes, Geom g, const int* __restrict__ slots, const int* __restrict__ gens,
+                                                 const FrameBase* __restrict__ bases, const u32* __restrict__ runrec, const u32* __restrict__ tilecnt,
+                                                 const u32* __restrict__ tileoff, const u8* __restrict__ entry, const u32* __restrict__ hdrrec,
+                                                 u32* __restrict__ runs, u32* __restrict__ runpos, u32* __restrict__ keys, u32* __restrict__ vals, u32* __restrict__ hist) {
+  __shared__ int wsum[5];
+  const int fi = blockIdx.y, slot = slots[fi], tid = threadIdx.x;
+  const u32 gen = (u32)gens[fi];
+  const FrameBase fb = bases[fi];
+  const u8* plane = planes + (size_t)slot * g.plane_stride;
+  const u32 Hr = fb.pad0;
+  if ((int)blockIdx.x == g.ntiles) {  // header runs: C C C N each, no pixel-type symbol
+    const u32* rec = hdrrec + (size_t)slot * (g.W + 2);
+    for (u32 j = tid; j < Hr; j += 256) {
+      u32 r = rec[j], start = r & 0xFFFF, n = r >> 16;
+      u32 pos = fb.sym_base + 4 * j;
+      runs[fb.run_base + j] = make_run(0, 0, (int)n, true);
+      runpos[fb.run_base + j] = pos;
+      const u8* px = start < (u32)g.W ? plane + start * 3 : plane + g.S;
+      u32 pg = 0, pb = 0;
+      if (start > 0) {  // previous pixel in raster order (start <= W, so it is in row 0)
+        const u8* pp = plane + (start - 1) * 3;
+        pg = pp[1];
+        pb = pp[2];
+      }
+      emit_colour(gen, ld3(px), pg, pb, pos, fb.col_base + 3 * j, keys, vals, hist);
+    }
+    return;
+  }
+  const int tile = blockIdx.x;
+  const size_t ti = (size_t)slot * g.ntiles + tile;
+  const int cnt = (int)tilecnt[ti * 2];
+  const u32 run_off = tileoff[ti * 2], lit_off = tileoff[ti * 2 + 1];
+  const u32* rec = runrec + ti * TILE;
+  const int tstart = g.p0 + tile * TILE;
+  int lit_run = 0;  // literals in earlier chunks of this tile
+  for (int base = 0; base < cnt; base += 256) {
+    const int i = base + tid;
+    u32 r = 0;
+    int type = -1, lastt = 0;
+    if (i < cnt) {
+      r = rec[i];
+      type = (r >> 10) & 7;
+      lastt = i > 0 ? (int)((rec[i - 1] >> 10) & 7) : (int)entry[ti * 2 + 1];
+    }
+    int tl = 0;
+    int lrank = block_excl_scan(type == 0 ? 1 : 0, &tl, wsum);
+    __syncthreads();
+    if (i < cnt) {
+      const u32 n = r >> 16, rel = r & 1023;
+      const u32 litidx = lit_off + lit_run + lrank;
+      const u32 pos = fb.sym_base + 4 * Hr + 2 * (run_off + i) + 3 * litidx;
+      const u32 ri = fb.run_base + Hr + run_off + i;
+      runs[ri] = make_run(type, lastt, (int)n, false);
+      runpos[ri] = pos;
+      if (type == 0) {
+        const int p = tstart + (int)rel;
+        const int y = p / g.W, x = p - y * g.W;
+        const u8* px = plane + (size_t)y * g.S + x * 3;
+        const u8* pp = x > 0 ? px - 3 : plane + (size_t)(y - 1) * g.S + (g.W - 1) * 3;
+        emit_colour(gen, ld3(px), pp[1], pp[2], pos + 1, fb.col_base + 3 * (Hr + litidx), keys, vals, hist);
+      }
+    }
+    lit_run += tl;
+  }
+}
+
+// --------------------------------------------------------- fixed chains ---
+// One wave per (generation, fixed context).  The table only changes when the
+// running total crosses the scale, so all symbols up to that point are
+// independent lookups; the rebuild is a wave prefix-scan.
+// cls 0..5: pixel-type model keyed by the previous type; 6..11: run-length
+// model keyed by the type.
+struct GenRange {
+  u32 run_begin, run_end;
+};
+__global__ __launch_bounds__(64) void k_fixed_chain(const u32* __restrict__ runs, const u32* __restrict__ runpos, const GenRange* __restrict__ ranges,
+                                                    u32* __restrict__ entries) {
+  __shared__ u32 freq[256], cum[256], cnt[256];
+  const int cls = blockIdx.x, gen = blockIdx.y, lane = threadIdx.x;
+  const bool is_n = cls >= 6;
+  const int key = is_n ? cls - 6 : cls, nsym = is_n ? 256 : 6;
+  {
+    const int fr = kProbScale / nsym, c0 = fr - (fr >> 1);
+    for (int j = lane; j < nsym; j += 64) {
+      freq[j] = fr;
+      cum[j] = fr * j;
+      cnt[j] = c0;
+    }
+  }
+  int total = (kProbScale / nsym - ((kProbScale / nsym) >> 1)) * nsym;
+  __syncthreads();
+  const GenRange rg = ranges[gen];
+  for (u32 base = rg.run_begin; base < rg.run_end; base += 64) {
+    const u32 i = base + lane;
+    bool sel = false;
+    u32 sym = 0, pos = 0;
+    if (i < rg.run_end) {
+      const u32 r = runs[i];
+      const int type = r & 7, lastt = (r >> 3) & 7;
+      const bool hdr = r >> 31;
+      if (is_n) {
+        sel = type == key;
+        sym = (r >> 8) & 255;
+        pos = runpos[i] + (hdr ? 3 : (type == 0 ? 4 : 1));
+      } else {
+        sel = !hdr && lastt == key;
+        sym = type;
+        pos = runpos[i];
+      }
+    }
+    const u64 m = __ballot(sel);
+    const int rank = __builtin_popcountll(m & lanemask_lt()), cntm = __builtin_popcountll(m);
+    int done = 0;
+    while (done < cntm) {
+      const int room = (kProbScale - kStepDense - total) / kStepDense + 1;
+      const int take = min(room, cntm - done);
+      if (sel && rank >= done && rank < done + take) {
+        entries[pos] = freq[sym] | (cum[sym] << 16);
+        atomicAdd(&cnt[sym], (u32)kStepDense);
+      }
+      total += kStepDense * take;
+      done += take;
+      __syncthreads();
+      if (take == room) {  // counts become the frequencies (incrCnt, ans_contexts.h:1075-1090)
+        const int per = (nsym + 63) >> 6, j0 = lane * per;
+        int s = 0;
+        for (int j = j0; j < j0 + per && j < nsym; j++) s += cnt[j];
+        int inc = s;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          int t = __shfl_up(inc, d);
+          if (lane >= d) inc += t;
+        }
+        int cf = inc - s, ns = 0;
+        for (int j = j0; j < j0 + per && j < nsym; j++) {
+          int fr = cnt[j];
+          cum[j] = cf;
+          freq[j] = fr;
+          cf += fr;
+          fr -= fr >> 1;
+          cnt[j] = fr;
+          ns += fr;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) ns += __shfl_xor(ns, d);
+        total = ns;
+        __syncthreads();
+      }
+    }
+  }
+}
+
+// -------------------------------------------------------- colour chains ---
+struct Arena {
+  DenseTab* tabs;
+  u32* top;
+  u32 cap;
+  u32* err;
+};
+__device__ __forceinline__ DenseTab* arena_alloc(const Arena& a, ColState& st) {
+  u32 idx = atomicAdd(a.top, 1u);
+  if (idx >= a.cap) {
+    atomicOr(a.err, 1u);
+    idx = 0;
+  }
+  st.dense = idx;
+  return a.tabs + idx;
+}
+
+// one lane per (generation, plane, context): walks its symbols in stream order
+__global__ __launch_bounds__(64) void k_colour_chain(const u32* __restrict__ skeys, const u32* __restrict__ svals, const u32* __restrict__ cstart, int nchains,
+                                                     int f0, Arena arena, u32* __restrict__ entries) {
+  const int q = blockIdx.x * 64 + threadIdx.x;
+  if (q >= nchains) return;
+  const u32 start = cstart[q], len = cstart[q + 1] - start;
+  if (!len) return;
+  ColState st;
+  col_reset(st);
+  auto alloc = [&](ColState& s) { return arena_alloc(arena, s); };
+  auto tab = [&](ColState& s) { return arena.tabs + s.dense; };
+  for (u32 i = 0; i < len; i++) {
+    const u32 k = skeys[start + i];
+    Ivl e = col_encode(st, (u8)(k & 255), f0, alloc, tab);
+    entries[svals[start + i]] = (u32)e.freq | ((u32)e.cum << 16);
+  }
+}
+
+// ------------------------------------------------------------------ rANS ---
+struct RansBlock {
+  u32 begin, len;
+};
+// One lane per block of <= 131072 entries, processed last to first; bytes are
+// written backwards into the block's scratch (ransmt.h:116-134).  x / freq uses
+// the exact 32-bit reciprocal (rans_byte.h:171-240).
+__global__ __launch_bounds__(64) void k_rans(const u32* __restrict__ entries, const RansBlock* __restrict__ blocks, int nblocks, const RansRcp* __restrict__ rcp,
+                                             u8* __restrict__ scratch, u32* __restrict__ blksize) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= nblocks) return;
+  const RansBlock blk = blocks[b];
+  u8* const end = scratch + (size_t)(b + 1) * RANS_SCRATCH;
+  u8* p = end;
+  u32 x = kRansL;
+  const u32* e = entries + blk.begin;
+  for (int i = (int)blk.len - 1; i >= 0; i--) {
+    const u32 v = e[i], fr = v & 0xFFFF, cf = v >> 16;
+    if (fr) {
+      const u32 x_max = fr << 19;  // ((L >> 12) << 8) * freq
+      while (x >= x_max) {
+        *--p = (u8)x;
+        x >>= 8;
+      }
+      const RansRcp r = rcp[fr];
+      const u32 q = fr == 1 ? x : (__umulhi(x, r.rcp) >> r.shift);
+      x = (q << kProbBits) + (x - q * fr) + cf;
+    } else {
+      *--p = (u8)cf;
+    }
+  }
+  p -= 4;
+  p[0] = (u8)x;
+  p[1] = (u8)(x >> 8);
+  p[2] = (u8)(x >> 16);
+  p[3] = (u8)(x >> 24);
+  blksize[b] = (u32)(end - p);
+}
+
+// ---------------------------------------------------------------- gather ---
+struct Packet {
+  u32 hdr_len;     // bytes in front of the coded blocks (1..4)
+  u32 hdr;         // those bytes, little endian
+  u32 blk_begin, blk_count;
+};
+// sizes[f], pktoff[f], blkdst[b]; totals[3] = total bytes
+__global__ __launch_bounds__(256) void k_offsets(const Packet* __restrict__ pk, int nfr, const u32* __restrict__ blksize, u32* __restrict__ sizes, u64* __restrict__ pktoff,
+                                                 u64* __restrict__ blkdst, u64* __restrict__ total) {
+  __shared__ int wsum[5];
+  __shared__ u64 carry;
+  const int tid = threadIdx.x;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < nfr; base += 256) {
+    const int f = base + tid;
+    int sz = 0;
+    if (f < nfr) {
+      sz = (int)pk[f].hdr_len;
+      for (u32 b = 0; b < pk[f].blk_count; b++) sz += (int)blksize[pk[f].blk_begin + b];
+    }
+    int tot = 0;
+    int off = block_excl_scan(sz, &tot, wsum);
+    __syncthreads();
+    if (f < nfr) {
+      u64 o = carry + (u64)off;
+      sizes[f] = (u32)sz;
+      pktoff[f] = o;
+      o += pk[f].hdr_len;
+      for (u32 b = 0; b < pk[f].blk_count; b++) {
+        blkdst[pk[f].blk_begin + b] = o;
+        o += blksize[pk[f].blk_begin + b];
+      }
+    }
+    __syncthreads();
+    if (tid == 0) carry += (u64)tot;
+    __syncthreads();
+  }
+  if (tid == 0) *total = carry;
+}
+// grid.x = nblocks + nframes: copies a coded block, or writes a packet header
+__global__ __launch_bounds__(256) void k_gather(const Packet* __restrict__ pk, int nfr, int nblocks, const u8* __restrict__ scratch, const u32* __restrict__ blksize,
+                                                const u64* __restrict__ pktoff, const u64* __restrict__ blkdst, u8* __restrict__ out, u64 out_cap, u32* __restrict__ err) {
+  const int b = blockIdx.x;
+  if (b < nblocks) {
+    const u32 sz = blksize[b];
+    const u8* s = scratch + (size_t)(b + 1) * RANS_SCRATCH - sz;
+    const u64 d = blkdst[b];
+    if (d + sz > out_cap) {
+      if (threadIdx.x == 0) atomicOr(err, 2u);
+      return;
+    }
+    for (u32 i = threadIdx.x; i < sz; i += 256) out[d + i] = s[i];
+  } else {
+    const int f = b - nblocks;
+    if (f < nfr && threadIdx.x < pk[f].hdr_len) {
+      const u64 d = pktoff[f] + threadIdx.x;
+      if (d < out_cap) out[d] = (u8)(pk[f].hdr >> (8 * threadIdx.x));
+      else atomicOr(err, 2u);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- decode ---
+struct DecFrame {
+  u64 src_off;   // packet offset in the packet buffer
+  u32 src_len;
+  int slot;      // destination plane
+  int kind;      // 0 = coded key frame, 1 = flat key frame
+};
+// One wave per key frame; lane 0 walks the symbol chain (DecompressI,
+// screencap.cpp:414-498), the fixed tables live in LDS.
+__global__ __launch_bounds__(64) void k_decode_intra(const u8* __restrict__ packets, const DecFrame* __restrict__ frames, u8* __restrict__ planes, Geom g,
+                                                     ColState* __restrict__ states, Arena arena, int f0, u32* __restrict__ status) {
+  __shared__ FixedTab<256> nt[6];
+  __shared__ FixedTab<8> pt[6];
+  const DecFrame fr = frames[blockIdx.x];
+  u8* dst = planes + (size_t)fr.slot * g.plane_stride;
+  ColState* cs = states + (size_t)blockIdx.x * NCOLCTX;
+  for (int i = threadIdx.x; i < NCOLCTX; i += 64) col_reset(cs[i]);
+  if (threadIdx.x < 6) {
+    fixed_reset(nt[threadIdx.x], 256);
+    fixed_reset(pt[threadIdx.x], 6);
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  const u8* in = packets + fr.src_off + 1;  // skip the frame header byte
+  const u8* const in_end = packets + fr.src_off + fr.src_len + 8;
+  u32 x = (u32)in[0] | ((u32)in[1] << 8) | ((u32)in[2] << 16) | ((u32)in[3] << 24);
+  in += 4;
+  int ndec = 0;
+  u32 cx = 0, cx1 = 0;
+  bool bad = false;
+  auto advance = [&](u32 start, u32 freq) {  // RansDecAdvance, rans_byte.h:130-146
+    x = freq * (x >> kProbBits) + (x & (kProbScale - 1)) - start;
+    while (x < kRansL && in < in_end) x = (x << 8) | *in++;
+  };
+  auto count = [&]() {  // screencap.h:327-331
+    if (++ndec == kBlockEntries) {
+      x = (u32)in[0] | ((u32)in[1] << 8) | ((u32)in[2] << 16) | ((u32)in[3] << 24);
+      in += 4;
+      ndec = 0;
+    }
+  };
+  auto alloc = [&](ColState& s) { return arena_alloc(arena, s); };
+  auto tab = [&](ColState& s) { return arena.tabs + s.dense; };
+  auto get_colour = [&](int plane) -> int {  // decodeC, screencap.h:318-333
+    ColState& st = cs[plane * 4096 + ((cx + cx1) & 4095)];
+    Ivl e;
+    u8 c = 0;
+    if (col_decode(st, (int)(x & (kProbScale - 1)), c, e, alloc, tab))
+      advance(e.cum, e.freq);
+    else {
+      c = *in++;
+      col_note_raw(st, c, f0, alloc);
+    }
+    count();
+    return c;
+  };
+  auto next_cx = [&](int v) {
+    cx1 = (cx << 6) & 0xFC0;
+    cx = (u32)v >> 2;
+  };
+  auto get_rgb = [&](int& r, int& gg, int& b) {
+    r = get_colour(0);
+    next_cx(r);
+    gg = get_colour(1);
+    next_cx(gg);
+    b = get_colour(2);
+    next_cx(b);
+  };
+  auto get_n = [&](int t) {
+    Ivl e;
+    int c = fixed_decode(nt[t], (int)(x & (kProbScale - 1)), e);
+    advance(e.cum, e.freq);
+    count();
+    return c;
+  };
+  auto get_p = [&](int t) {
+    Ivl e;
+    int c = fixed_decode(pt[t], (int)(x & (kProbScale - 1)), e);
+    advance(e.cum, e.freq);
+    count();
+    return c;
+  };
+  const int W = g.W, H = g.H, S = g.S;
+  int r = 0, gg = 0, b = 0;
+  int t = 0, last_t = 0, i = 0, n = 1, k = 0, lasti = 0;
+  while (k < W + 1 && !bad) {
+    get_rgb(r, gg, b);
+    n = get_n(t);
+    if (n < 1 || k + n > W + 1) {
+      bad = true;
+      break;
+    }
+    for (int q = 0; q < n; q++) {
+      dst[i] = (u8)r;
+      dst[i + 1] = (u8)gg;
+      dst[i + 2] = (u8)b;
+      k++;
+      lasti = i;
+      i += 3;
+      if (i % S >= W * 3) i = (i / S + 1) * S;
+    }
+  }
+  const int off = -S - 3;
+  int xx = (i % S) / 3, y = i / S;
+  while (y < H && !bad) {
+    last_t = t;
+    t = get_p(last_t);
+    if (!t) get_rgb(r, gg, b);
+    n = get_n(t);
+    if (n < 1 || t == 3 || in > in_end) {
+      bad = true;
+      break;
+    }
+    i = y * S + xx * 3;
+    while (n-- > 0) {
+      switch (t) {
+        case 0:
+          dst[i] = (u8)r;
+          dst[i + 1] = (u8)gg;
+          dst[i + 2] = (u8)b;
+          break;
+        case 1:
+          dst[i] = dst[lasti];
+          dst[i + 1] = dst[lasti + 1];
+          dst[i + 2] = dst[lasti + 2];
+          break;
+        case 2:
+          dst[i] = dst[i + off + 3];
+          dst[i + 1] = dst[i + off + 4];
+          dst[i + 2] = dst[i + off + 5];
+          break;
+        case 4:
+          dst[i] = (u8)((int)dst[lasti] + (int)dst[i + off + 3] - (int)dst[i + off]);
+          dst[i + 1] = (u8)((int)dst[lasti + 1] + (int)dst[i + off + 4] - (int)dst[i + off + 1]);
+          dst[i + 2] = (u8)((int)dst[lasti + 2] + (int)dst[i + off + 5] - (int)dst[i + off + 2]);
+          break;
+        default:
+          dst[i] = dst[i + off];
+          dst[i + 1] = dst[i + off + 1];
+          dst[i + 2] = dst[i + off + 2];
+          break;
+      }
+      lasti = i;
+      xx++;
+      i += 3;
+      if (xx >= W) {
+        xx = 0;
+        y++;
+        i = y * S;
+      }
+      if (y >= H && n > 0) {
+        bad = true;
+        break;
+      }
+    }
+    gg = dst[lasti + 1];
+    b = dst[lasti + 2];
+    cx = (u32)gg >> 2;
+    next_cx(b);
+  }
+  if (bad) atomicOr(status, 4u);
+}
+
+// flat key frame: every pixel = the 3 bytes after the header (screencap.cpp:1537-1553)
+__global__ __launch_bounds__(256) void k_fill_flat(u8* planes, Geom g, int slot, u32 rgb) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= g.H * g.S) return;
+  const int y = idx / g.S, bx = idx - y * g.S;
+  u8 v = bx < g.W * 3 ? (u8)(rgb >> (8 * (bx % 3))) : 0;
+  planes[(size_t)slot * g.plane_stride + idx] = v;
+}
+
+}  // namespace scpr

@@ -38,6 +38,7 @@ def lib():
         L.spo_decompress_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int]
         L.spo_crash_happened.argtypes = [C.c_void_p]
         L.spo_tap_entries.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.spo_tap_tags.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.spo_tap_blocks.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.spo_tap_prev.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.spo_tap_records.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
@@ -95,6 +96,13 @@ class OracleCodec:
         out = np.zeros((max(n, 0), 2), dtype=np.uint16)
         if n > 0:
             lib().spo_tap_entries(self.h_, _ptr(out), n)
+        return out
+
+    def tags(self):
+        n = lib().spo_tap_tags(self.h_, None, 0)
+        out = np.zeros(max(n, 0), dtype=np.uint16)
+        if n > 0:
+            lib().spo_tap_tags(self.h_, _ptr(out), n)
         return out
 
     def blocks(self):
