@@ -99,6 +99,10 @@ const char* scpr_stage_name(int stage);
  * to host memory; returns the entry count. */
 int64_t scpr_debug_entries(scpr_codec* c, uint16_t* out, int64_t cap);
 
+/* Test hook: runs ONE colour context over `n` symbols through the wave-per-chain
+ * encoder kernel and returns the coder entries ({freq, cum} pairs; freq 0 = raw). */
+int scpr_debug_colour_chain(int device, const uint8_t* syms, int n, int f0, uint16_t* out);
+
 const char* scpr_version(void);
 
 #ifdef __cplusplus

@@ -12,8 +12,8 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 LIB = os.path.join(PKG, "libscpr_amd.so")
 HIP_SRC = os.path.join(PKG, "csrc", "scpr_amd.hip")
-HIP_DEPS = [HIP_SRC, os.path.join(PKG, "csrc", "scpr_kernels.hpp"), os.path.join(PKG, "csrc", "scpr_model.hpp"),
-            os.path.join(ROOT, "include", "scpr_amd.h")]
+HIP_DEPS = [os.path.join(PKG, "csrc", f) for f in sorted(os.listdir(os.path.join(PKG, "csrc")))] + [
+    os.path.join(ROOT, "include", "scpr_amd.h"), os.path.abspath(__file__)]
 
 
 def _stale(out: str, deps: list[str]) -> bool:
@@ -24,7 +24,7 @@ def build_hip(force: bool = False) -> str:
     """hand-written HIP kernels + C ABI -> screenpressor_amd/libscpr_amd.so (gfx950)"""
     if force or _stale(LIB, HIP_DEPS):
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result",
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-strict-aliasing", "-fPIC", "-shared", "-Wno-unused-result",
                "-o", LIB, HIP_SRC]
         subprocess.check_call(cmd)
     return LIB

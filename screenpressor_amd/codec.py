@@ -18,7 +18,7 @@ _LIB_PATH = os.path.join(_PKG, "libscpr_amd.so")
 SCPR_OK, SCPR_E_DEVICE, SCPR_E_PARAM, SCPR_E_BAD_VERSION, SCPR_E_CAPACITY, SCPR_E_STREAM = 0, -1, -2, -3, -4, -5
 EXPORTS = ["scpr_create", "scpr_destroy", "scpr_init", "scpr_deinit", "scpr_crash_happened", "scpr_compress_frame",
            "scpr_decompress_frame", "scpr_compress_batch", "scpr_decompress_batch", "scpr_last_timing", "scpr_stage_name",
-           "scpr_debug_entries", "scpr_version"]
+           "scpr_debug_entries", "scpr_debug_colour_chain", "scpr_version"]
 
 
 class ScprParams(C.Structure):
@@ -60,6 +60,7 @@ def load_library() -> C.CDLL:
         L.scpr_stage_name.argtypes = [C.c_int]
         L.scpr_debug_entries.restype = C.c_int64
         L.scpr_debug_entries.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        L.scpr_debug_colour_chain.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.scpr_version.restype = C.c_char_p
         _lib = L
     return _lib
@@ -175,3 +176,14 @@ class ScreenCodec:
         if n > 0:
             self._L.scpr_debug_entries(self._h, out.ctypes.data_as(C.c_void_p), n)
         return out
+
+
+def debug_colour_chain(syms, f0: int = 32, device: int = 0) -> np.ndarray:
+    """one colour context fed `syms` through the wave-per-chain encoder kernel -> (n, 2) uint16 entries"""
+    L = load_library()
+    syms = np.ascontiguousarray(syms, dtype=np.uint8)
+    out = np.zeros((len(syms), 2), dtype=np.uint16)
+    rc = L.scpr_debug_colour_chain(device, syms.ctypes.data_as(C.c_void_p), len(syms), f0, out.ctypes.data_as(C.c_void_p))
+    if rc < 0:
+        raise RuntimeError(f"scpr_debug_colour_chain: {rc}")
+    return out

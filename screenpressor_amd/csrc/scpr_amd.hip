@@ -15,6 +15,7 @@
 
 #include "../../include/scpr_amd.h"
 #include "scpr_kernels.hpp"
+#include "scpr_wave.hpp"
 
 using namespace scpr;
 
@@ -77,7 +78,7 @@ struct scpr_codec {
   // per-batch buffers
   DevBuf flags, slotlist, genlist, bases, totals, runs, runpos, keys[2], vals[2], hist, cstart, sorttmp, scantmp, entries, ranges;
   DevBuf rblocks, rscratch, rsize, packets, pktoff, blkdst, outsizes, total64, arena, arena_top, err, rcp;
-  DevBuf decframes, decstates, hoststage_in, hoststage_out;
+  DevBuf decframes, decstates, hoststage_in, hoststage_out, chainlists, chaincounts;
   // timing
   hipEvent_t ev[ST_COUNT + 1][2];
   bool ev_used[ST_COUNT];
@@ -145,8 +146,8 @@ static int ensure_codec(scpr_codec* c, int version) {  // CreateCodec + CScreenC
   g.plane_stride = (u32)(((size_t)g.H * g.S + 16 + 255) & ~(size_t)255);
   // chunk size: keep the per-slot worst-case buffers within ~6 GiB
   size_t per_slot = (size_t)g.plane_stride + (size_t)g.ntiles * (512 + 2 + TILE * 4 + 16) + (size_t)(g.W + 2) * 4;
-  size_t s = (6ull << 30) / per_slot;
-  c->slots = (int)std::min<size_t>(std::max<size_t>(s, 1), 256);
+  size_t s = (12ull << 30) / per_slot;
+  c->slots = (int)std::min<size_t>(std::max<size_t>(s, 1), 512);
   const size_t ns = (size_t)c->slots + 1;  // +1: slot `slots` holds the previous frame of the stream
   HIPCHK(c->planes.reserve(ns * g.plane_stride));
   HIPCHK(hipMemsetAsync(c->planes.p, 0, ns * g.plane_stride, c->stream));
@@ -165,7 +166,7 @@ static int ensure_codec(scpr_codec* c, int version) {  // CreateCodec + CScreenC
   HIPCHK(c->totals.reserve(64));
   HIPCHK(c->ranges.reserve(ns * sizeof(GenRange)));
   HIPCHK(c->arena_top.reserve(16));
-  HIPCHK(c->err.reserve(16));
+  HIPCHK(c->err.reserve(64));
   HIPCHK(c->total64.reserve(16));
   // reciprocal table for every frequency on the 12-bit scale
   std::vector<RansRcp> tab(kProbScale + 1);
@@ -269,9 +270,21 @@ static int encode_intra_frames(scpr_codec* c, const std::vector<int>& islots, st
   hipLaunchKernelGGL(k_fixed_chain, dim3(NFIXED_I, n), dim3(64), 0, st, c->runs.as<u32>(), c->runpos.as<u32>(), c->ranges.as<GenRange>(), c->entries.as<u32>());
   stage_end(c, ST_FIXED);
   stage_begin(c, ST_COLOUR);
-  Arena ar{c->arena.as<DenseTab>(), c->arena_top.as<u32>(), (u32)arena_cap, c->err.as<u32>()};
-  hipLaunchKernelGGL(k_colour_chain, dim3((unsigned)((nchains + 63) / 64)), dim3(64), 0, st, c->keys[1].as<u32>(), c->vals[1].as<u32>(), c->cstart.as<u32>(), (int)nchains, c->f0, ar,
-                     c->entries.as<u32>());
+  {
+    Arena ar{c->arena.as<DenseTab>(), c->arena_top.as<u32>(), (u32)arena_cap, c->err.as<u32>()};
+    const u32 cap = (u32)std::min<size_t>(nchains, Ctot + 1);
+    HIPCHK(c->chainlists.reserve((size_t)cap * 8 + 64));
+    HIPCHK(c->chaincounts.reserve(16));
+    HIPCHK(hipMemsetAsync(c->chaincounts.p, 0, 8, st));
+    hipLaunchKernelGGL(k_chain_lists, dim3((unsigned)((nchains + 255) / 256)), dim3(256), 0, st, c->cstart.as<u32>(), (int)nchains, 192u, c->chainlists.as<u32>(), cap,
+                       c->chaincounts.as<u32>());
+    for (int which = 0; which < 2; which++) {  // long chains first
+      const unsigned grid = (unsigned)std::min<u32>(cap, which == 0 ? 16384u : 32768u);
+      if (grid)
+        hipLaunchKernelGGL(k_colour_chain_w, dim3(grid), dim3(64), 0, st, c->keys[1].as<u32>(), c->vals[1].as<u32>(), c->cstart.as<u32>(), c->chainlists.as<u32>() + (size_t)which * cap,
+                           c->chaincounts.as<u32>() + which, c->f0, ar, c->entries.as<u32>());
+    }
+  }
   stage_end(c, ST_COLOUR);
   return SCPR_OK;
 }
@@ -339,7 +352,7 @@ void scpr_destroy(scpr_codec* c) {
   DevBuf* all[] = {&c->planes, &c->exitmap, &c->entry, &c->runrec, &c->tilecnt, &c->tileoff, &c->hdrrec, &c->hdrcnt, &c->frametot, &c->flags, &c->slotlist, &c->genlist,
                    &c->bases, &c->totals, &c->runs, &c->runpos, &c->keys[0], &c->keys[1], &c->vals[0], &c->vals[1], &c->hist, &c->cstart, &c->sorttmp, &c->scantmp,
                    &c->entries, &c->ranges, &c->rblocks, &c->rscratch, &c->rsize, &c->packets, &c->pktoff, &c->blkdst, &c->outsizes, &c->total64, &c->arena,
-                   &c->arena_top, &c->err, &c->rcp, &c->decframes, &c->decstates, &c->hoststage_in, &c->hoststage_out};
+                   &c->arena_top, &c->err, &c->rcp, &c->decframes, &c->decstates, &c->hoststage_in, &c->hoststage_out, &c->chainlists, &c->chaincounts};
   for (DevBuf* b : all) b->release();
   for (int s = 0; s < ST_COUNT + 1; s++)
     for (int k = 0; k < 2; k++) (void)hipEventDestroy(c->ev[s][k]);
@@ -493,7 +506,7 @@ int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* 
     HIPCHK(hipMemcpyAsync(&heads[i], (const u8*)d_packets + offs[i], std::min<u32>(4, sizes[i]), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   int done = 0;
-  HIPCHK(c->err.reserve(16));
+  HIPCHK(c->err.reserve(64));
   for (int f0 = 0; f0 < nframes;) {
     if (!c->have_codec) {
       if (c->crashed && ftypes[f0] > 0) return done;
@@ -505,7 +518,7 @@ int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* 
     const Geom& g = c->g;
     const int n = std::min(c->slots, nframes - f0);
     std::vector<DecFrame> coded;
-    HIPCHK(hipMemsetAsync(c->err.p, 0, 4, st));
+    HIPCHK(hipMemsetAsync(c->err.p, 0, 32, st));
     stage_begin(c, ST_DECODE);
     for (int i = 0; i < n; i++) {
       const int fi = f0 + i;
@@ -530,13 +543,17 @@ int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* 
       const size_t nc = coded.size();
       HIPCHK(c->decframes.reserve(nc * sizeof(DecFrame)));
       HIPCHK(c->decstates.reserve(nc * NCOLCTX * sizeof(ColState)));
+      HIPCHK(hipMemsetAsync(c->decstates.p, 0, nc * NCOLCTX * sizeof(ColState), st));  // kind 0 everywhere (RenewI)
       const size_t arena_cap = nc * 4096 + 64;  // dense tables per key frame; overflow is reported
       HIPCHK(c->arena.reserve(arena_cap * sizeof(DenseTab)));
       HIPCHK(hipMemsetAsync(c->arena_top.p, 0, 4, st));
       HIPCHK(hipMemcpyAsync(c->decframes.p, coded.data(), nc * sizeof(DecFrame), hipMemcpyHostToDevice, st));
       Arena ar{c->arena.as<DenseTab>(), c->arena_top.as<u32>(), (u32)arena_cap, c->err.as<u32>()};
-      hipLaunchKernelGGL(k_decode_intra, dim3((unsigned)nc), dim3(64), 0, st, (const u8*)d_packets, c->decframes.as<DecFrame>(), c->planes.as<u8>(), g, c->decstates.as<ColState>(),
-                         ar, c->f0, c->err.as<u32>());
+      int ring = 4096;
+      while (ring < 2 * g.S + 1024) ring <<= 1;
+      HIPCHK(hipFuncSetAttribute((const void*)k_decode_intra_w, hipFuncAttributeMaxDynamicSharedMemorySize, ring));
+      hipLaunchKernelGGL(k_decode_intra_w, dim3((unsigned)nc), dim3(64), ring, st, (const u8*)d_packets, (const u8*)d_packets + offs[nframes] + 8, c->decframes.as<DecFrame>(),
+                         c->planes.as<u8>(), g, c->decstates.as<ColState>(), ar, c->f0, c->err.as<u32>(), ring);
     }
     stage_end(c, ST_DECODE);
     stage_begin(c, ST_UNPACK);
@@ -549,10 +566,12 @@ int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* 
       hipLaunchKernelGGL(k_unpack_rows, gr, dim3(256), 0, st, c->planes.as<u8>(), out, g, pitch, c->bpp, c->rs, c->gs, c->bs);
     }
     stage_end(c, ST_UNPACK);
-    u32 err = 0;
-    HIPCHK(hipMemcpyAsync(&err, c->err.p, 4, hipMemcpyDeviceToHost, st));
+    u32 errv[8] = {0};
+    HIPCHK(hipMemcpyAsync(errv, c->err.p, 32, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     timing_collect(c);
+    const u32 err = errv[0];
+    if (getenv("SCPR_DEBUG")) fprintf(stderr, "[scpr] decode stats: record misses %u, colour symbols %u, dense %u, raw %u\n", errv[1], errv[2], errv[3], errv[4]);
     if (err & 4) return SCPR_E_STREAM;
     if (err & 1) return SCPR_E_DEVICE;
     done += n;
@@ -603,6 +622,38 @@ int scpr_last_timing(scpr_codec* c, float* total_ms, float* stage_ms, int cap) {
   if (total_ms) *total_ms = c->total_ms;
   for (int s = 0; s < ST_COUNT && s < cap; s++) stage_ms[s] = c->stage_ms[s];
   return ST_COUNT;
+}
+
+int scpr_debug_colour_chain(int device, const uint8_t* syms, int n, int f0, uint16_t* out) {
+  if (hipSetDevice(device) != hipSuccess) return SCPR_E_DEVICE;
+  std::vector<u32> keys(n), vals(n);
+  for (int i = 0; i < n; i++) {
+    keys[i] = syms[i];
+    vals[i] = (u32)i;
+  }
+  const u32 cst[2] = {0, (u32)n}, lst[1] = {0}, cnt[1] = {1}, zero[2] = {0, 0};
+  DevBuf dk, dv, dc, dl, dn, de, da, dt;
+  const size_t acap = 4;
+  HIPCHK(dk.reserve((size_t)n * 4));
+  HIPCHK(dv.reserve((size_t)n * 4));
+  HIPCHK(dc.reserve(8));
+  HIPCHK(dl.reserve(4));
+  HIPCHK(dn.reserve(4));
+  HIPCHK(de.reserve((size_t)n * 4));
+  HIPCHK(da.reserve(acap * sizeof(DenseTab)));
+  HIPCHK(dt.reserve(8));
+  HIPCHK(hipMemcpy(dk.p, keys.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dv.p, vals.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dc.p, cst, 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dl.p, lst, 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dn.p, cnt, 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dt.p, zero, 8, hipMemcpyHostToDevice));
+  Arena ar{da.as<DenseTab>(), dt.as<u32>(), (u32)acap, dt.as<u32>() + 1};
+  hipLaunchKernelGGL(k_colour_chain_w, dim3(1), dim3(64), 0, 0, dk.as<u32>(), dv.as<u32>(), dc.as<u32>(), dl.as<u32>(), dn.as<u32>(), f0, ar, de.as<u32>());
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(out, de.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+  for (DevBuf* b : {&dk, &dv, &dc, &dl, &dn, &de, &da, &dt}) b->release();
+  return n;
 }
 
 int64_t scpr_debug_entries(scpr_codec* c, uint16_t* out, int64_t cap) {

@@ -687,6 +687,21 @@ struct RansBlock {
 // One lane per block of <= 131072 entries, processed last to first; bytes are
 // written backwards into the block's scratch (ransmt.h:116-134).  x / freq uses
 // the exact 32-bit reciprocal (rans_byte.h:171-240).
+__device__ __forceinline__ void rans_put(u32& x, u8*& p, u32 v, const RansRcp* __restrict__ rcp) {
+  const u32 fr = v & 0xFFFF, cf = v >> 16;
+  if (fr) {
+    const u32 x_max = fr << 19;  // ((L >> 12) << 8) * freq
+    while (x >= x_max) {
+      *--p = (u8)x;
+      x >>= 8;
+    }
+    const RansRcp r = rcp[fr];
+    const u32 q = fr == 1 ? x : (__umulhi(x, r.rcp) >> r.shift);
+    x = (q << kProbBits) + (x - q * fr) + cf;
+  } else {
+    *--p = (u8)cf;
+  }
+}
 __global__ __launch_bounds__(64) void k_rans(const u32* __restrict__ entries, const RansBlock* __restrict__ blocks, int nblocks, const RansRcp* __restrict__ rcp,
                                              u8* __restrict__ scratch, u32* __restrict__ blksize) {
   const int b = blockIdx.x * 64 + threadIdx.x;
@@ -696,20 +711,15 @@ __global__ __launch_bounds__(64) void k_rans(const u32* __restrict__ entries, co
   u8* p = end;
   u32 x = kRansL;
   const u32* e = entries + blk.begin;
-  for (int i = (int)blk.len - 1; i >= 0; i--) {
-    const u32 v = e[i], fr = v & 0xFFFF, cf = v >> 16;
-    if (fr) {
-      const u32 x_max = fr << 19;  // ((L >> 12) << 8) * freq
-      while (x >= x_max) {
-        *--p = (u8)x;
-        x >>= 8;
-      }
-      const RansRcp r = rcp[fr];
-      const u32 q = fr == 1 ? x : (__umulhi(x, r.rcp) >> r.shift);
-      x = (q << kProbBits) + (x - q * fr) + cf;
-    } else {
-      *--p = (u8)cf;
-    }
+  int i = (int)blk.len;
+  for (int r = i & 15; r > 0; r--) rans_put(x, p, e[--i], rcp);  // ragged top
+  while (i > 0) {  // 16 entries per trip: the loads do not depend on the coder state
+    i -= 16;
+    u32 v[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) v[k] = e[i + k];
+#pragma unroll
+    for (int k = 15; k >= 0; k--) rans_put(x, p, v[k], rcp);
   }
   p -= 4;
   p[0] = (u8)x;

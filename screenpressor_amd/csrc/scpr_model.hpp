@@ -110,7 +110,6 @@ SCPR_HD int fixed_decode(FixedTab<CAP>& t, int v, Ivl& e) {
 // ----------------------------------------------------------------- colour ---
 struct DenseTab {  // kinds 6 and 7
   uint16_t freq[256], cum[256], cnt[256];
-  uint32_t present[8];  // kind 6: symbols met so far
 };
 
 struct ColState {  // 64 bytes per (plane, context)
@@ -120,7 +119,7 @@ struct ColState {  // 64 bytes per (plane, context)
   uint32_t dense;  // arena index of the DenseTab (kinds 6/7)
   uint32_t pad1;
   union {
-    uint32_t seen[8];  // kinds 1-3
+    uint32_t seen[8];  // kinds 1-3: symbols seen once; kind 6: symbols met so far
     struct {
       uint8_t sym[16];
       uint16_t fr[16];
@@ -253,7 +252,7 @@ SCPR_HD void hash_rebuild(ColState& st, DenseTab& t) {
   int cf = 0, tot = (256 - st.d) << base;
   for (int j = 0; j < 256; j++) {
     t.cum[j] = (uint16_t)cf;
-    if (set_has(t.present, j)) {
+    if (set_has(st.u.seen, j)) {
       int fr = t.cnt[j];
       t.freq[j] = (uint16_t)fr;
       cf += fr;
@@ -278,7 +277,7 @@ SCPR_HD void hash_bump(ColState& st, DenseTab& t, int c) {  // incrCnt(): :686-6
 SCPR_HD void hash_to_dense(ColState& st, DenseTab& t) {
   const int w = 1 << st.fshift, base = w - (w >> 1);
   for (int j = 0; j < 256; j++)
-    if (!set_has(t.present, j)) t.cnt[j] = (uint16_t)base;
+    if (!set_has(st.u.seen, j)) t.cnt[j] = (uint16_t)base;
   st.kind = 7;
 }
 SCPR_HD void dense_bump(ColState& st, DenseTab& t, int c) {  // Cx7::incrCnt: :959-981
@@ -351,15 +350,21 @@ SCPR_HD void promote_small4_to_16(ColState& st, uint8_t c) {
 SCPR_HD void promote_small_to_hash(ColState& st, DenseTab& t, uint8_t c) {
   const int tot = small_exact_total(st), sh = scale_shift(tot), n = st.d;
   const int w = 1 << sh, base = w - (w >> 1);
-  for (int i = 0; i < 8; i++) t.present[i] = 0;
+  uint8_t osym[16];
+  uint16_t ofr[16];
+  for (int i = 0; i < 16; i++) {  // the small table shares storage with the set
+    osym[i] = st.u.s.sym[i];
+    ofr[i] = st.u.s.fr[i];
+  }
+  for (int i = 0; i < 8; i++) st.u.seen[i] = 0;
   int k = 0, cf = 0, sum = 0;
   for (int j = 0; j < 256; j++) {
     t.cum[j] = (uint16_t)cf;
-    if (k < n && st.u.s.sym[k] == j) {
-      int fr = st.u.s.fr[k] << sh;
+    if (k < n && osym[k] == j) {
+      int fr = ofr[k] << sh;
       t.freq[j] = (uint16_t)fr;
       t.cnt[j] = (uint16_t)(fr - (fr >> 1));
-      set_add(t.present, j);
+      set_add(st.u.seen, j);
       k++;
     } else {
       t.freq[j] = (uint16_t)w;
@@ -367,12 +372,12 @@ SCPR_HD void promote_small_to_hash(ColState& st, DenseTab& t, uint8_t c) {
     }
     cf += t.freq[j];
   }
-  set_add(t.present, c);
+  set_add(st.u.seen, c);
   t.cnt[c] = (uint16_t)(base + (kStepHash << sh));
   st.fshift = (uint8_t)sh;
   st.d = (uint16_t)(n + 1);
   for (int j = 0; j < 256; j++)
-    if (set_has(t.present, j)) sum += t.cnt[j];
+    if (set_has(st.u.seen, j)) sum += t.cnt[j];
   st.total = (uint16_t)(((256 - st.d) << (sh > 0 ? sh - 1 : 0)) + sum);
   st.kind = 6;
 }
@@ -382,10 +387,9 @@ SCPR_HD void promote_unique_to_hash(ColState& st, DenseTab& t, uint8_t c, int f0
   const int n = st.d, tot = 256 - n + n * f0 + f0, sh = scale_shift(tot);
   const int w = 1 << sh;
   int cf = 0, sum = 0;
-  for (int i = 0; i < 8; i++) t.present[i] = st.u.seen[i];
   for (int j = 0; j < 256; j++) {
     t.cum[j] = (uint16_t)cf;
-    if (set_has(t.present, j)) {
+    if (set_has(st.u.seen, j)) {
       int fr = ((j == c) ? 2 * f0 : f0) << sh;
       t.freq[j] = (uint16_t)fr;
       t.cnt[j] = (uint16_t)((fr & 0xFFFF) - ((fr & 0xFFFF) >> 1));
@@ -484,12 +488,12 @@ SCPR_HD Ivl col_encode(ColState& st, uint8_t c, int f0, Alloc&& alloc, Tab&& tab
       DenseTab& t = *tab(st);
       e.freq = t.freq[c];
       e.cum = t.cum[c];
-      if (set_has(t.present, c)) {
+      if (set_has(st.u.seen, c)) {
         hash_bump(st, t, c);
       } else if (st.d >= kHashMaxSyms) {  // :631 / :670: the 41st symbol goes uncounted
         hash_to_dense(st, t);
       } else {  // placeSymbol, :621-638
-        set_add(t.present, c);
+        set_add(st.u.seen, c);
         t.cnt[c] = (uint16_t)(e.freq - (e.freq >> 1));
         st.d++;
         hash_bump(st, t, c);
@@ -535,12 +539,12 @@ SCPR_HD bool col_decode(ColState& st, int v, uint8_t& c, Ivl& e, Alloc&& alloc, 
       c = (uint8_t)j;
       e.freq = t.freq[j];
       e.cum = t.cum[j];
-      if (set_has(t.present, j)) {
+      if (set_has(st.u.seen, j)) {
         hash_bump(st, t, j);
       } else if (st.d >= kHashMaxSyms) {
         hash_to_dense(st, t);
       } else {
-        set_add(t.present, j);
+        set_add(st.u.seen, j);
         t.cnt[j] = (uint16_t)(e.freq - (e.freq >> 1));
         st.d++;
         hash_bump(st, t, j);

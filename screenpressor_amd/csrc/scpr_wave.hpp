@@ -1,0 +1,836 @@
+// Wave-cooperative key-frame decoder (gfx950, one 64-lane wave per frame).
+//
+// The decode of one frame is a single dependent chain (every symbol's model
+// depends on the bytes decoded before it; DecompressI, screencap.cpp:414-498),
+// so the wave does not split the symbols; it splits the WORK PER SYMBOL:
+//   * the rANS state and all control flow are wave-uniform (scalar unit);
+//   * fixed-alphabet tables (run lengths, pixel types) live in LDS, four
+//     entries per lane; a symbol is found with one 16-byte LDS read per lane,
+//     a ballot and a readlane; rebuilds are a wave prefix-scan
+//     (FixedSizeRansCtx, ans_contexts.h:1054-1132);
+//   * colour contexts are 64-byte records cached in LDS (direct mapped,
+//     write-back to HBM); small tables use one lane per symbol and a 16-lane
+//     scan (SmallContext, :155-290); dense tables use four symbols per lane
+//     (Cx6/Cx7, :377-998);
+//   * the input bytes come through an LDS ring that is refilled 1 KiB ahead;
+//   * runs are written by all lanes at once; the gradient predictor is a wave
+//     prefix sum of (top - topleft) deltas.
+#pragma once
+#include "scpr_kernels.hpp"
+
+namespace scpr {
+
+// Lanes of one wave exchange data through LDS in program order (DS operations of a
+// wave execute in order), but to the compiler each lane is a thread of its own: without
+// a fence it may forward a lane's own earlier store to its later load and miss what
+// another lane wrote in between.  A wavefront-scope fence emits no instruction and
+// forbids exactly that.
+__device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+__device__ __forceinline__ u32 rfl(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ u32 rdl(u32 v, int lane) { return (u32)__builtin_amdgcn_readlane((int)v, lane); }
+// inclusive scan inside each row of 16 lanes: four DPP row_shr adds (no LDS traffic)
+__device__ __forceinline__ int row_incl_scan(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+  return v;
+}
+__device__ __forceinline__ int wave_incl_scan(int v) {
+  v = row_incl_scan(v);
+  const int t0 = (int)rdl((u32)v, 15), t1 = (int)rdl((u32)v, 31), t2 = (int)rdl((u32)v, 47);
+  const int row = lane_id() >> 4;
+  return v + (row > 0 ? t0 : 0) + (row > 1 ? t1 : 0) + (row > 2 ? t2 : 0);
+}
+__device__ __forceinline__ int row16_sum(int v) { return (int)rdl((u32)row_incl_scan(v), 15); }  // lanes 0..15
+__device__ __forceinline__ int wave_sum(int v) {
+  v = row_incl_scan(v);
+  return (int)(rdl((u32)v, 15) + rdl((u32)v, 31) + rdl((u32)v, 47) + rdl((u32)v, 63));
+}
+__device__ __forceinline__ int shift_for(int tot) {  // number of doublings until tot > 2048 (ans_contexts.h:196-199), tot >= 2
+  return max(0, __builtin_clz((u32)(tot - 1)) - 20);
+}
+
+constexpr int WIN = 4096;     // input ring, bytes
+constexpr int CACHE_N = 256;  // colour records cached in LDS
+
+struct WaveLds {
+  u32 ring[WIN / 4];
+  u32 nfc[6][256];   // run-length models: freq | cum << 16
+  u32 ncnt[6][256];
+  u32 pfc[6][8];     // pixel-type models
+  u32 pcnt[6][8];
+  u32 crec[CACHE_N][16];
+  u16 ctag[CACHE_N];
+  u16 tmp[256];
+};
+
+// The colour model of one context, operated by a whole wave.  The header is
+// wave-uniform (scalar registers), a small table is one entry per lane (lanes
+// 0..15), the 256-bit symbol set lives in the 64-byte LDS record (words 4..11,
+// layout = ColState) and dense tables live in the HBM arena.  Shared by the
+// decoder (symbol from coder value) and the encoder chains (interval from symbol).
+struct ColHdr {
+  int kind, maxpos, fshift, d, total;
+  u32 dense;
+};
+struct WaveModel {
+  const int lane;
+  u16* tmp;  // 256 x u16 LDS scratch
+  Arena arena;
+  int f0;
+  __device__ __forceinline__ WaveModel(u16* tmp_, Arena a, int f0_) : lane(lane_id()), tmp(tmp_), arena(a), f0(f0_) {}
+
+  static __device__ __forceinline__ ColHdr unpack(u32 h0, u32 h1, u32 h2) {
+    ColHdr h;
+    h.kind = h0 & 255;
+    h.maxpos = (h0 >> 8) & 255;
+    h.fshift = (h0 >> 16) & 255;
+    h.d = h1 & 0xFFFF;
+    h.total = h1 >> 16;
+    h.dense = h2;
+    return h;
+  }
+  __device__ __forceinline__ void store_header(u32* r, const ColHdr& h) {
+    if (lane == 0) {
+      r[0] = (u32)h.kind | ((u32)h.maxpos << 8) | ((u32)h.fshift << 16);
+      r[1] = (u32)h.d | ((u32)h.total << 16);
+      r[2] = h.dense;
+    }
+  }
+  // small-table entry of this lane <-> record bytes 16+lane (symbol) and 32+2*lane (count)
+  __device__ __forceinline__ void load_small(const u32* r, int d, int& sym, int& fq) {
+    const bool act = lane < d;
+    sym = act ? ((const u8*)r)[16 + lane] : 0;
+    fq = act ? ((const u16*)r)[16 + lane] : 0;
+  }
+  __device__ __forceinline__ void store_small(u32* r, int d, int sym, int fq) {
+    if (lane < d) {
+      ((u8*)r)[16 + lane] = (u8)sym;
+      ((u16*)r)[16 + lane] = (u16)fq;
+    }
+  }
+  __device__ __forceinline__ u32 alloc_dense() {
+    u32 idx = 0;
+    if (lane == 0) {
+      idx = atomicAdd(arena.top, 1u);
+      if (idx >= arena.cap) {
+        atomicOr(arena.err, 1u);
+        idx = 0;
+      }
+    }
+    return rfl(idx);
+  }
+  // this lane's 4 bits of the 256-bit set stored in r[4..11]
+  __device__ __forceinline__ u32 set_bits4(const u32* r) { return (r[4 + (lane >> 3)] >> ((lane & 7) * 4)) & 15u; }
+
+  // writes a dense table from per-lane (freq, count) of symbols 4*lane..+3; returns the count total
+  __device__ __forceinline__ int write_dense(DenseTab* t, const int fr[4], const int cn[4]) {
+    const int s = fr[0] + fr[1] + fr[2] + fr[3];
+    int cf = wave_incl_scan(s) - s;
+    u32 c0 = (u32)cf, c1 = c0 + fr[0], c2 = c1 + fr[1], c3 = c2 + fr[2];
+    ((uint2*)t->freq)[lane] = make_uint2((u32)(fr[0] & 0xFFFF) | ((u32)fr[1] << 16), (u32)(fr[2] & 0xFFFF) | ((u32)fr[3] << 16));
+    ((uint2*)t->cum)[lane] = make_uint2((c0 & 0xFFFF) | (c1 << 16), (c2 & 0xFFFF) | (c3 << 16));
+    ((uint2*)t->cnt)[lane] = make_uint2((u32)(cn[0] & 0xFFFF) | ((u32)cn[1] << 16), (u32)(cn[2] & 0xFFFF) | ((u32)cn[3] << 16));
+    return wave_sum(cn[0] + cn[1] + cn[2] + cn[3]);
+  }
+
+  // Context::update for kinds 0-3 (ans_contexts.cpp:3-31, :52-59): c arrived raw.
+  // On promotion to a small table (kind 4/5) the entries are returned in sym/fq.
+  __device__ __forceinline__ void note_raw(u32* r, ColHdr& h, int c, int& sym, int& fq) {
+    wave_fence();
+    if (h.kind == 0) {
+      if (lane < 8) r[4 + lane] = (lane == (c >> 5)) ? (1u << (c & 31)) : 0u;
+      h.kind = 1;
+      h.d = 1;
+      return;
+    }
+    const u32 w = rfl(r[4 + (c >> 5)]);
+    if (!((w >> (c & 31)) & 1u)) {
+      if (lane == 0) r[4 + (c >> 5)] = w | (1u << (c & 31));
+      h.d++;
+      if (h.kind == 1 && h.d == 15) h.kind = 2;
+      else if (h.kind == 2 && h.d == 65) h.kind = 3;
+      return;
+    }
+    const int d = h.d;
+    const u32 bits = set_bits4(r);  // the whole set, 4 symbols per lane
+    const int pc = __builtin_popcount(bits);
+    if (h.kind == 1) {  // -> sorted small table, 50 each, 100 for the repeated symbol (ans_contexts.h:161-172)
+      const int base = wave_incl_scan(pc) - pc;
+      const int lc = c >> 2;
+      h.maxpos = (int)rdl((u32)base, lc) + __builtin_popcount(rdl(bits, lc) & ((1u << (c & 3)) - 1u));
+      // rank -> lane: scatter through the LDS scratch (at most 14 symbols)
+      for (int q = 0; q < 4; q++)
+        if ((bits >> q) & 1u) tmp[base + __builtin_popcount(bits & ((1u << q) - 1u))] = (u16)(lane * 4 + q);
+      wave_fence();
+      sym = lane < d ? tmp[lane] : 0;
+      wave_fence();
+      fq = lane < d ? (sym == c ? 2 * kStepSmall : kStepSmall) : 0;
+      h.kind = d <= 4 ? 4 : 5;
+      h.total = h.kind == 5 ? 256 - d + kStepSmall * d + kStepSmall : 0;
+      return;
+    }
+    h.dense = alloc_dense();
+    DenseTab* t = arena.tabs + h.dense;
+    int fr[4], cn[4];
+    if (h.kind == 2) {  // Cx6::create23, ans_contexts.h:491-531
+      const int tot = 256 - d + d * f0 + f0, sh = shift_for(tot), wdt = 1 << sh;
+      for (int q = 0; q < 4; q++) {
+        const int j = lane * 4 + q;
+        if ((bits >> q) & 1u) {
+          fr[q] = (((j == c) ? 2 * f0 : f0) << sh) & 0xFFFF;
+          cn[q] = fr[q] - (fr[q] >> 1);
+        } else {
+          fr[q] = wdt;
+          cn[q] = 0;
+        }
+      }
+      const int sum = write_dense(t, fr, cn);
+      h.kind = 6;
+      h.fshift = sh;
+      h.total = ((256 - d) << (sh > 0 ? sh - 1 : 0)) + sum;
+    } else {  // Cx7::create(Cx3&), :917-951
+      const int g0 = (kProbScale - (256 - d)) / (d + 1), c0 = g0 - (g0 >> 1);
+      for (int q = 0; q < 4; q++) {
+        const int j = lane * 4 + q;
+        fr[q] = ((bits >> q) & 1u) ? g0 : 1;
+        cn[q] = ((bits >> q) & 1u) ? c0 : 1;
+        if (j == c) {
+          fr[q] += g0;
+          cn[q] += kStepDense;
+        }
+      }
+      h.kind = 7;
+      h.total = write_dense(t, fr, cn);
+    }
+  }
+
+  // kinds 4/5: SmallContext::decode / ::encode (ans_contexts.h:195-283), one lane per table entry
+  // (sym, fq in lanes 0..d-1, zero elsewhere).
+  // DEC: `in` is the coder value (state & 4095), the symbol is returned; else `in` is the symbol.
+  // When a full 16-table meets a 17th symbol the context becomes kind 6 (Cx6::create(Cx5&, c),
+  // :454-489): the set goes to r[4..11], the table to the arena.
+  template <bool DEC>
+  __device__ __forceinline__ int small_op(u32* r, ColHdr& h, int& sym, int& fq, int in, u32& ofr, u32& ocf) {
+    int d = h.d;
+    const bool act = lane < d;
+    int tot = h.kind == 4 ? 256 - d + row16_sum(fq) : h.total;
+    const int sh = shift_for(tot), bonus = (kProbScale - (tot << sh)) >> sh;
+    const int vv = DEC ? in >> sh : 0;
+    const int f = act ? ((fq + (lane == h.maxpos ? bonus : 0)) & 0xFFFF) : 0;
+    const int incl = row_incl_scan(f), P = incl - f;
+    const int start = sym - lane + P, end = start + f;
+    const u64 hit = DEC ? __ballot(act && start <= vv && vv < end) : __ballot(act && sym == in);
+    const int cap = h.kind == 4 ? 4 : 16;
+    int c;
+    if (hit) {
+      const int p = __builtin_ctzll(hit);
+      c = DEC ? (int)rdl((u32)sym, p) : in;
+      ofr = rdl((u32)f, p) << sh;
+      ocf = rdl((u32)start, p) << sh;
+      const int fmax = (int)rdl((u32)fq, h.maxpos);
+      if (lane == p) fq += kStepSmall;
+      tot += kStepSmall;
+      if (p != h.maxpos && (int)rdl((u32)fq, p) > fmax) h.maxpos = p;
+      if (tot + kStepSmall > kProbScale) {  // rescale, :186-193
+        fq -= fq >> 1;
+        tot = 256 - d + row16_sum(fq);
+      }
+      h.total = h.kind == 5 ? tot : 0;
+      return c;
+    }
+    const int pos = __builtin_popcountll(DEC ? __ballot(act && end <= vv) : __ballot(act && sym < in));
+    const int Ppos = pos < d ? (int)rdl((u32)P, pos) : (int)rdl((u32)incl, d - 1);
+    c = DEC ? vv - Ppos + pos : in;
+    ofr = 1u << sh;
+    ocf = (u32)(DEC ? vv : c - pos + Ppos) << sh;
+    if (d < cap || h.kind == 4) {  // addSymb (:174-184), or Cx5::create(Cx4&, c) (:350-369) when the 4-table is full
+      const int usym = __shfl_up(sym, 1), ufq = __shfl_up(fq, 1);
+      if (lane > pos && lane <= d) {
+        sym = usym;
+        fq = ufq;
+      } else if (lane == pos) {
+        sym = c;
+        fq = kStepSmall;
+      }
+      const bool grow = d == cap;  // kind 4 -> 5: maxpos restarts at 0 (value-initialised in the reference)
+      d++;
+      if (grow) {
+        h.maxpos = 0;
+        h.kind = 5;
+        tot = 256 - d + row16_sum(fq);
+      } else {
+        if (h.maxpos >= pos) h.maxpos++;
+        tot += kStepSmall;
+        if (tot + kStepSmall > kProbScale) {
+          fq -= fq >> 1;
+          tot = 256 - d + row16_sum(fq);
+        }
+      }
+      h.d = d;
+      h.total = h.kind == 5 ? tot : 0;
+      return c;
+    }
+    // kind 5 full
+    wave_fence();
+    for (int q = 0; q < 4; q++) tmp[lane * 4 + q] = 0;
+    wave_fence();
+    if (act) tmp[sym] = (u16)fq;
+    wave_fence();
+    const int tex = 256 - d + row16_sum(fq), s2 = shift_for(tex), wdt = 1 << s2, base = wdt - (wdt >> 1);
+    int fr[4], cn[4];
+    u32 bits = 0;
+    for (int q = 0; q < 4; q++) {
+      const int j = lane * 4 + q, pf = tmp[j];
+      if (pf) {
+        fr[q] = (pf << s2) & 0xFFFF;
+        cn[q] = fr[q] - (fr[q] >> 1);
+        bits |= 1u << q;
+      } else {
+        fr[q] = wdt;
+        cn[q] = 0;
+      }
+      if (j == c) {
+        cn[q] = base + (kStepHash << s2);
+        bits |= 1u << q;
+      }
+    }
+    wave_fence();
+    if (lane < 8) r[4 + lane] = 0;
+    wave_fence();
+    atomicOr(&r[4 + (lane >> 3)], bits << ((lane & 7) * 4));
+    wave_fence();
+    h.dense = alloc_dense();
+    const int sum = write_dense(arena.tabs + h.dense, fr, cn);
+    h.kind = 6;
+    h.fshift = s2;
+    h.d = d + 1;
+    h.total = ((256 - (d + 1)) << (s2 > 0 ? s2 - 1 : 0)) + sum;
+    return c;
+  }
+
+  // kinds 6/7: Cx6/Cx7 decode and encode (ans_contexts.h:640-740, :953-997), 4 symbols per lane
+  template <bool DEC>
+  __device__ __forceinline__ int dense_op(u32* r, ColHdr& h, int in, u32& ofr, u32& ocf) {
+    wave_fence();
+    DenseTab* t = arena.tabs + h.dense;
+    const uint2 cu = ((const uint2*)t->cum)[lane], fq = ((const uint2*)t->freq)[lane], cq = ((const uint2*)t->cnt)[lane];
+    const u32 v = (u32)in;
+    const u32 c0 = cu.x & 0xFFFF, c1 = cu.x >> 16, c2 = cu.y & 0xFFFF, c3 = cu.y >> 16;
+    const u64 m = DEC ? __ballot(c0 <= v) : 0;
+    const int own = DEC ? 63 - __builtin_clzll(m) : in >> 2;
+    const int k = DEC ? (c1 <= v) + (c2 <= v) + (c3 <= v) : (in & 3);
+    const u32 selc = k == 0 ? c0 : k == 1 ? c1 : k == 2 ? c2 : c3;
+    const u32 self = k == 0 ? (fq.x & 0xFFFF) : k == 1 ? (fq.x >> 16) : k == 2 ? (fq.y & 0xFFFF) : (fq.y >> 16);
+    const int kk = (int)rdl((u32)k, own);
+    const int j = own * 4 + kk;
+    ofr = rdl(self, own);
+    ocf = rdl(selc, own);
+    int cn[4] = {(int)(cq.x & 0xFFFF), (int)(cq.x >> 16), (int)(cq.y & 0xFFFF), (int)(cq.y >> 16)};
+    int fr[4] = {(int)(fq.x & 0xFFFF), (int)(fq.x >> 16), (int)(fq.y & 0xFFFF), (int)(fq.y >> 16)};
+    const u32 bits = h.kind == 6 ? set_bits4(r) : 15u;
+    u32 nbits = bits;
+    int step = kStepDense;
+    if (h.kind == 6) {
+      step = kStepHash << h.fshift;
+      const bool present = (rdl(bits, own) >> kk) & 1u;
+      if (!present) {
+        if (h.d >= kHashMaxSyms) {  // 41st symbol: becomes kind 7, uncounted (:631, Cx7::create(const Cx6&) :868-915)
+          const int wdt = 1 << h.fshift, base = wdt - (wdt >> 1);
+          for (int q = 0; q < 4; q++)
+            if (!((bits >> q) & 1u)) cn[q] = base;
+          ((uint2*)t->cnt)[lane] = make_uint2((u32)cn[0] | ((u32)cn[1] << 16), (u32)cn[2] | ((u32)cn[3] << 16));
+          h.kind = 7;
+          return j;
+        }
+        if (lane == own) {  // placeSymbol, :621-638
+          nbits |= 1u << kk;
+#pragma unroll
+          for (int q = 0; q < 4; q++)
+            if (q == kk) cn[q] = (int)ofr - ((int)ofr >> 1);
+          atomicOr(&r[4 + (lane >> 3)], (1u << kk) << ((lane & 7) * 4));
+        }
+        h.d++;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+      if (lane == own && q == kk) cn[q] += step;
+    h.total += step;
+    if (h.total + step > kProbScale) {
+      if (h.kind == 7) {  // Cx7::incrCnt rebuild, :963-980
+        for (int q = 0; q < 4; q++) {
+          fr[q] = cn[q];
+          cn[q] -= cn[q] >> 1;
+        }
+        h.total = write_dense(t, fr, cn);
+      } else {  // Cx6::rescale, :742-796
+        const int wdt = 1 << (h.fshift > 0 ? h.fshift - 1 : 0);
+        if (h.fshift > 0) h.fshift--;
+        for (int q = 0; q < 4; q++) {
+          if ((nbits >> q) & 1u) {
+            fr[q] = cn[q];
+            cn[q] -= cn[q] >> 1;
+          } else {
+            fr[q] = wdt;
+            cn[q] = 0;
+          }
+        }
+        const int sum = write_dense(t, fr, cn);
+        h.total = ((256 - h.d) << (h.fshift > 0 ? h.fshift - 1 : 0)) + sum;
+      }
+    } else if (lane == own) {
+      ((uint2*)t->cnt)[lane] = make_uint2((u32)cn[0] | ((u32)cn[1] << 16), (u32)cn[2] | ((u32)cn[3] << 16));
+    }
+    return j;
+  }
+};
+
+struct WaveDec : WaveModel {
+  WaveLds& L;
+  // input stream
+  const u8* src;
+  const u8* src_end;
+  u32 rpos = 0, loaded = 0, issued = 0, pre = 0;
+  u64 buf = 0;
+  int nb = 0;
+  bool have_pre = false;
+  uint4 pend;
+  // coder
+  u32 x = 0;
+  int ndec = 0;
+  // models
+  ColState* gstates;
+  bool bad = false;
+  int ftot[12] = {2048, 2048, 2048, 2048, 2048, 2048, 2046, 2046, 2046, 2046, 2046, 2046};  // wave-uniform
+
+  __device__ __forceinline__ WaveDec(WaveLds& l, const u8* s, const u8* e, ColState* gs, Arena a, int f0_) : WaveModel(l.tmp, a, f0_), L(l), src(s), src_end(e), gstates(gs) {}
+
+  // ---------------------------------------------------------------- input ---
+  __device__ __forceinline__ uint4 load16(u32 off) {
+    const u8* p = src + off + 16 * lane;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (p + 16 <= src_end) {
+      __builtin_memcpy(&v, p, 16);
+    } else {
+      u8 b[16];
+      for (int i = 0; i < 16; i++) b[i] = (p + i < src_end) ? p[i] : (u8)0;
+      __builtin_memcpy(&v, b, 16);
+    }
+    return v;
+  }
+  __device__ __forceinline__ void stream_init() {
+    ((uint4*)L.ring)[lane] = load16(0);
+    ((uint4*)L.ring)[64 + lane] = load16(1024);
+    loaded = 2048;
+    pend = load16(2048);
+    issued = 3072;
+    __syncthreads();
+  }
+  // once per symbol: keep >= 1 KiB of input in LDS and one word prefetched
+  __device__ __forceinline__ void tick() {
+    wave_fence();
+    if (rpos + 1024 > loaded) {
+      ((uint4*)L.ring)[((loaded & (WIN - 1)) >> 4) + lane] = pend;
+      loaded += 1024;
+      pend = load16(issued);
+      issued += 1024;
+      wave_fence();
+    }
+    if (nb <= 4 && !have_pre) {
+      pre = rfl(L.ring[(rpos & (WIN - 1)) >> 2]);
+      rpos += 4;
+      have_pre = true;
+    }
+  }
+  __device__ __forceinline__ void need(int k) {
+    wave_fence();
+    while (nb < k) {
+      if (!have_pre) {
+        pre = rfl(L.ring[(rpos & (WIN - 1)) >> 2]);
+        rpos += 4;
+      }
+      buf |= (u64)pre << (8 * nb);
+      nb += 4;
+      have_pre = false;
+    }
+  }
+  __device__ __forceinline__ u32 take_byte() {
+    need(1);
+    u32 b = (u32)buf & 255u;
+    buf >>= 8;
+    nb--;
+    return b;
+  }
+  __device__ __forceinline__ u32 take_u32() {  // RansDecInit, rans_byte.h:106-119
+    need(4);
+    u32 v = (u32)buf;
+    buf >>= 32;
+    nb -= 4;
+    return v;
+  }
+  __device__ __forceinline__ void advance(u32 cf, u32 fr, u32 v) {  // RansDecAdvance, rans_byte.h:130-146
+    x = fr * (x >> kProbBits) + v - cf;
+    while (x < kRansL) x = (x << 8) | take_byte();
+  }
+  __device__ __forceinline__ void count() {  // screencap.h:327-331
+    if (++ndec == kBlockEntries) {
+      x = take_u32();
+      ndec = 0;
+    }
+  }
+
+  // ---------------------------------------------------------------- fixed ---
+  __device__ __forceinline__ void fixed_init() {
+    for (int t = 0; t < 6; t++) {
+      for (int j = lane; j < 256; j += 64) {
+        L.nfc[t][j] = 16u | ((u32)(16 * j) << 16);
+        L.ncnt[t][j] = 8;
+      }
+      if (lane < 8) {
+        L.pfc[t][lane] = lane < 6 ? (682u | ((u32)(682 * lane) << 16)) : 0xFFFF0000u;
+        L.pcnt[t][lane] = lane < 6 ? 341u : 0u;
+      }
+    }
+  }
+  template <int PER>
+  __device__ __forceinline__ int fixed_rebuild(u32* fc, u32* cnt, int nsym) {  // incrCnt rebuild, ans_contexts.h:1075-1090
+    wave_fence();
+    int c[PER], s = 0;
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+      int j = lane * PER + q;
+      c[q] = j < nsym ? (int)cnt[j] : 0;
+      s += c[q];
+    }
+    int cf = wave_incl_scan(s) - s, ns = 0;
+    wave_fence();
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+      int j = lane * PER + q;
+      if (j < nsym) {
+        fc[j] = (u32)c[q] | ((u32)cf << 16);
+        cf += c[q];
+        int h = c[q] - (c[q] >> 1);
+        cnt[j] = (u32)h;
+        ns += h;
+      }
+    }
+    wave_fence();
+    return wave_sum(ns);
+  }
+  // symbol whose interval holds v; updates the table (decode + incrCnt, :1093-1112, :1070-1091)
+  __device__ __forceinline__ int get_tot(int i) {
+    int v = ftot[0];
+#pragma unroll
+    for (int q = 1; q < 12; q++) v = (i == q) ? ftot[q] : v;
+    return v;
+  }
+  __device__ __forceinline__ void set_tot(int i, int v) {
+#pragma unroll
+    for (int q = 0; q < 12; q++) ftot[q] = (i == q) ? v : ftot[q];
+  }
+  __device__ __forceinline__ int fixed_n(int t) {
+    wave_fence();
+    u32* fc = L.nfc[t];
+    u32* cnt = L.ncnt[t];
+    const u32 v = x & (kProbScale - 1);
+    const uint4 e = ((const uint4*)fc)[lane];
+    const u64 m = __ballot((e.x >> 16) <= v);
+    const int own = 63 - __builtin_clzll(m);
+    int k = ((e.y >> 16) <= v) + ((e.z >> 16) <= v) + ((e.w >> 16) <= v);
+    u32 sel = k == 0 ? e.x : k == 1 ? e.y : k == 2 ? e.z : e.w;
+    const int kk = (int)rdl((u32)k, own);
+    const u32 s = rdl(sel, own);
+    const int sym = own * 4 + kk;
+    if (lane == own) cnt[sym] += kStepDense;
+    wave_fence();
+    int tot = get_tot(t) + kStepDense;
+    advance(s >> 16, s & 0xFFFF, v);
+    if (tot + kStepDense > kProbScale) tot = fixed_rebuild<4>(fc, cnt, 256);
+    set_tot(t, tot);
+    count();
+    return sym;
+  }
+  __device__ __forceinline__ int fixed_p(int t) {
+    wave_fence();
+    u32* fc = L.pfc[t];
+    u32* cnt = L.pcnt[t];
+    const u32 v = x & (kProbScale - 1);
+    const u32 e = lane < 8 ? fc[lane] : 0xFFFF0000u;
+    const u64 m = __ballot((e >> 16) <= v);
+    const int sym = 63 - __builtin_clzll(m);
+    const u32 s = rdl(e, sym);
+    if (lane == sym) cnt[sym] += kStepDense;
+    wave_fence();
+    int tot = get_tot(6 + t) + kStepDense;
+    advance(s >> 16, s & 0xFFFF, v);
+    if (tot + kStepDense > kProbScale) tot = fixed_rebuild<1>(fc, cnt, 6);
+    set_tot(6 + t, tot);
+    count();
+    return sym;
+  }
+
+  // --------------------------------------------------------------- colour ---
+  // the record of a context in the LDS cache (one LDS wait on a hit: tag, header and table entry are read together)
+  __device__ __forceinline__ u32* record(int ctxid, ColHdr& h, int& sym, int& fq) {
+    wave_fence();
+    const int slot = (ctxid ^ (ctxid >> 7)) & (CACHE_N - 1);
+    u32* r = L.crec[slot];
+    const u32 tg = L.ctag[slot];
+    u32 a = r[0], b = r[1], c2 = r[2];
+    u32 sy = lane < 16 ? ((const u8*)r)[16 + lane] : 0, fv = lane < 16 ? ((const u16*)r)[16 + lane] : 0;
+    const int tag = (int)rfl(tg);
+    if (tag != ctxid + 1) {
+      if (tag && lane < 16) ((u32*)&gstates[tag - 1])[lane] = r[lane];
+      if (lane < 16) r[lane] = ((const u32*)&gstates[ctxid])[lane];
+      if (lane == 0) L.ctag[slot] = (u16)(ctxid + 1);
+      wave_fence();
+      a = r[0];
+      b = r[1];
+      c2 = r[2];
+      sy = lane < 16 ? ((const u8*)r)[16 + lane] : 0;
+      fv = lane < 16 ? ((const u16*)r)[16 + lane] : 0;
+    }
+    h = unpack(rfl(a), rfl(b), rfl(c2));
+    const bool act = lane < h.d && (h.kind == 4 || h.kind == 5);
+    sym = act ? (int)sy : 0;
+    fq = act ? (int)fv : 0;
+    return r;
+  }
+  __device__ __forceinline__ void flush_records() {
+    wave_fence();
+    for (int slot = 0; slot < CACHE_N; slot++) {
+      const int tag = (int)rfl((u32)L.ctag[slot]);
+      if (tag && lane < 16) ((u32*)&gstates[tag - 1])[lane] = L.crec[slot][lane];
+    }
+  }
+  // decodeC (screencap.h:318-333)
+  __device__ __forceinline__ int colour(int ctxid) {
+    tick();
+    ColHdr h;
+    int sym, fq;
+    u32* r = record(ctxid, h, sym, fq);
+    int c;
+    if (h.kind < 4) {
+      c = (int)take_byte();
+      note_raw(r, h, c, sym, fq);
+    } else {
+      u32 fr, cf;
+      const u32 v = x & (kProbScale - 1);
+      c = h.kind <= 5 ? small_op<true>(r, h, sym, fq, (int)v, fr, cf) : dense_op<true>(r, h, (int)v, fr, cf);
+      advance(cf, fr, v);
+    }
+    wave_fence();
+    if (h.kind == 4 || h.kind == 5) store_small(r, h.d, sym, fq);
+    store_header(r, h);
+    wave_fence();
+    count();
+    return c;
+  }
+};
+
+// One wave per key frame (DecompressI, screencap.cpp:414-498).
+// Decoded pixels go to an LDS ring that always holds the last two rows (the
+// predictors read "previous", "top" and "top-left" from it) and every finished
+// row is flushed to HBM with wide stores; the plane in HBM is never read back.
+__global__ __launch_bounds__(64) void k_decode_intra_w(const u8* __restrict__ packets, const u8* packets_end, const DecFrame* __restrict__ frames, u8* __restrict__ planes,
+                                                       Geom g, ColState* __restrict__ states, Arena arena, int f0, u32* __restrict__ status, int ring_bytes) {
+  __shared__ WaveLds L;
+  extern __shared__ __align__(16) u8 pix[];  // ring_bytes (power of two >= 2*S + 1024)
+  const DecFrame fr = frames[blockIdx.x];
+  u8* dst = planes + (size_t)fr.slot * g.plane_stride;
+  const int lane = lane_id();
+  const u32 pmask = (u32)ring_bytes - 1u;
+  for (int i = lane; i < CACHE_N; i += 64) L.ctag[i] = 0;
+  const u8* payload = packets + fr.src_off + 1;  // after the frame header byte
+  WaveDec D(L, payload, packets_end, states + (size_t)blockIdx.x * NCOLCTX, arena, f0);
+  D.fixed_init();
+  wave_fence();
+  D.stream_init();
+  D.x = D.take_u32();
+  const int W = g.W, H = g.H, S = g.S;
+  const int chunk = W < 64 ? W : 64;
+
+  auto ctx_c0 = [&](u32 lp) __attribute__((always_inline)) { return (int)(((lp >> 18) & 63) | (((lp >> 10) & 63) << 6)); };  // (b>>2) | (g>>2)<<6
+  auto get_rgb = [&](u32 lp) __attribute__((always_inline)) -> u32 {  // DecodeRGB, screencap.cpp:662-679; lp = pixel that sets the first context
+    const int c0 = D.colour(ctx_c0(lp));
+    const int c1 = D.colour(4096 + ((c0 >> 2) | (((lp >> 18) & 63) << 6)));
+    const int c2 = D.colour(8192 + ((c1 >> 2) | ((c0 >> 2) << 6)));
+    return (u32)c0 | ((u32)c1 << 8) | ((u32)c2 << 16);
+  };
+  auto put3 = [&](u32 i, u32 v) __attribute__((always_inline)) {
+    pix[i & pmask] = (u8)v;
+    pix[(i + 1) & pmask] = (u8)(v >> 8);
+    pix[(i + 2) & pmask] = (u8)(v >> 16);
+  };
+  // pixel (xq, yq); the last pixel of a row also clears the row padding, which the
+  // top-left predictor of the row after next reads (screencap.cpp:881, DecompressFrame :1524-1528)
+  auto put_px = [&](int xq, int yq, u32 v) __attribute__((always_inline)) {
+    const u32 i = (u32)(yq * S + xq * 3);
+    put3(i, v);
+    if (xq == W - 1)
+      for (int q = W * 3; q < S; q++) pix[((u32)(yq * S + q)) & pmask] = 0;
+  };
+  auto get3 = [&](u32 i) __attribute__((always_inline)) -> u32 { return (u32)pix[i & pmask] | ((u32)pix[(i + 1) & pmask] << 8) | ((u32)pix[(i + 2) & pmask] << 16); };
+  // rows [from, to) are complete in the ring: copy them to the plane (row padding is zero, DecompressFrame :1524-1528)
+  int flushed = 0;
+  auto flush_rows = [&](int to) __attribute__((always_inline)) {
+    wave_fence();
+    for (; flushed < to; flushed++) {
+      const u32 rb = (u32)flushed * (u32)S;
+      const int pad0 = W * 3;
+      if (((S | ring_bytes) & 15) == 0 && (rb & 15) == 0) {
+        for (int o = lane * 16; o < S; o += 1024) {
+          uint4 v = *(const uint4*)(pix + ((rb + o) & pmask));
+          if (o + 16 > pad0) {  // zero the padding bytes of the last vector
+            u8 b[16];
+            __builtin_memcpy(b, &v, 16);
+            for (int q = 0; q < 16; q++)
+              if (o + q >= pad0) b[q] = 0;
+            __builtin_memcpy(&v, b, 16);
+          }
+          *(uint4*)(dst + rb + o) = v;
+        }
+      } else {
+        for (int o = lane * 4; o < S; o += 256) {
+          u32 v = *(const u32*)(pix + ((rb + o) & pmask));
+          if (o + 4 > pad0) v &= (o >= pad0) ? 0u : ((1u << (8 * (pad0 - o))) - 1u);
+          *(u32*)(dst + rb + o) = v;
+        }
+      }
+    }
+  };
+
+  u32 lastpix = 0;  // last decoded pixel (3 bytes), wave-uniform; 0 gives context 0 for the first pixel (cx = cx1 = 0, :419)
+  // One loop for both phases so that every model routine is instantiated once:
+  //   header phase (k < W+1): literal + run length over the first row and pixel (0,1)  (:421-438)
+  //   body: pixel type, literal if type 0, run length                                  (:443-494)
+  int k = 0, xx = 0, y = 0, t = 0;
+  while (y < H && !D.bad) {
+    const bool hdr = k < W + 1;
+    if (!hdr) {
+      D.tick();
+      t = D.fixed_p(t);
+    }
+    u32 px = lastpix;
+    if (hdr || t == 0) px = get_rgb(lastpix);
+    D.tick();
+    const int n = D.fixed_n(hdr ? 0 : t);
+    if (n < 1 || t == 3 || (long long)y * W + xx + n > (long long)H * W || (hdr && k + n > W + 1)) {
+      D.bad = true;
+      break;
+    }
+    if (hdr) k += n;
+    if (hdr || t <= 1) {  // literal, or copy of the previous pixel: every pixel of the run has the same value
+      for (int q = lane; q < n; q += 64) {
+        int xq = xx + q, yq = y;
+        while (xq >= W) {
+          xq -= W;
+          yq++;
+        }
+        put_px(xq, yq, px);
+      }
+      lastpix = px;
+    } else {
+      for (int q0 = 0; q0 < n; q0 += chunk) {
+        wave_fence();  // pixels written by other lanes are read below
+        const int m = min(chunk, n - q0);
+        int xq = xx + q0 + lane, yq = y;
+        while (xq >= W) {
+          xq -= W;
+          yq++;
+        }
+        const bool act = lane < m;
+        const u32 i = (u32)(yq * S + xq * 3);
+        u32 v = 0;
+        if (t == 2) {
+          if (act) v = get3(i - S);
+        } else if (t == 5) {
+          if (act) v = get3(i - S - 3);
+        } else {  // gradient: previous + top - topleft, a running sum along the run (mod 256 per channel)
+          u32 tp = 0, tl = 0;
+          if (act) {
+            tp = get3(i - S);
+            tl = get3(i - S - 3);
+          }
+          int d0 = (int)(tp & 255) - (int)(tl & 255), d1 = (int)((tp >> 8) & 255) - (int)((tl >> 8) & 255), d2 = (int)((tp >> 16) & 255) - (int)((tl >> 16) & 255);
+          if (!act) d0 = d1 = d2 = 0;
+          d0 = wave_incl_scan(d0);
+          d1 = wave_incl_scan(d1);
+          d2 = wave_incl_scan(d2);
+          v = (u32)(((int)(lastpix & 255) + d0) & 255) | ((u32)(((int)((lastpix >> 8) & 255) + d1) & 255) << 8) | ((u32)(((int)((lastpix >> 16) & 255) + d2) & 255) << 16);
+        }
+        if (act) put_px(xq, yq, v);
+        wave_fence();
+        lastpix = rdl(v, m - 1);
+      }
+    }
+    xx += n;
+    while (xx >= W) {
+      xx -= W;
+      y++;
+    }
+    if (flushed < y) flush_rows(y);
+  }
+  if (!D.bad) flush_rows(H);
+  D.flush_records();
+  if (D.bad && lane == 0) atomicOr(status, 4u);
+
+}
+
+// ------------------------------------------------------------- encoder chains ---
+// Non-empty colour chains, split by length so that the long ones start first.
+__global__ __launch_bounds__(256) void k_chain_lists(const u32* __restrict__ cstart, int nchains, u32 thresh, u32* __restrict__ lists, u32 cap, u32* __restrict__ counts) {
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= nchains) return;
+  const u32 len = cstart[q + 1] - cstart[q];
+  if (!len) return;
+  const int which = len >= thresh ? 0 : 1;
+  const u32 idx = atomicAdd(&counts[which], 1u);
+  if (idx < cap) lists[(size_t)which * cap + idx] = (u32)q;
+}
+
+// One wave per colour chain (Context::encode over the symbols of one context in stream
+// order, ans_contexts.cpp:34-50).  The whole state of the chain stays in registers:
+// header in scalar registers, small table one entry per lane; only the 256-bit symbol
+// set (LDS) and dense tables (arena) live in memory.  Entries are produced 64 at a
+// time and scattered to their stream positions.
+__global__ __launch_bounds__(64) void k_colour_chain_w(const u32* __restrict__ skeys, const u32* __restrict__ svals, const u32* __restrict__ cstart, const u32* __restrict__ list,
+                                                       const u32* __restrict__ count, int f0, Arena arena, u32* __restrict__ entries) {
+  __shared__ u32 rec[16];
+  __shared__ u16 tmp[256];
+  WaveModel M(tmp, arena, f0);
+  const int lane = M.lane;
+  const u32 n = *count;
+  for (u32 li = blockIdx.x; li < n; li += gridDim.x) {
+    const u32 q = list[li];
+    const u32 start = cstart[q], len = cstart[q + 1] - start;
+    ColHdr h = WaveModel::unpack(0, 0, 0);
+    int sym = 0, fq = 0;
+    for (u32 base = 0; base < len; base += 64) {
+      const int m = (int)min(64u, len - base);
+      u32 key = 0, pos = 0, mine = 0;
+      if (lane < m) {
+        key = skeys[start + base + lane];
+        pos = svals[start + base + lane];
+      }
+      for (int j = 0; j < m; j++) {
+        const int c = (int)(rdl(key, j) & 255u);
+        u32 fr = 0, cf = (u32)c;
+        wave_fence();
+        if (h.kind < 4)
+          M.note_raw(rec, h, c, sym, fq);
+        else if (h.kind <= 5)
+          M.small_op<false>(rec, h, sym, fq, c, fr, cf);
+        else
+          M.dense_op<false>(rec, h, c, fr, cf);
+        if (lane == j) mine = (fr & 0xFFFFu) | (cf << 16);
+      }
+      if (lane < m) entries[pos] = mine;
+    }
+  }
+}
+
+}  // namespace scpr
