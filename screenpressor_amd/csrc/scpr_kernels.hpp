@@ -687,7 +687,7 @@ struct RansBlock {
 // One lane per block of <= 131072 entries, processed last to first; bytes are
 // written backwards into the block's scratch (ransmt.h:116-134).  x / freq uses
 // the exact 32-bit reciprocal (rans_byte.h:171-240).
-__device__ __forceinline__ void rans_put(u32& x, u8*& p, u32 v, const RansRcp* __restrict__ rcp) {
+__device__ __forceinline__ void rans_put(u32& x, u8*& p, u32 v, const RansRcp* rcp) {
   const u32 fr = v & 0xFFFF, cf = v >> 16;
   if (fr) {
     const u32 x_max = fr << 19;  // ((L >> 12) << 8) * freq
@@ -702,8 +702,12 @@ __device__ __forceinline__ void rans_put(u32& x, u8*& p, u32 v, const RansRcp* _
     *--p = (u8)cf;
   }
 }
-__global__ __launch_bounds__(64) void k_rans(const u32* __restrict__ entries, const RansBlock* __restrict__ blocks, int nblocks, const RansRcp* __restrict__ rcp,
+__global__ __launch_bounds__(64) void k_rans(const u32* __restrict__ entries, const RansBlock* __restrict__ blocks, int nblocks, const RansRcp* __restrict__ rcp_g,
                                              u8* __restrict__ scratch, u32* __restrict__ blksize) {
+  __shared__ RansRcp lrcp[kProbScale + 1];  // reciprocals in LDS: the lookup is off the HBM path
+  for (int i = threadIdx.x; i <= kProbScale; i += 64) lrcp[i] = rcp_g[i];
+  __syncthreads();
+  const RansRcp* rcp = lrcp;
   const int b = blockIdx.x * 64 + threadIdx.x;
   if (b >= nblocks) return;
   const RansBlock blk = blocks[b];

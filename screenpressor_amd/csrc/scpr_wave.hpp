@@ -60,6 +60,7 @@ struct WaveLds {
   u32 ncnt[6][256];
   u32 pfc[6][8];     // pixel-type models
   u32 pcnt[6][8];
+  int ftot[12];  // running count totals: run-length tables 0-5, pixel-type tables 6-11
   u32 crec[CACHE_N][16];
   u16 ctag[CACHE_N];
   u16 tmp[256];
@@ -403,7 +404,6 @@ struct WaveDec : WaveModel {
   // models
   ColState* gstates;
   bool bad = false;
-  int ftot[12] = {2048, 2048, 2048, 2048, 2048, 2048, 2046, 2046, 2046, 2046, 2046, 2046};  // wave-uniform
 
   __device__ __forceinline__ WaveDec(WaveLds& l, const u8* s, const u8* e, ColState* gs, Arena a, int f0_) : WaveModel(l.tmp, a, f0_), L(l), src(s), src_end(e), gstates(gs) {}
 
@@ -414,9 +414,11 @@ struct WaveDec : WaveModel {
     if (p + 16 <= src_end) {
       __builtin_memcpy(&v, p, 16);
     } else {
-      u8 b[16];
-      for (int i = 0; i < 16; i++) b[i] = (p + i < src_end) ? p[i] : (u8)0;
-      __builtin_memcpy(&v, b, 16);
+      u32 w[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int i = 0; i < 16; i++)
+        if (p + i < src_end) w[i >> 2] |= (u32)p[i] << (8 * (i & 3));
+      v = make_uint4(w[0], w[1], w[2], w[3]);
     }
     return v;
   }
@@ -493,6 +495,7 @@ struct WaveDec : WaveModel {
         L.pcnt[t][lane] = lane < 6 ? 341u : 0u;
       }
     }
+    if (lane < 12) L.ftot[lane] = lane < 6 ? 2048 : 2046;
   }
   template <int PER>
   __device__ __forceinline__ int fixed_rebuild(u32* fc, u32* cnt, int nsym) {  // incrCnt rebuild, ans_contexts.h:1075-1090
@@ -521,22 +524,13 @@ struct WaveDec : WaveModel {
     return wave_sum(ns);
   }
   // symbol whose interval holds v; updates the table (decode + incrCnt, :1093-1112, :1070-1091)
-  __device__ __forceinline__ int get_tot(int i) {
-    int v = ftot[0];
-#pragma unroll
-    for (int q = 1; q < 12; q++) v = (i == q) ? ftot[q] : v;
-    return v;
-  }
-  __device__ __forceinline__ void set_tot(int i, int v) {
-#pragma unroll
-    for (int q = 0; q < 12; q++) ftot[q] = (i == q) ? v : ftot[q];
-  }
   __device__ __forceinline__ int fixed_n(int t) {
     wave_fence();
     u32* fc = L.nfc[t];
     u32* cnt = L.ncnt[t];
     const u32 v = x & (kProbScale - 1);
     const uint4 e = ((const uint4*)fc)[lane];
+    const int tot0 = L.ftot[t];
     const u64 m = __ballot((e.x >> 16) <= v);
     const int own = 63 - __builtin_clzll(m);
     int k = ((e.y >> 16) <= v) + ((e.z >> 16) <= v) + ((e.w >> 16) <= v);
@@ -546,10 +540,10 @@ struct WaveDec : WaveModel {
     const int sym = own * 4 + kk;
     if (lane == own) cnt[sym] += kStepDense;
     wave_fence();
-    int tot = get_tot(t) + kStepDense;
+    int tot = (int)rfl((u32)tot0) + kStepDense;
     advance(s >> 16, s & 0xFFFF, v);
     if (tot + kStepDense > kProbScale) tot = fixed_rebuild<4>(fc, cnt, 256);
-    set_tot(t, tot);
+    if (lane == 0) L.ftot[t] = tot;
     count();
     return sym;
   }
@@ -559,15 +553,16 @@ struct WaveDec : WaveModel {
     u32* cnt = L.pcnt[t];
     const u32 v = x & (kProbScale - 1);
     const u32 e = lane < 8 ? fc[lane] : 0xFFFF0000u;
+    const int tot0 = L.ftot[6 + t];
     const u64 m = __ballot((e >> 16) <= v);
     const int sym = 63 - __builtin_clzll(m);
     const u32 s = rdl(e, sym);
     if (lane == sym) cnt[sym] += kStepDense;
     wave_fence();
-    int tot = get_tot(6 + t) + kStepDense;
+    int tot = (int)rfl((u32)tot0) + kStepDense;
     advance(s >> 16, s & 0xFFFF, v);
     if (tot + kStepDense > kProbScale) tot = fixed_rebuild<1>(fc, cnt, 6);
-    set_tot(6 + t, tot);
+    if (lane == 0) L.ftot[6 + t] = tot;
     count();
     return sym;
   }
@@ -685,11 +680,14 @@ __global__ __launch_bounds__(64) void k_decode_intra_w(const u8* __restrict__ pa
         for (int o = lane * 16; o < S; o += 1024) {
           uint4 v = *(const uint4*)(pix + ((rb + o) & pmask));
           if (o + 16 > pad0) {  // zero the padding bytes of the last vector
-            u8 b[16];
-            __builtin_memcpy(b, &v, 16);
-            for (int q = 0; q < 16; q++)
-              if (o + q >= pad0) b[q] = 0;
-            __builtin_memcpy(&v, b, 16);
+            u32 w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+              const int keep = pad0 - (o + 4 * q);  // bytes of this word that are pixel data
+              if (keep <= 0) w[q] = 0;
+              else if (keep < 4) w[q] &= (1u << (8 * keep)) - 1u;
+            }
+            v = make_uint4(w[0], w[1], w[2], w[3]);
           }
           *(uint4*)(dst + rb + o) = v;
         }
