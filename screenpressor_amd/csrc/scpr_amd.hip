@@ -16,6 +16,7 @@
 #include "../../include/scpr_amd.h"
 #include "scpr_kernels.hpp"
 #include "scpr_wave.hpp"
+#include "scpr_inter.hpp"
 
 using namespace scpr;
 
@@ -43,6 +44,21 @@ struct DevBuf {  // grow-only device allocation
     if (e == hipSuccess) cap = want;
     return e;
   }
+  hipError_t reserve_keep(size_t bytes, size_t keep, hipStream_t st) {  // grow, preserving the first `keep` bytes
+    if (bytes <= cap) return hipSuccess;
+    void* np = nullptr;
+    size_t want = bytes + bytes / 2 + 4096;
+    hipError_t e = hipMalloc(&np, want);
+    if (e != hipSuccess) return e;
+    if (p && keep) {
+      e = hipMemcpyAsync(np, p, std::min(keep, cap), hipMemcpyDeviceToDevice, st);
+      if (e == hipSuccess) e = hipStreamSynchronize(st);
+    }
+    if (p) (void)hipFree(p);
+    p = np;
+    cap = want;
+    return e;
+  }
   void release() {
     if (p) (void)hipFree(p);
     p = nullptr;
@@ -54,8 +70,8 @@ struct DevBuf {  // grow-only device allocation
   }
 };
 
-enum Stage { ST_PACK, ST_CLASSIFY, ST_SCAN, ST_SYMBOLS, ST_SORT, ST_FIXED, ST_COLOUR, ST_RANS, ST_GATHER, ST_DECODE, ST_UNPACK, ST_COUNT };
-const char* kStageNames[ST_COUNT] = {"pack", "classify", "scan", "symbols", "sort", "fixed_chain", "colour_chain", "rans", "gather", "decode", "unpack"};
+enum Stage { ST_PACK, ST_CLASSIFY, ST_INTER, ST_SCAN, ST_SYMBOLS, ST_SORT, ST_FIXED, ST_COLOUR, ST_RANS, ST_GATHER, ST_DECODE, ST_UNPACK, ST_COUNT };
+const char* kStageNames[ST_COUNT] = {"pack", "classify", "inter", "scan", "symbols", "sort", "fixed_chain", "colour_chain", "rans", "gather", "decode", "unpack"};
 
 }  // namespace
 
@@ -79,6 +95,14 @@ struct scpr_codec {
   DevBuf flags, slotlist, genlist, bases, totals, runs, runpos, keys[2], vals[2], hist, cstart, sorttmp, scantmp, entries, ranges;
   DevBuf rblocks, rscratch, rsize, packets, pktoff, blkdst, outsizes, total64, arena, arena_top, err, rcp;
   DevBuf decframes, decstates, hoststage_in, hoststage_out, chainlists, chaincounts;
+  // P-frame buffers
+  DevBuf kinds, pidx, fidx, pframes, pflag, binfo, smv, btype, bmv, bcnt, boff, bflag, pinfo, ptot, pbase, misc, miscpos, miscranges;
+  // state of the live generation, carried between calls (models are reset only by key frames, screencap.cpp:1118)
+  DevBuf mvs, fixed_persist, misc_persist, colour_persist;
+  bool live_valid = false;   // a generation is live (a key frame or flat frame has been coded)
+  bool live_has_state = false;  // ... and it has coded symbols (a flat frame renews the models without coding any)
+  u32 live_stamp = 0, next_stamp = 1;
+  size_t arena_used_bound = 0;  // upper bound of dense tables held by the live generation
   // timing
   hipEvent_t ev[ST_COUNT + 1][2];
   bool ev_used[ST_COUNT];
@@ -165,6 +189,31 @@ static int ensure_codec(scpr_codec* c, int version) {  // CreateCodec + CScreenC
   HIPCHK(c->bases.reserve(ns * sizeof(FrameBase)));
   HIPCHK(c->totals.reserve(64));
   HIPCHK(c->ranges.reserve(ns * sizeof(GenRange)));
+  {
+    const size_t nblk = (size_t)((g.W + 15) / 16) * ((g.H + 15) / 16);
+    HIPCHK(c->kinds.reserve(ns * 4));
+    HIPCHK(c->pidx.reserve(ns * 4));
+    HIPCHK(c->fidx.reserve(ns * 4));
+    HIPCHK(c->pframes.reserve(ns * sizeof(PFrame)));
+    HIPCHK(c->pflag.reserve(ns * 4));
+    HIPCHK(c->pinfo.reserve(ns * 8));
+    HIPCHK(c->ptot.reserve(ns * 32));
+    HIPCHK(c->pbase.reserve(ns * sizeof(PBase)));
+    HIPCHK(c->miscranges.reserve(ns * sizeof(MiscRange)));
+    HIPCHK(c->mvs.reserve(nblk * 4));
+    HIPCHK(hipMemsetAsync(c->mvs.p, 0, nblk * 4, c->stream));  // calloc'd in the reference (screencap.cpp:96-97), never reset
+    HIPCHK(c->fixed_persist.reserve(12 * sizeof(FixedPersist)));
+    HIPCHK(c->misc_persist.reserve(MC_COUNT * sizeof(FixedPersist)));
+    HIPCHK(hipMemsetAsync(c->fixed_persist.p, 0, 12 * sizeof(FixedPersist), c->stream));
+    HIPCHK(hipMemsetAsync(c->misc_persist.p, 0, MC_COUNT * sizeof(FixedPersist), c->stream));
+    HIPCHK(c->colour_persist.reserve((size_t)NCOLCTX * sizeof(ColState)));
+    HIPCHK(hipMemsetAsync(c->colour_persist.p, 0, (size_t)NCOLCTX * sizeof(ColState), c->stream));
+  }
+  c->live_valid = false;
+  c->live_has_state = false;
+  c->live_stamp = 0;
+  c->next_stamp = 1;
+  c->arena_used_bound = 0;
   HIPCHK(c->arena_top.reserve(16));
   HIPCHK(c->err.reserve(64));
   HIPCHK(c->total64.reserve(16));
@@ -180,50 +229,100 @@ static int ensure_codec(scpr_codec* c, int version) {  // CreateCodec + CScreenC
 }
 
 // ---------------------------------------------------------------------------
-// Encode one chunk of key frames (all in `slot_ids`, generation = index).
+// One chunk of frames (all resident as RGB24 planes in slots 0..n-1).
 // ---------------------------------------------------------------------------
 struct ChunkFrame {
-  int slot;
-  int kind;      // 0 coded I, 1 flat, 2 coded P, 3 unchanged P
+  int kind;      // 0 coded key frame, 1 flat key frame, 2 P-frame
+  int gen;       // model generation inside the chunk
   u32 hdr, hdr_len;
 };
 
-static int encode_intra_frames(scpr_codec* c, const std::vector<int>& islots, std::vector<FrameBase>& hb) {
+static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int ngens, bool load_first, std::vector<FrameBase>& hb, std::vector<u32>& pchanged) {
   const Geom& g = c->g;
-  const int n = (int)islots.size();
-  hb.clear();
-  if (!n) return SCPR_OK;
   hipStream_t st = c->stream;
-  HIPCHK(hipMemcpyAsync(c->slotlist.p, islots.data(), n * sizeof(int), hipMemcpyHostToDevice, st));
-  std::vector<int> gens(n);
-  for (int i = 0; i < n; i++) gens[i] = i;
-  HIPCHK(hipMemcpyAsync(c->genlist.p, gens.data(), n * sizeof(int), hipMemcpyHostToDevice, st));
-  const int* d_slots = c->slotlist.as<int>();
   const u8* planes = c->planes.as<u8>();
-
-  if (c->loss_mask != 0xFFFFFFFFu) {
-    dim3 gl((g.H * (g.S >> 2) + 255) / 256, n);
-    hipLaunchKernelGGL(k_loss, gl, dim3(256), 0, st, c->planes.as<u8>(), g, d_slots, c->loss_mask, c->corr_mask);
+  const int nbx = (g.W + 15) / 16, nby = (g.H + 15) / 16, nblocks = nbx * nby;
+  const MvParams mp{(int)std::min<u32>(c->prm.high_range_x, 256), (int)std::min<u32>(c->prm.high_range_y, 256), (int)c->prm.low_range_x, (int)c->prm.low_range_y};
+  std::vector<int> islots, igens, ifidx, kinds(n), pidx(n, -1), slots(n);
+  std::vector<PFrame> pfr;
+  std::vector<int> pgen, pfidx, lossslots;
+  for (int i = 0; i < n; i++) {
+    kinds[i] = cf[i].kind;
+    slots[i] = i;
+    if (cf[i].kind == 0) {
+      islots.push_back(i);
+      igens.push_back(cf[i].gen);
+      ifidx.push_back(i);
+      lossslots.push_back(i);
+    } else if (cf[i].kind == 2) {
+      pidx[i] = (int)pfr.size();
+      pfr.push_back({i, i > 0 ? i - 1 : c->slots});
+      pgen.push_back(cf[i].gen);
+      pfidx.push_back(i);
+      lossslots.push_back(i);
+    }
   }
-  stage_begin(c, ST_CLASSIFY);
-  hipLaunchKernelGGL(k_tiles<false>, dim3(g.ntiles, n), dim3(256), 0, st, planes, g, d_slots, c->exitmap.as<u8>(), (const u8*)nullptr, (u32*)nullptr, (u32*)nullptr);
-  hipLaunchKernelGGL(k_entries, dim3(n), dim3(64), 0, st, c->exitmap.as<u8>(), c->entry.as<u8>(), g, d_slots);
-  hipLaunchKernelGGL(k_tiles<true>, dim3(g.ntiles, n), dim3(256), 0, st, planes, g, d_slots, (u8*)nullptr, c->entry.as<u8>(), c->runrec.as<u32>(), c->tilecnt.as<u32>());
-  hipLaunchKernelGGL(k_header, dim3(n), dim3(64), 0, st, planes, g, d_slots, c->hdrrec.as<u32>(), c->hdrcnt.as<u32>());
-  stage_end(c, ST_CLASSIFY);
-  stage_begin(c, ST_SCAN);
-  hipLaunchKernelGGL(k_scan_tiles, dim3(n), dim3(256), 0, st, c->tilecnt.as<u32>(), c->tileoff.as<u32>(), c->frametot.as<u32>(), g, d_slots);
-  hipLaunchKernelGGL(k_bases, dim3(1), dim3(64), 0, st, c->frametot.as<u32>(), c->hdrcnt.as<u32>(), d_slots, n, c->bases.as<FrameBase>(), c->totals.as<u32>());
-  stage_end(c, ST_SCAN);
-  hb.resize(n);
-  u32 tot[3];
+  const int ni = (int)islots.size(), np = (int)pfr.size();
+  hb.assign(n, FrameBase{});
+  pchanged.assign(np, 0);
+  if (ni + np == 0) return SCPR_OK;
+  HIPCHK(hipMemcpyAsync(c->kinds.p, kinds.data(), n * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(c->pidx.p, pidx.data(), n * 4, hipMemcpyHostToDevice, st));
+  if (c->loss_mask != 0xFFFFFFFFu) {  // DoLoss: coded frames only (flat frames keep the source bytes, screencap.cpp:1488-1499)
+    HIPCHK(hipMemcpyAsync(c->slotlist.p, lossslots.data(), lossslots.size() * 4, hipMemcpyHostToDevice, st));
+    dim3 gl((g.H * (g.S >> 2) + 255) / 256, (unsigned)lossslots.size());
+    hipLaunchKernelGGL(k_loss, gl, dim3(256), 0, st, c->planes.as<u8>(), g, c->slotlist.as<int>(), c->loss_mask, c->corr_mask);
+    HIPCHK(hipStreamSynchronize(st));  // slotlist is reused below
+  }
+  const int* d_slots = c->slotlist.as<int>();
+  if (ni) {
+    HIPCHK(hipMemcpyAsync(c->slotlist.p, islots.data(), ni * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(c->genlist.p, igens.data(), ni * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(c->fidx.p, ifidx.data(), ni * 4, hipMemcpyHostToDevice, st));
+    stage_begin(c, ST_CLASSIFY);
+    hipLaunchKernelGGL(k_tiles<false>, dim3(g.ntiles, ni), dim3(256), 0, st, planes, g, d_slots, c->exitmap.as<u8>(), (const u8*)nullptr, (u32*)nullptr, (u32*)nullptr);
+    hipLaunchKernelGGL(k_entries, dim3(ni), dim3(64), 0, st, c->exitmap.as<u8>(), c->entry.as<u8>(), g, d_slots);
+    hipLaunchKernelGGL(k_tiles<true>, dim3(g.ntiles, ni), dim3(256), 0, st, planes, g, d_slots, (u8*)nullptr, c->entry.as<u8>(), c->runrec.as<u32>(), c->tilecnt.as<u32>());
+    hipLaunchKernelGGL(k_header, dim3(ni), dim3(64), 0, st, planes, g, d_slots, c->hdrrec.as<u32>(), c->hdrcnt.as<u32>());
+    stage_end(c, ST_CLASSIFY);
+    stage_begin(c, ST_SCAN);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(ni), dim3(256), 0, st, c->tilecnt.as<u32>(), c->tileoff.as<u32>(), c->frametot.as<u32>(), g, d_slots);
+    stage_end(c, ST_SCAN);
+  }
+  if (np) {
+    const size_t pb = (size_t)np * nblocks;
+    HIPCHK(c->binfo.reserve(pb * 4));
+    HIPCHK(c->smv.reserve(pb * 4));
+    HIPCHK(c->btype.reserve(pb));
+    HIPCHK(c->bmv.reserve(pb * 4));
+    HIPCHK(c->bcnt.reserve(pb * 4));
+    HIPCHK(c->boff.reserve(pb * sizeof(BOff)));
+    HIPCHK(c->bflag.reserve(pb * 4));
+    HIPCHK(hipMemcpyAsync(c->pframes.p, pfr.data(), np * sizeof(PFrame), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(c->pflag.p, 0, (size_t)np * 4, st));
+    stage_begin(c, ST_INTER);
+    hipLaunchKernelGGL(k_pblocks, dim3((nblocks + 3) / 4, np), dim3(64), 0, st, planes, g, c->pframes.as<PFrame>(), c->binfo.as<u32>(), c->pflag.as<u32>());
+    hipLaunchKernelGGL(k_mvsearch, dim3(nblocks, np), dim3(64), 0, st, planes, g, c->pframes.as<PFrame>(), c->binfo.as<u32>(), mp, c->smv.as<u32>());
+    hipLaunchKernelGGL(k_mvresolve, dim3(1), dim3(64), 0, st, planes, g, c->pframes.as<PFrame>(), np, c->binfo.as<u32>(), c->smv.as<u32>(), mp, c->mvs.as<u32>(), c->btype.as<u8>(),
+                       c->bmv.as<u32>(), c->pinfo.as<int>());
+    hipLaunchKernelGGL(k_pcount, dim3((nblocks + 63) / 64, np), dim3(64), 0, st, planes, g, c->pframes.as<PFrame>(), c->binfo.as<u32>(), c->btype.as<u8>(), c->bcnt.as<u32>());
+    hipLaunchKernelGGL(k_pscan, dim3((np + 63) / 64), dim3(64), 0, st, g, np, c->btype.as<u8>(), c->bmv.as<u32>(), c->bcnt.as<u32>(), c->pinfo.as<int>(), c->boff.as<BOff>(),
+                       c->bflag.as<u32>(), c->ptot.as<u32>());
+    stage_end(c, ST_INTER);
+  }
+  hipLaunchKernelGGL(k_bases, dim3(1), dim3(64), 0, st, c->kinds.as<int>(), c->pidx.as<int>(), n, c->frametot.as<u32>(),
+                     c->hdrcnt.as<u32>(), c->ptot.as<u32>(), c->bases.as<FrameBase>(), c->totals.as<u32>());
+  u32 tot[4];
   HIPCHK(hipMemcpyAsync(hb.data(), c->bases.p, n * sizeof(FrameBase), hipMemcpyDeviceToHost, st));
   HIPCHK(hipMemcpyAsync(tot, c->totals.p, sizeof tot, hipMemcpyDeviceToHost, st));
+  if (np) HIPCHK(hipMemcpyAsync(pchanged.data(), c->pflag.p, (size_t)np * 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
-  const size_t Rtot = tot[0], Ttot = tot[1], Ctot = tot[2];
-  const size_t nchains = (size_t)n * NCOLCTX;
+  const size_t Rtot = tot[0], Ttot = tot[1], Ctot = tot[2], Mtot = tot[3];
+  const size_t nchains = (size_t)ngens * NCOLCTX;
   HIPCHK(c->runs.reserve(Rtot * 4 + 64));
   HIPCHK(c->runpos.reserve(Rtot * 4 + 64));
+  HIPCHK(c->misc.reserve(Mtot * 4 + 64));
+  HIPCHK(c->miscpos.reserve(Mtot * 4 + 64));
   for (int k = 0; k < 2; k++) {
     HIPCHK(c->keys[k].reserve(Ctot * 4 + 64));
     HIPCHK(c->vals[k].reserve(Ctot * 4 + 64));
@@ -231,16 +330,34 @@ static int encode_intra_frames(scpr_codec* c, const std::vector<int>& islots, st
   HIPCHK(c->hist.reserve((nchains + 1) * 4));
   HIPCHK(c->cstart.reserve((nchains + 1) * 4));
   HIPCHK(c->entries.reserve(Ttot * 4 + 64));
-  const size_t arena_cap = Ctot / 16 + 64;
-  HIPCHK(c->arena.reserve(arena_cap * sizeof(DenseTab)));
+  // dense-table arena: tables of the live generation stay valid while it continues
+  if (!load_first) {
+    c->arena_used_bound = 0;
+    HIPCHK(hipMemsetAsync(c->arena_top.p, 0, 4, st));
+  }
+  const size_t arena_cap = c->arena_used_bound + Ctot / 16 + 64;
+  HIPCHK(c->arena.reserve_keep(arena_cap * sizeof(DenseTab), c->arena_used_bound * sizeof(DenseTab), st));
+  c->arena_used_bound = arena_cap;
   HIPCHK(hipMemsetAsync(c->hist.p, 0, (nchains + 1) * 4, st));
-  HIPCHK(hipMemsetAsync(c->arena_top.p, 0, 4, st));
   c->dbg_entries = (int64_t)Ttot;
 
   stage_begin(c, ST_SYMBOLS);
-  hipLaunchKernelGGL(k_symbols, dim3(g.ntiles + 1, n), dim3(256), 0, st, planes, g, d_slots, c->genlist.as<int>(), c->bases.as<FrameBase>(), c->runrec.as<u32>(),
-                     c->tilecnt.as<u32>(), c->tileoff.as<u32>(), c->entry.as<u8>(), c->hdrrec.as<u32>(), c->runs.as<u32>(), c->runpos.as<u32>(), c->keys[0].as<u32>(),
-                     c->vals[0].as<u32>(), c->hist.as<u32>());
+  if (ni)
+    hipLaunchKernelGGL(k_symbols, dim3(g.ntiles + 1, ni), dim3(256), 0, st, planes, g, d_slots, c->genlist.as<int>(), c->fidx.as<int>(), c->bases.as<FrameBase>(), c->runrec.as<u32>(),
+                       c->tilecnt.as<u32>(), c->tileoff.as<u32>(), c->entry.as<u8>(), c->hdrrec.as<u32>(), c->runs.as<u32>(), c->runpos.as<u32>(), c->keys[0].as<u32>(),
+                       c->vals[0].as<u32>(), c->hist.as<u32>());
+  if (np) {
+    std::vector<PBase> pbv(np);
+    for (int k = 0; k < np; k++) {
+      const FrameBase& b = hb[pfidx[k]];
+      pbv[k] = PBase{b.run_base, b.sym_base, b.col_base, b.misc_base, b.nbt, (u32)pgen[k], 0, 0};
+    }
+    HIPCHK(hipMemcpyAsync(c->pbase.p, pbv.data(), np * sizeof(PBase), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_pemit, dim3((nblocks + 63) / 64 + 1, np), dim3(64), 0, st, planes, g, c->pframes.as<PFrame>(), c->pbase.as<PBase>(), c->binfo.as<u32>(), c->btype.as<u8>(),
+                       c->bmv.as<u32>(), c->boff.as<BOff>(), c->bflag.as<u32>(), c->pinfo.as<int>(), mp, c->runs.as<u32>(), c->runpos.as<u32>(), c->keys[0].as<u32>(),
+                       c->vals[0].as<u32>(), c->hist.as<u32>(), c->misc.as<u32>(), c->miscpos.as<u32>(), c->entries.as<u32>());
+    HIPCHK(hipStreamSynchronize(st));  // pbv is host memory
+  }
   stage_end(c, ST_SYMBOLS);
 
   stage_begin(c, ST_SORT);
@@ -250,7 +367,7 @@ static int encode_intra_frames(scpr_codec* c, const std::vector<int>& islots, st
     HIPCHK(c->scantmp.reserve(tmp));
     HIPCHK(rocprim::exclusive_scan(c->scantmp.p, tmp, c->hist.as<u32>(), c->cstart.as<u32>(), 0u, nchains + 1, rocprim::plus<u32>(), st));
     int genbits = 1;
-    while ((1 << genbits) < n) genbits++;
+    while ((1 << genbits) < ngens) genbits++;
     if (Ctot > 0) {
       size_t stmp = 0;
       HIPCHK(rocprim::radix_sort_pairs(nullptr, stmp, c->keys[0].as<u32>(), c->keys[1].as<u32>(), c->vals[0].as<u32>(), c->vals[1].as<u32>(), Ctot, 8, 22 + genbits, st));
@@ -260,18 +377,39 @@ static int encode_intra_frames(scpr_codec* c, const std::vector<int>& islots, st
   }
   stage_end(c, ST_SORT);
 
-  std::vector<GenRange> rg(n);
-  for (int i = 0; i < n; i++) {
-    rg[i].run_begin = hb[i].run_base;
-    rg[i].run_end = hb[i].run_base + hb[i].nruns;
+  // per-generation ranges of the run list and of the misc list (frames of a generation are consecutive)
+  std::vector<GenRange> rg(ngens, GenRange{0, 0});
+  std::vector<MiscRange> mr(ngens, MiscRange{0, 0});
+  {
+    std::vector<bool> seen(ngens, false);
+    for (int i = 0; i < n; i++) {
+      const int gq = cf[i].gen;
+      if (gq < 0 || cf[i].kind == 1) continue;
+      if (!seen[gq]) {
+        rg[gq].run_begin = hb[i].run_base;
+        mr[gq].begin = hb[i].misc_base;
+        seen[gq] = true;
+      }
+      rg[gq].run_end = hb[i].run_base + hb[i].nruns;
+      mr[gq].end = hb[i].misc_base + hb[i].nmisc;
+    }
   }
-  HIPCHK(hipMemcpyAsync(c->ranges.p, rg.data(), n * sizeof(GenRange), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(c->ranges.p, rg.data(), ngens * sizeof(GenRange), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(c->miscranges.p, mr.data(), ngens * sizeof(MiscRange), hipMemcpyHostToDevice, st));
   stage_begin(c, ST_FIXED);
-  hipLaunchKernelGGL(k_fixed_chain, dim3(NFIXED_I, n), dim3(64), 0, st, c->runs.as<u32>(), c->runpos.as<u32>(), c->ranges.as<GenRange>(), c->entries.as<u32>());
+  hipLaunchKernelGGL(k_fixed_chain, dim3(NFIXED_I, ngens), dim3(64), 0, st, c->runs.as<u32>(), c->runpos.as<u32>(), c->ranges.as<GenRange>(), ngens, load_first ? 1 : 0,
+                     c->fixed_persist.as<FixedPersist>(), c->entries.as<u32>());
+  if (Mtot)
+    hipLaunchKernelGGL(k_misc_chain, dim3(MC_COUNT, ngens), dim3(64), 0, st, c->misc.as<u32>(), c->miscpos.as<u32>(), c->miscranges.as<MiscRange>(), ngens, load_first ? 1 : 0,
+                       c->misc_persist.as<FixedPersist>(), c->entries.as<u32>());
   stage_end(c, ST_FIXED);
+  HIPCHK(hipStreamSynchronize(st));  // rg / mr are host memory
   stage_begin(c, ST_COLOUR);
   {
     Arena ar{c->arena.as<DenseTab>(), c->arena_top.as<u32>(), (u32)arena_cap, c->err.as<u32>()};
+    const u32 stamp_out = (load_first && ngens == 1) ? c->live_stamp : c->next_stamp++;
+    ChainPersist cp{c->colour_persist.as<ColState>(), c->live_stamp, stamp_out, load_first ? 1 : 0, ngens};
+    c->live_stamp = stamp_out;
     const u32 cap = (u32)std::min<size_t>(nchains, Ctot + 1);
     HIPCHK(c->chainlists.reserve((size_t)cap * 8 + 64));
     HIPCHK(c->chaincounts.reserve(16));
@@ -282,7 +420,7 @@ static int encode_intra_frames(scpr_codec* c, const std::vector<int>& islots, st
       const unsigned grid = (unsigned)std::min<u32>(cap, which == 0 ? 16384u : 32768u);
       if (grid)
         hipLaunchKernelGGL(k_colour_chain_w, dim3(grid), dim3(64), 0, st, c->keys[1].as<u32>(), c->vals[1].as<u32>(), c->cstart.as<u32>(), c->chainlists.as<u32>() + (size_t)which * cap,
-                           c->chaincounts.as<u32>() + which, c->f0, ar, c->entries.as<u32>());
+                           c->chaincounts.as<u32>() + which, c->f0, ar, cp, c->entries.as<u32>());
     }
   }
   stage_end(c, ST_COLOUR);
@@ -352,7 +490,7 @@ void scpr_destroy(scpr_codec* c) {
   DevBuf* all[] = {&c->planes, &c->exitmap, &c->entry, &c->runrec, &c->tilecnt, &c->tileoff, &c->hdrrec, &c->hdrcnt, &c->frametot, &c->flags, &c->slotlist, &c->genlist,
                    &c->bases, &c->totals, &c->runs, &c->runpos, &c->keys[0], &c->keys[1], &c->vals[0], &c->vals[1], &c->hist, &c->cstart, &c->sorttmp, &c->scantmp,
                    &c->entries, &c->ranges, &c->rblocks, &c->rscratch, &c->rsize, &c->packets, &c->pktoff, &c->blkdst, &c->outsizes, &c->total64, &c->arena,
-                   &c->arena_top, &c->err, &c->rcp, &c->decframes, &c->decstates, &c->hoststage_in, &c->hoststage_out, &c->chainlists, &c->chaincounts};
+                   &c->arena_top, &c->err, &c->rcp, &c->decframes, &c->decstates, &c->hoststage_in, &c->hoststage_out, &c->chainlists, &c->chaincounts, &c->kinds, &c->pidx, &c->fidx, &c->pframes, &c->pflag, &c->binfo, &c->smv, &c->btype, &c->bmv, &c->bcnt, &c->boff, &c->bflag, &c->pinfo, &c->ptot, &c->pbase, &c->misc, &c->miscpos, &c->miscranges, &c->mvs, &c->fixed_persist, &c->misc_persist, &c->colour_persist};
   for (DevBuf* b : all) b->release();
   for (int s = 0; s < ST_COUNT + 1; s++)
     for (int k = 0; k < 2; k++) (void)hipEventDestroy(c->ev[s][k]);
@@ -376,7 +514,7 @@ int64_t scpr_compress_batch(scpr_codec* c, const void* d_frames, int nframes, in
   hipStream_t st = c->stream;
   const size_t frame_bytes = (size_t)c->pitch_in * g.H;
   int64_t written = 0;
-  HIPCHK(hipMemsetAsync(c->err.p, 0, 4, st));
+  HIPCHK(hipMemsetAsync(c->err.p, 0, 32, st));
   for (int f0 = 0; f0 < nframes; f0 += c->slots) {
     const int n = std::min(c->slots, nframes - f0);
     const u8* src = (const u8*)d_frames + (size_t)f0 * frame_bytes;
@@ -402,18 +540,22 @@ int64_t scpr_compress_batch(scpr_codec* c, const void* d_frames, int nframes, in
 
     // frame-type decisions: CScreenCapt::CompressFrame, screencap.cpp:1488-1511
     std::vector<ChunkFrame> cf(n);
-    std::vector<int> islots;
+    int ngens = 0;
+    bool load_first = false;
     for (int i = 0; i < n; i++) {
       ChunkFrame& fr = cf[i];
-      fr.slot = i;
       const bool flat = hflags[i] == 0;
       const u32 rgb = hflags[n + i] & 0xFFFFFFu;
       if (flat) {
         fr.kind = 1;
         fr.hdr_len = 4;
         fr.hdr = (u32)(1 + (c->version - 1) * 16) | (rgb << 8);
-        // prev/model refresh when the colour differs from the last flat frame (:1490-1494):
-        // it matters to the next P-frame only; key-frame streams need no action here.
+        if (!(c->last_flat && c->last_flat_rgb == rgb)) {  // :1490-1494: prev := this frame, models renewed
+          fr.gen = ngens++;
+          c->live_valid = true;
+        } else {
+          fr.gen = -1;
+        }
         c->last_flat = true;
         c->last_flat_rgb = rgb;
         ftypes[f0 + i] = 0;
@@ -421,32 +563,56 @@ int64_t scpr_compress_batch(scpr_codec* c, const void* d_frames, int nframes, in
       }
       c->last_flat = false;
       if (c->frames_done && ftypes[f0 + i]) {
-        fprintf(stderr, "[scpr] P-frames are not implemented in this build\n");
-        return SCPR_E_PARAM;
+        fr.kind = 2;
+        fr.hdr_len = 1;
+        fr.hdr = 1;
+        if (ngens == 0) {  // continues the generation that was live when the call started
+          ngens = 1;
+          load_first = c->live_valid && c->live_has_state;
+        }
+        fr.gen = ngens - 1;
+        ftypes[f0 + i] = 1;
+      } else {
+        fr.kind = 0;
+        fr.hdr_len = 1;
+        fr.hdr = (u32)(2 + (c->version - 1) * 16);
+        fr.gen = ngens++;
+        c->live_valid = true;
+        ftypes[f0 + i] = 0;
       }
-      fr.kind = 0;
-      fr.hdr_len = 1;
-      fr.hdr = (u32)(2 + (c->version - 1) * 16);
-      ftypes[f0 + i] = 0;
       c->frames_done++;
-      islots.push_back(i);
+    }
+    // a flat frame that renews the models starts a generation of its own; if it is first in the chunk nothing is loaded
+    const bool any_gen = ngens > 0;
+    if (ngens == 0) ngens = 1, load_first = c->live_valid && c->live_has_state;
+    if (any_gen) {  // does the generation that is live after this chunk hold coded symbols?
+      bool coded = false;
+      for (int i = 0; i < n; i++) coded |= cf[i].kind != 1 && cf[i].gen == ngens - 1;
+      c->live_has_state = coded;
     }
     std::vector<FrameBase> hb;
-    rc = encode_intra_frames(c, islots, hb);
+    std::vector<u32> pchanged;
+    rc = encode_chunk(c, n, cf, ngens, load_first, hb, pchanged);
     if (rc != SCPR_OK) return rc;
+    // the last plane of the chunk is the "previous frame" of the next call
+    HIPCHK(hipMemcpyAsync(c->planes.as<u8>() + (size_t)c->slots * g.plane_stride, c->planes.as<u8>() + (size_t)(n - 1) * g.plane_stride, g.plane_stride, hipMemcpyDeviceToDevice, st));
 
     // rANS blocks and packets
     std::vector<RansBlock> blocks;
     std::vector<Packet> pk(n);
     {
-      int k = 0;
+      int pk_i = 0;
       for (int i = 0; i < n; i++) {
         pk[i].hdr_len = cf[i].hdr_len;
         pk[i].hdr = cf[i].hdr;
         pk[i].blk_begin = (u32)blocks.size();
         pk[i].blk_count = 0;
-        if (cf[i].kind == 0) {
-          const FrameBase& b = hb[k++];
+        if (cf[i].kind == 2) {
+          if (!pchanged[pk_i]) pk[i].hdr = 0;  // nothing changed: the frame is the single byte 0 (:1113-1116)
+          pk_i++;
+        }
+        if (cf[i].kind != 1) {
+          const FrameBase& b = hb[i];
           for (u32 o = 0; o < b.nsyms; o += kBlockEntries) {
             blocks.push_back({b.sym_base + o, std::min<u32>(kBlockEntries, b.nsyms - o)});
             pk[i].blk_count++;
@@ -649,7 +815,8 @@ int scpr_debug_colour_chain(int device, const uint8_t* syms, int n, int f0, uint
   HIPCHK(hipMemcpy(dn.p, cnt, 4, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(dt.p, zero, 8, hipMemcpyHostToDevice));
   Arena ar{da.as<DenseTab>(), dt.as<u32>(), (u32)acap, dt.as<u32>() + 1};
-  hipLaunchKernelGGL(k_colour_chain_w, dim3(1), dim3(64), 0, 0, dk.as<u32>(), dv.as<u32>(), dc.as<u32>(), dl.as<u32>(), dn.as<u32>(), f0, ar, de.as<u32>());
+  ChainPersist cp{nullptr, 0, 0, 0, 0};  // nothing loaded, nothing kept
+  hipLaunchKernelGGL(k_colour_chain_w, dim3(1), dim3(64), 0, 0, dk.as<u32>(), dv.as<u32>(), dc.as<u32>(), dl.as<u32>(), dn.as<u32>(), f0, ar, cp, de.as<u32>());
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpy(out, de.p, (size_t)n * 4, hipMemcpyDeviceToHost));
   for (DevBuf* b : {&dk, &dv, &dc, &dl, &dn, &de, &da, &dt}) b->release();

@@ -1,0 +1,659 @@
+// P-frame analysis and symbol emission (CompressP, screencap.cpp:1091-1271).
+//
+//   k_pblocks    per 16x16 block: compare with the previous plane, bounding box of the
+//                changed pixels (DecideBlockTypes :985-1039); 4 blocks per wave, one row per lane
+//   k_mvsearch   per changed block: the fixed-order exact-match search of FindMV (:737-811),
+//                64 candidates per step, first hit by ballot
+//   k_mvresolve  the serial part of FindMV (:715-735): "last found vector" and "vector of the
+//                block above" are tried first and chain through the blocks in raster order
+//                and, through mvs[], through the frames; blocks are resolved 64 at a time
+//                under the current last vector and re-tested only after it changes
+//   k_pcount     per pixel-coded block: greedy predictor runs over the changed rect (:1043-1065)
+//   k_pscan      per frame: stream offsets of every block, block-type run lengths (:1155-1169)
+//   k_pemit      per block: rect / motion / run symbols at their stream positions (:1179-1248)
+#pragma once
+#include "scpr_kernels.hpp"
+
+namespace scpr {
+
+// binfo: bit0 changed, bits 4-7 sx1, 8-11 sy1, 12-15 sx2 (inclusive), 16-19 sy2 (inclusive), 20-22 type (1 whole, 2 partial)
+__device__ __forceinline__ u32 binfo_pack(int sx1, int sy1, int sx2, int sy2, int type) {
+  return 1u | ((u32)sx1 << 4) | ((u32)sy1 << 8) | ((u32)sx2 << 12) | ((u32)sy2 << 16) | ((u32)type << 20);
+}
+struct Rect {
+  int x1, y1, x2, y2;  // absolute, exclusive end
+};
+__device__ __forceinline__ Rect binfo_rect(u32 v, int bx, int by) {
+  Rect r;
+  r.x1 = bx * 16 + (int)((v >> 4) & 15);
+  r.y1 = by * 16 + (int)((v >> 8) & 15);
+  r.x2 = bx * 16 + (int)((v >> 12) & 15) + 1;
+  r.y2 = by * 16 + (int)((v >> 16) & 15) + 1;
+  return r;
+}
+__device__ __forceinline__ u32 mv_pack(int dx, int dy) { return ((u32)(dx & 0xFFFF)) | ((u32)(dy & 0xFFFF) << 16); }
+__device__ __forceinline__ int mv_x(u32 v) { return (int)(int16_t)(v & 0xFFFF); }
+__device__ __forceinline__ int mv_y(u32 v) { return (int)(int16_t)(v >> 16); }
+
+struct PFrame {
+  int slot, prev_slot;
+};
+
+__global__ __launch_bounds__(64) void k_pblocks(const u8* __restrict__ planes, Geom g, const PFrame* __restrict__ pf, u32* __restrict__ binfo, u32* __restrict__ pflag) {
+  const int pi = blockIdx.y, lane = threadIdx.x;
+  const int nbx = (g.W + 15) >> 4, nby = (g.H + 15) >> 4, nblocks = nbx * nby;
+  const int b = blockIdx.x * 4 + (lane >> 4), row = lane & 15;
+  const u8* cur = planes + (size_t)pf[pi].slot * g.plane_stride;
+  const u8* prv = planes + (size_t)pf[pi].prev_slot * g.plane_stride;
+  const bool vb = b < nblocks;
+  const int by = vb ? b / nbx : 0, bx = vb ? b - by * nbx : 0;
+  const int y = by * 16 + row, bw = min(16, g.W - bx * 16), bh = min(16, g.H - by * 16);
+  int first = 64, last = -1;
+  if (vb && y < g.H) {
+    const u32* c = (const u32*)(cur + (size_t)y * g.S + bx * 48);
+    const u32* p = (const u32*)(prv + (size_t)y * g.S + bx * 48);
+    const int nbytes = bw * 3;
+    for (int k = 0; k * 4 < nbytes; k++) {
+      u32 d = c[k] ^ p[k];
+      const int rem = nbytes - k * 4;
+      if (rem < 4) d &= (1u << (8 * rem)) - 1u;
+      if (d) {
+        first = min(first, k * 4 + (__builtin_ctz(d) >> 3));
+        last = max(last, k * 4 + ((31 - __builtin_clz(d)) >> 3));
+      }
+    }
+  }
+  const bool rc = last >= 0;
+  const u64 m = __ballot(rc);
+  const u32 rows = (u32)(m >> (16 * (lane >> 4))) & 0xFFFFu;
+  int fx = rc ? first / 3 : 64, lx = rc ? last / 3 : -1;
+#pragma unroll
+  for (int d = 1; d < 16; d <<= 1) {
+    fx = min(fx, __shfl_xor(fx, d, 16));
+    lx = max(lx, __shfl_xor(lx, d, 16));
+  }
+  if (vb && row == 0) {
+    u32 v = 0;
+    if (rows) {
+      const int sy1 = __builtin_ctz(rows), sy2 = 31 - __builtin_clz(rows);
+      const int type = (fx > 0 || sy1 > 0 || lx < bw - 1 || sy2 < bh - 1) ? 2 : 1;
+      v = binfo_pack(fx, sy1, lx, sy2, type);
+      if (pflag[pi] == 0) atomicOr(&pflag[pi], 1u);
+    }
+    binfo[(size_t)pi * nblocks + b] = v;
+  }
+}
+
+// SameBlocks (screencap.cpp:817-825): rect of the current plane at (x1,y1) == rect of prev at (x,y)
+__device__ __forceinline__ bool same_rect(const u8* cur, const u8* prv, int S, const Rect& r, int x, int y) {
+  const int wb = (r.x2 - r.x1) * 3, h = r.y2 - r.y1;
+  const u8* a = cur + (size_t)r.y1 * S + r.x1 * 3;
+  const u8* b = prv + (size_t)y * S + x * 3;
+  for (int q = 0; q < h; q++) {
+    int k = 0;
+    for (; k + 4 <= wb; k += 4) {
+      u32 va, vb;
+      __builtin_memcpy(&va, a + k, 4);
+      __builtin_memcpy(&vb, b + k, 4);
+      if (va != vb) return false;
+    }
+    for (; k < wb; k++)
+      if (a[k] != b[k]) return false;
+    a += S;
+    b += S;
+  }
+  return true;
+}
+
+// search windows of FindMV (:691-709)
+struct Windows {
+  int rx1, rx2, ry1, ry2, fx1, fx2, fy1, fy2;
+};
+__device__ __forceinline__ Windows mv_windows(const Rect& r, const Geom& g, int far_x, int far_y, int near_x, int near_y) {
+  Windows w;
+  const int dw = r.x2 - r.x1, dh = r.y2 - r.y1;
+  w.rx1 = max(r.x1 - near_x, 0);
+  w.ry1 = max(r.y1 - near_y, 0);
+  w.rx2 = r.x1 + near_x;
+  w.ry2 = r.y1 + near_y;
+  if (w.rx2 + dw > g.W) w.rx2 = g.W - dw + 1;
+  if (w.ry2 + dh > g.H) w.ry2 = g.H - dh + 1;
+  w.fx1 = max(r.x1 - far_x, 0);
+  w.fy1 = max(r.y1 - far_y, 0);
+  w.fx2 = r.x1 + far_x;
+  w.fy2 = r.y1 + far_y;
+  if (w.fx2 + dw > g.W) w.fx2 = g.W - dw + 1;
+  if (w.fy2 + dh > g.H) w.fy2 = g.H - dh + 1;
+  return w;
+}
+
+struct MvParams {
+  int far_x, far_y, near_x, near_y;
+};
+
+// One wave per changed block: candidates in the order of FindMV's search loops (:737-811).
+// smv: bit31 found, low bits mv_pack.
+__global__ __launch_bounds__(64) void k_mvsearch(const u8* __restrict__ planes, Geom g, const PFrame* __restrict__ pf, const u32* __restrict__ binfo, MvParams mp,
+                                                 u32* __restrict__ smv) {
+  const int pi = blockIdx.y, b = blockIdx.x, lane = threadIdx.x;
+  const int nbx = (g.W + 15) >> 4, nby = (g.H + 15) >> 4, nblocks = nbx * nby;
+  const u32 info = binfo[(size_t)pi * nblocks + b];
+  if (!(info & 1u)) return;
+  const u8* cur = planes + (size_t)pf[pi].slot * g.plane_stride;
+  const u8* prv = planes + (size_t)pf[pi].prev_slot * g.plane_stride;
+  const int by = b / nbx, bx = b - by * nbx;
+  const Rect r = binfo_rect(info, bx, by);
+  const Windows w = mv_windows(r, g, mp.far_x, mp.far_y, mp.near_x, mp.near_y);
+  const int x1 = r.x1, y1 = r.y1;
+  // segment lengths
+  const int common = max(0, min(y1 - w.fy1, w.fy2 - y1 - 1));
+  const int n1 = 2 * common;
+  const int n2 = max(0, (y1 - 1 - common) - w.fy1 + 1);  // remaining rows upwards
+  const int n3 = max(0, w.fy2 - (y1 + 1 + common));      // remaining rows downwards
+  const int n4 = max(0, x1 - w.fx1 + 1), n5 = max(0, w.fx2 - x1);
+  const int ny_up = max(0, y1 - w.ry1 + 1), ny_dn = max(0, w.ry2 - y1 - 1), ny = ny_up + ny_dn;
+  const int nxl = max(0, x1 - w.rx1 + 1), nxr = max(0, w.rx2 - x1 - 1);
+  const int n6 = nxl * ny, n7 = nxr * ny;
+  const int total = n1 + n2 + n3 + n4 + n5 + n6 + n7;
+  auto cand = [&](int i, int& x, int& y) {
+    x = x1;
+    y = y1;
+    if (i < n1) {
+      const int k = i >> 1;
+      y = (i & 1) ? y1 + 1 + k : y1 - 1 - k;
+      return;
+    }
+    i -= n1;
+    if (i < n2) {
+      y = y1 - 1 - common - i;
+      return;
+    }
+    i -= n2;
+    if (i < n3) {
+      y = y1 + 1 + common + i;
+      return;
+    }
+    i -= n3;
+    if (i < n4) {
+      x = x1 - i;
+      return;
+    }
+    i -= n4;
+    if (i < n5) {
+      x = x1 + i;
+      return;
+    }
+    i -= n5;
+    int xi, yi;
+    if (i < n6) {
+      xi = i / ny;
+      yi = i - xi * ny;
+      x = x1 - xi;
+    } else {
+      i -= n6;
+      xi = i / ny;
+      yi = i - xi * ny;
+      x = x1 + 1 + xi;
+    }
+    y = yi < ny_up ? y1 - yi : y1 + 1 + (yi - ny_up);
+  };
+  for (int base = 0; base < total; base += 64) {
+    const int i = base + lane;
+    int x = 0, y = 0;
+    bool ok = false;
+    if (i < total) {
+      cand(i, x, y);
+      ok = same_rect(cur, prv, g.S, r, x, y);
+    }
+    const u64 m = __ballot(ok);
+    if (m) {
+      const int f = __builtin_ctzll(m);
+      const int fx = __shfl(x, f), fy = __shfl(y, f);
+      if (lane == 0) {  // |d| <= 256: two 10-bit fields, biased by 512
+        const int dx = fx - x1, dy = fy - y1;
+        smv[(size_t)pi * nblocks + b] = 0x80000000u | ((u32)(dx + 512) & 0x3FF) | (((u32)(dy + 512) & 0x3FF) << 10);
+      }
+      return;
+    }
+  }
+  if (lane == 0) smv[(size_t)pi * nblocks + b] = 0;
+}
+__device__ __forceinline__ u32 smv_to_mv(u32 s) { return mv_pack((int)(s & 0x3FF) - 512, (int)((s >> 10) & 0x3FF) - 512); }
+
+// Serial resolution over the P-frames of the chunk, in order (mvs[] carries over).
+// btype: 0 unchanged, 1/2 pixel-coded (whole/partial), 3/4 motion (whole/partial).
+// pinfo[pi] = {xx1, xx2}: bounding box corners of the changed blocks as block indices (:1145-1150)
+__global__ __launch_bounds__(64) void k_mvresolve(const u8* __restrict__ planes, Geom g, const PFrame* __restrict__ pf, int npf, const u32* __restrict__ binfo,
+                                                  const u32* __restrict__ smv, MvParams mp, u32* mvs, u8* __restrict__ btype, u32* __restrict__ bmv, int* __restrict__ pinfo) {
+  const int lane = threadIdx.x;
+  const int nbx = (g.W + 15) >> 4, nby = (g.H + 15) >> 4, nblocks = nbx * nby;
+  const int G = min(64, nbx);
+  for (int pi = 0; pi < npf; pi++) {
+    const u8* cur = planes + (size_t)pf[pi].slot * g.plane_stride;
+    const u8* prv = planes + (size_t)pf[pi].prev_slot * g.plane_stride;
+    u32 last = 0;  // last vector found by search (0,0), wave-uniform
+    int bx1 = nbx, bx2 = -1, by1 = nby, by2 = -1;
+    for (int base = 0; base < nblocks; base += G) {
+      const int b = base + lane;
+      const bool vb = lane < G && b < nblocks;
+      const u32 info = vb ? binfo[(size_t)pi * nblocks + b] : 0;
+      const bool changed = info & 1u;
+      const int by = vb ? b / nbx : 0, bx = vb ? b - by * nbx : 0;
+      int type = changed ? (int)((info >> 20) & 7) : 0;
+      u32 my_mv = 0;
+      bool has_mv = false;
+      if (changed) {
+        bx1 = min(bx1, bx);
+        bx2 = max(bx2, bx);
+        by1 = min(by1, by);
+        by2 = max(by2, by);
+      }
+      u64 unresolved = __ballot(changed);
+      if (unresolved) {
+        const Rect r = binfo_rect(info, bx, by);
+        const Windows w = mv_windows(r, g, mp.far_x, mp.far_y, mp.near_x, mp.near_y);
+        const u32 s = changed ? smv[(size_t)pi * nblocks + b] : 0;
+        const u32 umv = (changed && by > 0) ? __hip_atomic_load(&mvs[b - nbx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        while (unresolved) {
+          const bool mine = changed && ((unresolved >> lane) & 1ull);
+          bool ta = false, tb = false;
+          if (mine) {
+            const int sx = r.x1 + mv_x(last), sy = r.y1 + mv_y(last);
+            ta = sx >= w.fx1 && sx < w.fx2 && sy >= w.fy1 && sy < w.fy2 && same_rect(cur, prv, g.S, r, sx, sy);
+            if (!ta && by > 0 && umv != last) {
+              const int ux = r.x1 + mv_x(umv), uy = r.y1 + mv_y(umv);
+              tb = ux >= w.fx1 && ux < w.fx2 && uy >= w.fy1 && uy < w.fy2 && same_rect(cur, prv, g.S, r, ux, uy);
+            }
+          }
+          const u64 A = __ballot(ta), B = __ballot(tb), Sm = __ballot(mine && !ta && !tb && (s >> 31));
+          const int f = Sm ? __builtin_ctzll(Sm) : 64;
+          const u64 upto = f >= 63 ? ~0ull : ((2ull << f) - 1ull);
+          if (mine && ((upto >> lane) & 1ull)) {
+            if (ta) {
+              my_mv = last;
+              has_mv = true;
+            } else if (tb) {
+              my_mv = umv;
+              has_mv = true;
+            } else if (lane == f) {
+              my_mv = smv_to_mv(s);
+              has_mv = true;
+            }
+          }
+          if (f < 64) last = __shfl(my_mv, f);
+          unresolved &= ~upto;
+          (void)A;
+          (void)B;
+        }
+      }
+      if (vb) {
+        if (has_mv) {
+          type += 2;
+          __hip_atomic_store(&mvs[b], my_mv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        btype[(size_t)pi * nblocks + b] = (u8)type;
+        bmv[(size_t)pi * nblocks + b] = my_mv;
+      }
+    }
+    // bounding box of the changed blocks
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      bx1 = min(bx1, __shfl_xor(bx1, d));
+      by1 = min(by1, __shfl_xor(by1, d));
+      bx2 = max(bx2, __shfl_xor(bx2, d));
+      by2 = max(by2, __shfl_xor(by2, d));
+    }
+    if (lane == 0) {
+      pinfo[pi * 2] = bx2 < 0 ? 0 : by1 * nbx + bx1;
+      pinfo[pi * 2 + 1] = bx2 < 0 ? -1 : by2 * nbx + bx2;
+    }
+  }
+}
+
+// ---- inter predictors (GetPixelTypeP / PixelTypeFitsP and the edge forms, :525-604) ----
+__device__ __forceinline__ bool eq3p(const u8* a, const u8* b) { return a[0] == b[0] && a[1] == b[1] && a[2] == b[2]; }
+__device__ __forceinline__ bool grad3p(const u8* p, int off) {
+  return p[0] == (int)p[-3] + (int)p[off + 3] - (int)p[off] && p[1] == (int)p[-2] + (int)p[off + 4] - (int)p[off + 1] && p[2] == (int)p[-1] + (int)p[off + 5] - (int)p[off + 2];
+}
+__device__ __forceinline__ int inter_type(const u8* p, const u8* pr, int off, bool inner) {
+  if (!inner) return eq3p(p, pr) ? 3 : 0;
+  if (eq3p(p, p - 3)) return 1;
+  if (eq3p(p, pr)) return 3;
+  if (eq3p(p, p + off)) return 5;
+  if (eq3p(p, p + off + 3)) return 2;
+  if (grad3p(p, off)) return 4;
+  return 0;
+}
+__device__ __forceinline__ bool inter_fits(int t, const u8* p, const u8* pr, const u8* lastp, int off, bool inner) {
+  if (!inner) return t == 0 ? eq3p(p, lastp) : t == 3 ? eq3p(p, pr) : false;
+  switch (t) {
+    case 0: return eq3p(p, lastp);
+    case 1: return eq3p(p, p - 3);
+    case 2: return eq3p(p, p + off + 3);
+    case 3: return eq3p(p, pr);
+    case 4: return grad3p(p, off);
+    default: return eq3p(p, p + off);
+  }
+}
+
+// Walks the greedy runs of one changed rect (:1043-1065) and calls emit(type, n, first_index, last_index)
+// for each run (indices are byte offsets into the plane).
+template <class Emit>
+__device__ __forceinline__ void walk_rect_runs(const u8* cur, const u8* prv, int S, const Rect& r, Emit&& emit) {
+  const int off = -S - 3;
+  int n = 0, t = 0, lasti = 0, first = 0;
+  bool open = false;
+  for (int y = r.y1; y < r.y2; y++) {
+    int i = y * S + r.x1 * 3;
+    for (int x = r.x1; x < r.x2; x++, i += 3) {
+      const bool inner = x > 0 && y > 0;
+      if (open && n < 255 && inter_fits(t, cur + i, prv + i, cur + lasti, off, inner)) {
+        n++;
+      } else {
+        if (open) emit(t, n, first, lasti);
+        t = inter_type(cur + i, prv + i, off, inner);
+        n = 1;
+        first = i;
+        open = true;
+      }
+      lasti = i;
+    }
+  }
+  if (open) emit(t, n, first, lasti);
+}
+
+// bcnt[b] = runs | literal runs << 16 for pixel-coded blocks
+__global__ __launch_bounds__(64) void k_pcount(const u8* __restrict__ planes, Geom g, const PFrame* __restrict__ pf, const u32* __restrict__ binfo, const u8* __restrict__ btype,
+                                               u32* __restrict__ bcnt) {
+  const int pi = blockIdx.y, b = blockIdx.x * 64 + threadIdx.x;
+  const int nbx = (g.W + 15) >> 4, nby = (g.H + 15) >> 4, nblocks = nbx * nby;
+  if (b >= nblocks) return;
+  const int type = btype[(size_t)pi * nblocks + b];
+  u32 out = 0;
+  if (type == 1 || type == 2) {
+    const u8* cur = planes + (size_t)pf[pi].slot * g.plane_stride;
+    const u8* prv = planes + (size_t)pf[pi].prev_slot * g.plane_stride;
+    const int by = b / nbx, bx = b - by * nbx;
+    const Rect r = binfo_rect(binfo[(size_t)pi * nblocks + b], bx, by);
+    int nr = 0, nl = 0;
+    walk_rect_runs(cur, prv, g.S, r, [&](int t, int, int, int) {
+      nr++;
+      nl += t == 0;
+    });
+    out = (u32)nr | ((u32)nl << 16);
+  }
+  bcnt[(size_t)pi * nblocks + b] = out;
+}
+
+// Per frame, one thread walks the blocks in raster order (cheap: a few instructions per block):
+//   boff[b] = {symbol offset, run offset, colour-symbol offset, misc offset} relative to the frame's bases
+//   bflag[b] bit0: motion vector equals the last coded one (:1202); bits 8..: index+1 of the previous pixel-coded block
+//   ptot[pi] = {runs, symbols, colour symbols, misc symbols, block-type symbols}
+struct BOff {
+  u32 sym, run, col, misc;
+};
+__global__ __launch_bounds__(64) void k_pscan(Geom g, int npf, const u8* __restrict__ btype, const u32* __restrict__ bmv, const u32* __restrict__ bcnt, const int* __restrict__ pinfo,
+                                              BOff* __restrict__ boff, u32* __restrict__ bflag, u32* __restrict__ ptot) {
+  const int pi = blockIdx.x * 64 + threadIdx.x;
+  if (pi >= npf) return;
+  const int nbx = (g.W + 15) >> 4, nby = (g.H + 15) >> 4, nblocks = nbx * nby;
+  const u8* bt = btype + (size_t)pi * nblocks;
+  const int xx1 = pinfo[pi * 2], xx2 = pinfo[pi * 2 + 1];
+  // block-type run-length symbols: one (type, length) pair per run of equal types, length <= 255
+  u32 nbt = 0;
+  {
+    int oldt = -1, n = -1;
+    for (int x = xx1; x <= xx2; x++) {
+      if (bt[x] == oldt && n < 255)
+        n++;
+      else {
+        nbt += (n > 0) ? 2 : 1;
+        oldt = bt[x];
+        n = 1;
+      }
+    }
+    if (xx2 >= xx1) nbt += 1;
+  }
+  u32 sym = 4 + nbt, run = 0, col = 0, misc = 4 + nbt;
+  u32 lastmv = 0;
+  int prevpix = 0;
+  for (int b = 0; b < nblocks; b++) {
+    const int t = bt[b];
+    BOff o = {sym, run, col, misc};
+    u32 fl = (u32)prevpix << 8;
+    if (t) {
+      if (t == 2 || t == 4) {
+        sym += 4;
+        misc += 4;
+      }
+      if (t >= 3) {
+        const u32 mv = bmv[(size_t)pi * nblocks + b];
+        const bool same = b > 0 && mv == lastmv;
+        sym += same ? 1 : 3;
+        misc += same ? 0 : 2;
+        if (!same) lastmv = mv;
+        fl |= same ? 1u : 0u;
+      } else {
+        const u32 c = bcnt[(size_t)pi * nblocks + b];
+        const u32 nr = c & 0xFFFF, nl = c >> 16;
+        sym += 2 * nr + 3 * nl;
+        run += nr;
+        col += 3 * nl;
+        prevpix = b + 1;
+      }
+    }
+    boff[(size_t)pi * nblocks + b] = o;
+    bflag[(size_t)pi * nblocks + b] = fl;
+  }
+  if (xx2 < xx1) {  // nothing changed: no stream at all
+    sym = run = col = misc = 0;
+    nbt = 0;
+  }
+  u32* o = ptot + (size_t)pi * 8;
+  o[0] = run;
+  o[1] = sym;
+  o[2] = col;
+  o[3] = misc;
+  o[4] = nbt;
+}
+
+// misc fixed-alphabet symbols of a P-frame: ctx << 16 | value, with the stream position
+enum { MC_X = 0, MC_BN = 1, MC_BT = 2, MC_SXY = 3, MC_MX = 7, MC_MY = 8, MC_COUNT = 9 };
+
+struct PBase {  // per P-frame (device copy of the relevant FrameBase fields)
+  u32 run_base, sym_base, col_base, misc_base, nbt, gen, pad0, pad1;
+};
+
+// grid.x = ceil(nblocks/64) + 1; the extra block's thread 0 writes the frame header symbols
+__global__ __launch_bounds__(64) void k_pemit(const u8* __restrict__ planes, Geom g, const PFrame* __restrict__ pf, const PBase* __restrict__ pb, const u32* __restrict__ binfo,
+                                              const u8* __restrict__ btype, const u32* __restrict__ bmv, const BOff* __restrict__ boff, const u32* __restrict__ bflag,
+                                              const int* __restrict__ pinfo, MvParams mp, u32* __restrict__ runs, u32* __restrict__ runpos, u32* __restrict__ keys,
+                                              u32* __restrict__ vals, u32* __restrict__ hist, u32* __restrict__ misc, u32* __restrict__ miscpos, u32* __restrict__ entries) {
+  const int pi = blockIdx.y;
+  const int nbx = (g.W + 15) >> 4, nby = (g.H + 15) >> 4, nblocks = nbx * nby;
+  const PBase fb = pb[pi];
+  const int xx1 = pinfo[pi * 2], xx2 = pinfo[pi * 2 + 1];
+  if (xx2 < xx1) return;
+  const u8* bt = btype + (size_t)pi * nblocks;
+  if ((int)blockIdx.x == (nblocks + 63) / 64) {
+    if (threadIdx.x != 0) return;
+    u32 k = fb.misc_base, pos = fb.sym_base;
+    auto put = [&](int ctx, int v) {
+      misc[k] = ((u32)ctx << 16) | (u32)v;
+      miscpos[k] = pos;
+      k++;
+      pos++;
+    };
+    put(MC_X, xx1 & 255);  // :1145-1150
+    put(MC_X, (xx1 >> 8) & 255);
+    put(MC_X, xx2 & 255);
+    put(MC_X, (xx2 >> 8) & 255);
+    int oldt = -1, n = -1;
+    for (int x = xx1; x <= xx2; x++) {  // :1155-1169
+      if (bt[x] == oldt && n < 255)
+        n++;
+      else {
+        if (n > 0) put(MC_BN, n);
+        put(MC_BT, bt[x]);
+        oldt = bt[x];
+        n = 1;
+      }
+    }
+    put(MC_BN, n);
+    return;
+  }
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= nblocks) return;
+  const int t = bt[b];
+  if (!t) return;
+  const u8* cur = planes + (size_t)pf[pi].slot * g.plane_stride;
+  const u8* prv = planes + (size_t)pf[pi].prev_slot * g.plane_stride;
+  const int by = b / nbx, bx = b - by * nbx;
+  const u32 info = binfo[(size_t)pi * nblocks + b];
+  const Rect r = binfo_rect(info, bx, by);
+  const BOff o = boff[(size_t)pi * nblocks + b];
+  const u32 fl = bflag[(size_t)pi * nblocks + b];
+  u32 pos = fb.sym_base + o.sym, mk = fb.misc_base + o.misc;
+  auto put = [&](int ctx, int v) {
+    misc[mk] = ((u32)ctx << 16) | (u32)v;
+    miscpos[mk] = pos;
+    mk++;
+    pos++;
+  };
+  if (t == 2 || t == 4) {  // :1190-1197
+    put(MC_SXY + 0, r.x1 - bx * 16);
+    put(MC_SXY + 1, r.y1 - by * 16);
+    put(MC_SXY + 2, r.x2 - 1 - bx * 16);
+    put(MC_SXY + 3, r.y2 - 1 - by * 16);
+  }
+  if (t >= 3) {  // :1199-1214
+    const u32 mv = bmv[(size_t)pi * nblocks + b];
+    const bool same = fl & 1u;
+    entries[pos++] = (u32)(kProbScale / 2) | ((same ? (u32)(kProbScale / 2) : 0u) << 16);  // encodeBool, screencap.h:407-410
+    if (!same) {
+      put(MC_MX, mv_x(mv) + mp.far_x);
+      put(MC_MY, mv_y(mv) + mp.far_y);
+    }
+    return;
+  }
+  // pixel runs (:1215-1245).  The colour context of the first literal comes from the last pixel
+  // coded before this block: the bottom-right pixel of the previous pixel-coded block's rect
+  // (cx = cx1 = 0 at the start of the frame, :1176).
+  u32 pg = 0, pbv = 0;
+  const int pp = (int)(fl >> 8);
+  if (pp) {
+    const int pbi = pp - 1, pby = pbi / nbx, pbx = pbi - pby * nbx;
+    const Rect q = binfo_rect(binfo[(size_t)pi * nblocks + pbi], pbx, pby);
+    const u8* px = cur + (size_t)(q.y2 - 1) * g.S + (q.x2 - 1) * 3;
+    pg = px[1];
+    pbv = px[2];
+  }
+  u32 ri = fb.run_base + o.run, ci = fb.col_base + o.col;
+  int lastt = 0;
+  walk_rect_runs(cur, prv, g.S, r, [&](int type, int n, int first, int lasti) {
+    runs[ri] = make_run(type, lastt, n, false);
+    runpos[ri] = pos;
+    ri++;
+    if (type == 0) {
+      emit_colour(fb.gen, ld3(cur + first), pg, pbv, pos + 1, ci, keys, vals, hist);
+      ci += 3;
+    }
+    pos += 2 + (type == 0 ? 3 : 0);
+    lastt = type;
+    pg = cur[lasti + 1];
+    pbv = cur[lasti + 2];
+  });
+}
+
+// ---- misc fixed chains: one wave per (generation, context), same engine as k_fixed_chain ----
+struct MiscRange {
+  u32 begin, end;
+};
+__global__ __launch_bounds__(64) void k_misc_chain(const u32* __restrict__ misc, const u32* __restrict__ miscpos, const MiscRange* __restrict__ ranges, int ngens, int load_first,
+                                                   FixedPersist* __restrict__ persist /* [MC_COUNT] */, u32* __restrict__ entries) {
+  __shared__ u32 freq[512], cum[512], cnt[512];
+  const int ctx = blockIdx.x, gen = blockIdx.y, lane = threadIdx.x;
+  const int nsym = ctx == MC_BT ? 5 : (ctx >= MC_SXY && ctx < MC_SXY + 4) ? 16 : (ctx >= MC_MX) ? 512 : 256;
+  int total;
+  if (gen == 0 && load_first && persist[ctx].valid) {
+    for (int j = lane; j < nsym; j += 64) {
+      freq[j] = persist[ctx].freq[j];
+      cum[j] = persist[ctx].cum[j];
+      cnt[j] = persist[ctx].cnt[j];
+    }
+    total = persist[ctx].total;
+  } else {
+    const int fr = kProbScale / nsym, c0 = fr - (fr >> 1);
+    for (int j = lane; j < nsym; j += 64) {
+      freq[j] = fr;
+      cum[j] = fr * j;
+      cnt[j] = c0;
+    }
+    total = c0 * nsym;
+  }
+  __syncthreads();
+  const MiscRange rg = ranges[gen];
+  for (u32 base = rg.begin; base < rg.end; base += 64) {
+    const u32 i = base + lane;
+    bool sel = false;
+    u32 sym = 0, pos = 0;
+    if (i < rg.end) {
+      const u32 v = misc[i];
+      sel = (int)(v >> 16) == ctx;
+      sym = v & 0xFFFF;
+      pos = miscpos[i];
+    }
+    const u64 m = __ballot(sel);
+    const int rank = __builtin_popcountll(m & lanemask_lt()), cntm = __builtin_popcountll(m);
+    int done = 0;
+    while (done < cntm) {
+      const int room = (kProbScale - kStepDense - total) / kStepDense + 1;
+      const int take = min(room, cntm - done);
+      if (sel && rank >= done && rank < done + take) {
+        entries[pos] = freq[sym] | (cum[sym] << 16);
+        atomicAdd(&cnt[sym], (u32)kStepDense);
+      }
+      total += kStepDense * take;
+      done += take;
+      __syncthreads();
+      if (take == room) {
+        const int per = (nsym + 63) >> 6, j0 = lane * per;
+        int s = 0;
+        for (int j = j0; j < j0 + per && j < nsym; j++) s += cnt[j];
+        int inc = s;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          int tt = __shfl_up(inc, d);
+          if (lane >= d) inc += tt;
+        }
+        int cf = inc - s, ns = 0;
+        for (int j = j0; j < j0 + per && j < nsym; j++) {
+          int fr = cnt[j];
+          cum[j] = cf;
+          freq[j] = fr;
+          cf += fr;
+          fr -= fr >> 1;
+          cnt[j] = fr;
+          ns += fr;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) ns += __shfl_xor(ns, d);
+        total = ns;
+        __syncthreads();
+      }
+    }
+  }
+  if (gen == ngens - 1) {  // the last generation of the call is the live one
+    for (int j = lane; j < nsym; j += 64) {
+      persist[ctx].freq[j] = freq[j];
+      persist[ctx].cum[j] = cum[j];
+      persist[ctx].cnt[j] = cnt[j];
+    }
+    if (lane == 0) {
+      persist[ctx].total = total;
+      persist[ctx].valid = 1;
+    }
+  }
+}
+
+}  // namespace scpr

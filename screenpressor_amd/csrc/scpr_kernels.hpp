@@ -443,33 +443,46 @@ __global__ __launch_bounds__(256) void k_scan_tiles(const u32* __restrict__ tile
   }
 }
 
-// per batch: frame bases (one small block).  bases[f] = {run_base, sym_base, col_base, nsyms}
+// per batch: frame bases (one thread).  kinds: 0 key frame, 1 flat (no symbols), 2 P-frame
 struct FrameBase {
-  u32 run_base, sym_base, col_base, nsyms, nruns, ncol, pad0, pad1;
+  u32 run_base, sym_base, col_base, misc_base, nruns, nsyms, ncol, nmisc, hdr_runs, nbt, pad0, pad1;
 };
-__global__ void k_bases(const u32* __restrict__ frametot, const u32* __restrict__ hdrcnt, const int* __restrict__ slots, int nfr, FrameBase* __restrict__ bases, u32* __restrict__ totals) {
+__global__ void k_bases(const int* __restrict__ kinds, const int* __restrict__ pidx, int nfr, const u32* __restrict__ frametot,
+                        const u32* __restrict__ hdrcnt, const u32* __restrict__ ptot, FrameBase* __restrict__ bases, u32* __restrict__ totals) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  u32 rb = 0, sb = 0, cb = 0;
+  u32 rb = 0, sb = 0, cb = 0, mb = 0;
   for (int i = 0; i < nfr; i++) {
-    int slot = slots[i];
-    u32 R = frametot[slot * 2], L = frametot[slot * 2 + 1], Hr = hdrcnt[slot];
     FrameBase b;
     b.run_base = rb;
     b.sym_base = sb;
     b.col_base = cb;
-    b.nruns = Hr + R;
-    b.nsyms = 4 * Hr + 2 * R + 3 * L;
-    b.ncol = 3 * (Hr + L);
-    b.pad0 = Hr;
-    b.pad1 = 0;
+    b.misc_base = mb;
+    b.nruns = b.nsyms = b.ncol = b.nmisc = b.hdr_runs = b.nbt = b.pad0 = b.pad1 = 0;
+    if (kinds[i] == 0) {
+      const int slot = i;  // planes of a chunk sit in slots 0..n-1
+      const u32 R = frametot[slot * 2], L = frametot[slot * 2 + 1], Hr = hdrcnt[slot];
+      b.nruns = Hr + R;
+      b.nsyms = 4 * Hr + 2 * R + 3 * L;
+      b.ncol = 3 * (Hr + L);
+      b.hdr_runs = Hr;
+    } else if (kinds[i] == 2) {
+      const u32* t = ptot + (size_t)pidx[i] * 8;
+      b.nruns = t[0];
+      b.nsyms = t[1];
+      b.ncol = t[2];
+      b.nmisc = t[3];
+      b.nbt = t[4];
+    }
     bases[i] = b;
     rb += b.nruns;
     sb += b.nsyms;
     cb += b.ncol;
+    mb += b.nmisc;
   }
   totals[0] = rb;
   totals[1] = sb;
   totals[2] = cb;
+  totals[3] = mb;
 }
 
 // colour context ids from the two previous bytes (SC_CXSHIFT = 2, MAKECX1,
@@ -493,16 +506,16 @@ __device__ __forceinline__ void emit_colour(u32 gen, u32 pix, u32 prev_g, u32 pr
 
 // unified run list + colour symbols.  grid = (ntiles + 1, frames); the extra
 // block handles the header runs.
-__global__ __launch_bounds__(256) void k_symbols(const u8* __restrict__ planes, Geom g, const int* __restrict__ slots, const int* __restrict__ gens,
+__global__ __launch_bounds__(256) void k_symbols(const u8* __restrict__ planes, Geom g, const int* __restrict__ slots, const int* __restrict__ gens, const int* __restrict__ fidx,
                                                  const FrameBase* __restrict__ bases, const u32* __restrict__ runrec, const u32* __restrict__ tilecnt,
                                                  const u32* __restrict__ tileoff, const u8* __restrict__ entry, const u32* __restrict__ hdrrec,
                                                  u32* __restrict__ runs, u32* __restrict__ runpos, u32* __restrict__ keys, u32* __restrict__ vals, u32* __restrict__ hist) {
   __shared__ int wsum[5];
   const int fi = blockIdx.y, slot = slots[fi], tid = threadIdx.x;
   const u32 gen = (u32)gens[fi];
-  const FrameBase fb = bases[fi];
+  const FrameBase fb = bases[fidx[fi]];
   const u8* plane = planes + (size_t)slot * g.plane_stride;
-  const u32 Hr = fb.pad0;
+  const u32 Hr = fb.hdr_runs;
   if ((int)blockIdx.x == g.ntiles) {  // header runs: C C C N each, no pixel-type symbol
     const u32* rec = hdrrec + (size_t)slot * (g.W + 2);
     for (u32 j = tid; j < Hr; j += 256) {
@@ -568,21 +581,33 @@ __global__ __launch_bounds__(256) void k_symbols(const u8* __restrict__ planes, 
 struct GenRange {
   u32 run_begin, run_end;
 };
-__global__ __launch_bounds__(64) void k_fixed_chain(const u32* __restrict__ runs, const u32* __restrict__ runpos, const GenRange* __restrict__ ranges,
-                                                    u32* __restrict__ entries) {
+struct FixedPersist {  // one fixed-alphabet table as kept between calls (P-frames continue the models, screencap.cpp:1118)
+  u32 freq[512], cum[512], cnt[512];
+  int total, valid, pad0, pad1;
+};
+__global__ __launch_bounds__(64) void k_fixed_chain(const u32* __restrict__ runs, const u32* __restrict__ runpos, const GenRange* __restrict__ ranges, int ngens, int load_first,
+                                                    FixedPersist* __restrict__ persist /* [12] */, u32* __restrict__ entries) {
   __shared__ u32 freq[256], cum[256], cnt[256];
   const int cls = blockIdx.x, gen = blockIdx.y, lane = threadIdx.x;
   const bool is_n = cls >= 6;
   const int key = is_n ? cls - 6 : cls, nsym = is_n ? 256 : 6;
-  {
+  int total;
+  if (gen == 0 && load_first && persist[cls].valid) {
+    for (int j = lane; j < nsym; j += 64) {
+      freq[j] = persist[cls].freq[j];
+      cum[j] = persist[cls].cum[j];
+      cnt[j] = persist[cls].cnt[j];
+    }
+    total = persist[cls].total;
+  } else {
     const int fr = kProbScale / nsym, c0 = fr - (fr >> 1);
     for (int j = lane; j < nsym; j += 64) {
       freq[j] = fr;
       cum[j] = fr * j;
       cnt[j] = c0;
     }
+    total = c0 * nsym;
   }
-  int total = (kProbScale / nsym - ((kProbScale / nsym) >> 1)) * nsym;
   __syncthreads();
   const GenRange rg = ranges[gen];
   for (u32 base = rg.run_begin; base < rg.run_end; base += 64) {
@@ -641,6 +666,18 @@ __global__ __launch_bounds__(64) void k_fixed_chain(const u32* __restrict__ runs
         total = ns;
         __syncthreads();
       }
+    }
+  }
+  if (gen == ngens - 1) {  // the last generation of the call is the live one
+    __syncthreads();
+    for (int j = lane; j < nsym; j += 64) {
+      persist[cls].freq[j] = freq[j];
+      persist[cls].cum[j] = cum[j];
+      persist[cls].cnt[j] = cnt[j];
+    }
+    if (lane == 0) {
+      persist[cls].total = total;
+      persist[cls].valid = 1;
     }
   }
 }

@@ -795,8 +795,15 @@ __global__ __launch_bounds__(256) void k_chain_lists(const u32* __restrict__ cst
 // header in scalar registers, small table one entry per lane; only the 256-bit symbol
 // set (LDS) and dense tables (arena) live in memory.  Entries are produced 64 at a
 // time and scattered to their stream positions.
+struct ChainPersist {
+  ColState* states;   // [NCOLCTX] records of the live generation (pad1 = generation stamp)
+  u32 stamp_in;       // stamp of the live generation when the call started
+  u32 stamp_out;      // stamp given to the last generation of this call
+  int load_first;     // generation 0 of the call continues the live generation
+  int ngens;
+};
 __global__ __launch_bounds__(64) void k_colour_chain_w(const u32* __restrict__ skeys, const u32* __restrict__ svals, const u32* __restrict__ cstart, const u32* __restrict__ list,
-                                                       const u32* __restrict__ count, int f0, Arena arena, u32* __restrict__ entries) {
+                                                       const u32* __restrict__ count, int f0, Arena arena, ChainPersist cp, u32* __restrict__ entries) {
   __shared__ u32 rec[16];
   __shared__ u16 tmp[256];
   WaveModel M(tmp, arena, f0);
@@ -805,8 +812,20 @@ __global__ __launch_bounds__(64) void k_colour_chain_w(const u32* __restrict__ s
   for (u32 li = blockIdx.x; li < n; li += gridDim.x) {
     const u32 q = list[li];
     const u32 start = cstart[q], len = cstart[q + 1] - start;
+    const int gen = (int)(q / NCOLCTX), ctx = (int)(q - (u32)gen * NCOLCTX);
     ColHdr h = WaveModel::unpack(0, 0, 0);
     int sym = 0, fq = 0;
+    wave_fence();
+    if (gen == 0 && cp.load_first) {  // continue the model of this context from the previous call
+      const u32* src = (const u32*)&cp.states[ctx];
+      const u32 w = lane < 16 ? src[lane] : 0;
+      if (rdl(w, 3) == cp.stamp_in) {
+        if (lane < 16) rec[lane] = w;
+        wave_fence();
+        h = WaveModel::unpack(rdl(w, 0), rdl(w, 1), rdl(w, 2));
+        if (h.kind == 4 || h.kind == 5) M.load_small(rec, h.d, sym, fq);
+      }
+    }
     for (u32 base = 0; base < len; base += 64) {
       const int m = (int)min(64u, len - base);
       u32 key = 0, pos = 0, mine = 0;
@@ -827,6 +846,14 @@ __global__ __launch_bounds__(64) void k_colour_chain_w(const u32* __restrict__ s
         if (lane == j) mine = (fr & 0xFFFFu) | (cf << 16);
       }
       if (lane < m) entries[pos] = mine;
+    }
+    if (gen == cp.ngens - 1) {  // live generation: keep the state for the next call
+      wave_fence();
+      if (h.kind == 4 || h.kind == 5) M.store_small(rec, h.d, sym, fq);
+      M.store_header(rec, h);
+      if (lane == 0) rec[3] = cp.stamp_out;
+      wave_fence();
+      if (lane < 16) ((u32*)&cp.states[ctx])[lane] = rec[lane];
     }
   }
 }

@@ -104,3 +104,75 @@ def test_batch_key_frames_1080p_roundtrip_and_hash():
     r, dec = gpu.DecompressBatch(out, sizes, ft)
     assert r == n
     assert torch.equal(dec.reshape(n, -1), d_frames)
+
+
+def _encode_sequence_both(frames, w, h, bpp=32, keys=(0,), **kw):
+    """per-frame API on both sides; returns list of (gpu_bytes, oracle_bytes, ftype)"""
+    gpu = _codec(w, h, bpp, **kw)
+    ora = O.OracleCodec(w, h, bpp, **{k: v for k, v in kw.items() if k in ("loss", "workers")})
+    out = []
+    for t, f in enumerate(frames):
+        want, wft = ora.compress(f, key=(t in keys))
+        got, gft = gpu.CompressFrame(f, 0 if t in keys else 1)
+        if got != want and len(want) > 4:
+            _check_entries(gpu, ora)
+        assert gft == wft and got == want, (t, gft, wft, _first_diff(got, want))
+        out.append((got, gft))
+    return out
+
+
+@pytest.mark.parametrize("w,h", [(64, 48), (100, 37), (320, 240), (640, 480)])
+def test_p_frames_bit_exact_encode(w, h):
+    seq = DesktopSequence(w, h, seed=3)
+    _encode_sequence_both([seq.frame(t) for t in range(8)], w, h)
+
+
+def test_p_frames_motion_scroll_and_static():
+    w, h = 320, 240
+    rng = np.random.default_rng(7)
+    tex = rng.integers(0, 256, (h + 64, w, 3), dtype=np.uint8)
+    frames = []
+    for t in range(5):
+        f = np.full((h, w, 4), 255, np.uint8)
+        f[..., :3] = tex[3 * t:3 * t + h]
+        frames.append(f)
+    frames.append(frames[-1].copy())           # unchanged P-frame: one byte
+    g = frames[-1].copy()
+    g[5, 3, :3] = (9, 9, 9)                    # one changed pixel
+    frames.append(g)
+    pk = _encode_sequence_both(frames, w, h)
+    assert pk[5][0] == b"\x00"
+
+
+def test_p_frames_with_flat_frames_and_second_key():
+    w, h = 64, 48
+    a = np.full((h, w, 4), 255, np.uint8)
+    a[..., :3] = (10, 20, 30)
+    b = a.copy()
+    b[..., :3] = (11, 20, 30)
+    seq = DesktopSequence(w, h, seed=5)
+    frames = [a, a, b, seq.frame(0), seq.frame(1), a, seq.frame(2), seq.frame(3), seq.frame(4), seq.frame(5)]
+    _encode_sequence_both(frames, w, h, keys=(7,))
+
+
+def test_p_frames_batch_api_1080p():
+    """I+P stream through the batch API (several chunks of state carried inside one call and across calls)"""
+    import torch
+    w, h, n = 1920, 1080, 10
+    seq = DesktopSequence(w, h, seed=1)
+    frames = seq.frames(n)
+    ora = O.OracleCodec(w, h, 32)
+    want = [ora.compress(frames[t], key=(t == 0))[0] for t in range(n)]
+    gpu = _codec(w, h)
+    d = torch.from_numpy(frames).cuda().reshape(n, -1)
+    got = b""
+    sizes = []
+    for lo, hi in ((0, 4), (4, 10)):     # two calls: the live generation continues across them
+        out, sz, ft = gpu.CompressBatch(d[lo:hi].contiguous(), [0 if t == 0 else 1 for t in range(lo, hi)])
+        got += out.cpu().numpy().tobytes()
+        sizes += [int(x) for x in sz]
+    off = 0
+    for t in range(n):
+        g = got[off:off + sizes[t]]
+        off += sizes[t]
+        assert g == want[t], (t, _first_diff(g, want[t]))
