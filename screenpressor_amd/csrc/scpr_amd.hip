@@ -103,6 +103,9 @@ struct scpr_codec {
   bool live_has_state = false;  // ... and it has coded symbols (a flat frame renews the models without coding any)
   u32 live_stamp = 0, next_stamp = 1;
   size_t arena_used_bound = 0;  // upper bound of dense tables held by the live generation
+  // decoder side of the same
+  DevBuf decgops, decfixed, dec_fixed_persist, dec_colour_persist;
+  bool dec_live = false;
   // timing
   hipEvent_t ev[ST_COUNT + 1][2];
   bool ev_used[ST_COUNT];
@@ -210,6 +213,7 @@ static int ensure_codec(scpr_codec* c, int version) {  // CreateCodec + CScreenC
     HIPCHK(hipMemsetAsync(c->colour_persist.p, 0, (size_t)NCOLCTX * sizeof(ColState), c->stream));
   }
   c->live_valid = false;
+  c->dec_live = false;
   c->live_has_state = false;
   c->live_stamp = 0;
   c->next_stamp = 1;
@@ -490,7 +494,7 @@ void scpr_destroy(scpr_codec* c) {
   DevBuf* all[] = {&c->planes, &c->exitmap, &c->entry, &c->runrec, &c->tilecnt, &c->tileoff, &c->hdrrec, &c->hdrcnt, &c->frametot, &c->flags, &c->slotlist, &c->genlist,
                    &c->bases, &c->totals, &c->runs, &c->runpos, &c->keys[0], &c->keys[1], &c->vals[0], &c->vals[1], &c->hist, &c->cstart, &c->sorttmp, &c->scantmp,
                    &c->entries, &c->ranges, &c->rblocks, &c->rscratch, &c->rsize, &c->packets, &c->pktoff, &c->blkdst, &c->outsizes, &c->total64, &c->arena,
-                   &c->arena_top, &c->err, &c->rcp, &c->decframes, &c->decstates, &c->hoststage_in, &c->hoststage_out, &c->chainlists, &c->chaincounts, &c->kinds, &c->pidx, &c->fidx, &c->pframes, &c->pflag, &c->binfo, &c->smv, &c->btype, &c->bmv, &c->bcnt, &c->boff, &c->bflag, &c->pinfo, &c->ptot, &c->pbase, &c->misc, &c->miscpos, &c->miscranges, &c->mvs, &c->fixed_persist, &c->misc_persist, &c->colour_persist};
+                   &c->arena_top, &c->err, &c->rcp, &c->decframes, &c->decstates, &c->hoststage_in, &c->hoststage_out, &c->chainlists, &c->chaincounts, &c->kinds, &c->pidx, &c->fidx, &c->pframes, &c->pflag, &c->binfo, &c->smv, &c->btype, &c->bmv, &c->bcnt, &c->boff, &c->bflag, &c->pinfo, &c->ptot, &c->pbase, &c->misc, &c->miscpos, &c->miscranges, &c->mvs, &c->fixed_persist, &c->misc_persist, &c->colour_persist, &c->decgops, &c->decfixed, &c->dec_fixed_persist, &c->dec_colour_persist};
   for (DevBuf* b : all) b->release();
   for (int s = 0; s < ST_COUNT + 1; s++)
     for (int k = 0; k < 2; k++) (void)hipEventDestroy(c->ev[s][k]);
@@ -675,7 +679,6 @@ int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* 
   HIPCHK(c->err.reserve(64));
   for (int f0 = 0; f0 < nframes;) {
     if (!c->have_codec) {
-      if (c->crashed && ftypes[f0] > 0) return done;
       if (ftypes[f0] > 0) return done;  // P-frame before any key frame (:1699)
       int version = (int)((heads[f0] & 0xFF) >> 4) + 1;
       int rc = ensure_codec(c, version);
@@ -683,44 +686,77 @@ int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* 
     }
     const Geom& g = c->g;
     const int n = std::min(c->slots, nframes - f0);
-    std::vector<DecFrame> coded;
+    std::vector<DecFrame> fr;
+    std::vector<DecGop> gops;
     HIPCHK(hipMemsetAsync(c->err.p, 0, 32, st));
     stage_begin(c, ST_DECODE);
+    int ncoded = 0;
     for (int i = 0; i < n; i++) {
       const int fi = f0 + i;
-      if (ftypes[fi]) {
-        fprintf(stderr, "[scpr] P-frames are not implemented in this build\n");
-        return SCPR_E_PARAM;
-      }
+      if (c->crashed && ftypes[fi] > 0) return done;  // (:1697)
       c->crashed = false;
       c->frames_done++;
-      const int alg = heads[fi] & 15;
-      if (alg == 1) {
+      DecFrame d{offs[fi], sizes[fi], i, 0, i > 0 ? i - 1 : c->slots};
+      bool new_gop = false;
+      if (ftypes[fi]) {  // DecompressP
+        d.kind = 2;
+        c->last_flat = false;
+        if (gops.empty()) gops.push_back({(int)fr.size(), 0, c->dec_live ? 1 : 0, 0});
+      } else if ((heads[fi] & 15) == 1) {  // flat key frame (:1537-1553)
         const u32 rgb = (heads[fi] >> 8) & 0xFFFFFFu;
+        d.kind = 1;
         hipLaunchKernelGGL(k_fill_flat, dim3((g.H * g.S + 255) / 256), dim3(256), 0, st, c->planes.as<u8>(), g, i, rgb);
+        new_gop = !(c->last_flat && c->last_flat_rgb == rgb);  // models renewed unless the colour repeats
         c->last_flat = true;
         c->last_flat_rgb = rgb;
+        if (!new_gop && gops.empty()) gops.push_back({(int)fr.size(), 0, c->dec_live ? 1 : 0, 0});
       } else {
+        d.kind = 0;
         c->last_flat = false;
-        coded.push_back({offs[fi], sizes[fi], i, 0});
+        new_gop = true;
+        ncoded++;
       }
+      if (new_gop) gops.push_back({(int)fr.size(), 0, 0, 0});
+      fr.push_back(d);
+      gops.back().count++;
     }
-    if (!coded.empty()) {
-      const size_t nc = coded.size();
-      HIPCHK(c->decframes.reserve(nc * sizeof(DecFrame)));
-      HIPCHK(c->decstates.reserve(nc * NCOLCTX * sizeof(ColState)));
-      HIPCHK(hipMemsetAsync(c->decstates.p, 0, nc * NCOLCTX * sizeof(ColState), st));  // kind 0 everywhere (RenewI)
-      const size_t arena_cap = nc * 4096 + 64;  // dense tables per key frame; overflow is reported
-      HIPCHK(c->arena.reserve(arena_cap * sizeof(DenseTab)));
-      HIPCHK(hipMemsetAsync(c->arena_top.p, 0, 4, st));
-      HIPCHK(hipMemcpyAsync(c->decframes.p, coded.data(), nc * sizeof(DecFrame), hipMemcpyHostToDevice, st));
+    const size_t ng = gops.size();
+    if (ng) {
+      HIPCHK(c->decframes.reserve(fr.size() * sizeof(DecFrame)));
+      HIPCHK(c->decgops.reserve(ng * sizeof(DecGop)));
+      HIPCHK(c->decstates.reserve(ng * NCOLCTX * sizeof(ColState)));
+      HIPCHK(c->decfixed.reserve(ng * sizeof(FixedBlob)));
+      HIPCHK(c->dec_fixed_persist.reserve(sizeof(FixedBlob)));
+      HIPCHK(c->dec_colour_persist.reserve((size_t)NCOLCTX * sizeof(ColState)));
+      HIPCHK(hipMemsetAsync(c->decstates.p, 0, ng * NCOLCTX * sizeof(ColState), st));  // kind 0 everywhere (RenewI)
+      const bool cont = gops[0].load != 0;
+      if (cont) {  // the first GOP continues the state kept from the previous call
+        HIPCHK(hipMemcpyAsync(c->decstates.p, c->dec_colour_persist.p, (size_t)NCOLCTX * sizeof(ColState), hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync(c->decfixed.p, c->dec_fixed_persist.p, sizeof(FixedBlob), hipMemcpyDeviceToDevice, st));
+      } else {
+        c->arena_used_bound = 0;
+        HIPCHK(hipMemsetAsync(c->arena_top.p, 0, 4, st));
+      }
+      const size_t arena_cap = c->arena_used_bound + ng * 12288 + 64;
+      HIPCHK(c->arena.reserve_keep(arena_cap * sizeof(DenseTab), c->arena_used_bound * sizeof(DenseTab), st));
+      c->arena_used_bound = arena_cap;
+      HIPCHK(hipMemcpyAsync(c->decframes.p, fr.data(), fr.size() * sizeof(DecFrame), hipMemcpyHostToDevice, st));
+      HIPCHK(hipMemcpyAsync(c->decgops.p, gops.data(), ng * sizeof(DecGop), hipMemcpyHostToDevice, st));
       Arena ar{c->arena.as<DenseTab>(), c->arena_top.as<u32>(), (u32)arena_cap, c->err.as<u32>()};
       int ring = 4096;
       while (ring < 2 * g.S + 1024) ring <<= 1;
-      HIPCHK(hipFuncSetAttribute((const void*)k_decode_intra_w, hipFuncAttributeMaxDynamicSharedMemorySize, ring));
-      hipLaunchKernelGGL(k_decode_intra_w, dim3((unsigned)nc), dim3(64), ring, st, (const u8*)d_packets, (const u8*)d_packets + offs[nframes] + 8, c->decframes.as<DecFrame>(),
-                         c->planes.as<u8>(), g, c->decstates.as<ColState>(), ar, c->f0, c->err.as<u32>(), ring);
+      const int nblocks = ((g.W + 15) / 16) * ((g.H + 15) / 16);
+      const int dyn = ring + ((nblocks + 15) & ~15);
+      HIPCHK(hipFuncSetAttribute((const void*)k_decode_gop_w, hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
+      hipLaunchKernelGGL(k_decode_gop_w, dim3((unsigned)ng), dim3(64), dyn, st, (const u8*)d_packets, (const u8*)d_packets + offs[nframes] + 8, c->decframes.as<DecFrame>(),
+                         c->decgops.as<DecGop>(), c->planes.as<u8>(), g, c->decstates.as<ColState>(), ar, c->f0, c->err.as<u32>(), ring, c->decfixed.as<FixedBlob>(),
+                         (int)std::min<u32>(c->prm.high_range_x, 256), (int)std::min<u32>(c->prm.high_range_y, 256));
+      // keep the state of the last GOP and the last plane for the next call
+      HIPCHK(hipMemcpyAsync(c->dec_colour_persist.p, c->decstates.as<ColState>() + (ng - 1) * NCOLCTX, (size_t)NCOLCTX * sizeof(ColState), hipMemcpyDeviceToDevice, st));
+      HIPCHK(hipMemcpyAsync(c->dec_fixed_persist.p, c->decfixed.as<FixedBlob>() + (ng - 1), sizeof(FixedBlob), hipMemcpyDeviceToDevice, st));
+      c->dec_live = true;
     }
+    HIPCHK(hipMemcpyAsync(c->planes.as<u8>() + (size_t)c->slots * g.plane_stride, c->planes.as<u8>() + (size_t)(n - 1) * g.plane_stride, g.plane_stride, hipMemcpyDeviceToDevice, st));
     stage_end(c, ST_DECODE);
     stage_begin(c, ST_UNPACK);
     u8* out = (u8*)d_frames_out + (size_t)f0 * pitch * g.H;
@@ -734,10 +770,9 @@ int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* 
     stage_end(c, ST_UNPACK);
     u32 errv[8] = {0};
     HIPCHK(hipMemcpyAsync(errv, c->err.p, 32, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipStreamSynchronize(st));  // also covers fr / gops (host memory)
     timing_collect(c);
     const u32 err = errv[0];
-    if (getenv("SCPR_DEBUG")) fprintf(stderr, "[scpr] decode stats: record misses %u, colour symbols %u, dense %u, raw %u\n", errv[1], errv[2], errv[3], errv[4]);
     if (err & 4) return SCPR_E_STREAM;
     if (err & 1) return SCPR_E_DEVICE;
     done += n;

@@ -834,168 +834,7 @@ __global__ __launch_bounds__(256) void k_gather(const Packet* __restrict__ pk, i
 }
 
 // ---------------------------------------------------------------- decode ---
-struct DecFrame {
-  u64 src_off;   // packet offset in the packet buffer
-  u32 src_len;
-  int slot;      // destination plane
-  int kind;      // 0 = coded key frame, 1 = flat key frame
-};
-// One wave per key frame; lane 0 walks the symbol chain (DecompressI,
-// screencap.cpp:414-498), the fixed tables live in LDS.
-__global__ __launch_bounds__(64) void k_decode_intra(const u8* __restrict__ packets, const DecFrame* __restrict__ frames, u8* __restrict__ planes, Geom g,
-                                                     ColState* __restrict__ states, Arena arena, int f0, u32* __restrict__ status) {
-  __shared__ FixedTab<256> nt[6];
-  __shared__ FixedTab<8> pt[6];
-  const DecFrame fr = frames[blockIdx.x];
-  u8* dst = planes + (size_t)fr.slot * g.plane_stride;
-  ColState* cs = states + (size_t)blockIdx.x * NCOLCTX;
-  for (int i = threadIdx.x; i < NCOLCTX; i += 64) col_reset(cs[i]);
-  if (threadIdx.x < 6) {
-    fixed_reset(nt[threadIdx.x], 256);
-    fixed_reset(pt[threadIdx.x], 6);
-  }
-  __syncthreads();
-  if (threadIdx.x != 0) return;
-  const u8* in = packets + fr.src_off + 1;  // skip the frame header byte
-  const u8* const in_end = packets + fr.src_off + fr.src_len + 8;
-  u32 x = (u32)in[0] | ((u32)in[1] << 8) | ((u32)in[2] << 16) | ((u32)in[3] << 24);
-  in += 4;
-  int ndec = 0;
-  u32 cx = 0, cx1 = 0;
-  bool bad = false;
-  auto advance = [&](u32 start, u32 freq) {  // RansDecAdvance, rans_byte.h:130-146
-    x = freq * (x >> kProbBits) + (x & (kProbScale - 1)) - start;
-    while (x < kRansL && in < in_end) x = (x << 8) | *in++;
-  };
-  auto count = [&]() {  // screencap.h:327-331
-    if (++ndec == kBlockEntries) {
-      x = (u32)in[0] | ((u32)in[1] << 8) | ((u32)in[2] << 16) | ((u32)in[3] << 24);
-      in += 4;
-      ndec = 0;
-    }
-  };
-  auto alloc = [&](ColState& s) { return arena_alloc(arena, s); };
-  auto tab = [&](ColState& s) { return arena.tabs + s.dense; };
-  auto get_colour = [&](int plane) -> int {  // decodeC, screencap.h:318-333
-    ColState& st = cs[plane * 4096 + ((cx + cx1) & 4095)];
-    Ivl e;
-    u8 c = 0;
-    if (col_decode(st, (int)(x & (kProbScale - 1)), c, e, alloc, tab))
-      advance(e.cum, e.freq);
-    else {
-      c = *in++;
-      col_note_raw(st, c, f0, alloc);
-    }
-    count();
-    return c;
-  };
-  auto next_cx = [&](int v) {
-    cx1 = (cx << 6) & 0xFC0;
-    cx = (u32)v >> 2;
-  };
-  auto get_rgb = [&](int& r, int& gg, int& b) {
-    r = get_colour(0);
-    next_cx(r);
-    gg = get_colour(1);
-    next_cx(gg);
-    b = get_colour(2);
-    next_cx(b);
-  };
-  auto get_n = [&](int t) {
-    Ivl e;
-    int c = fixed_decode(nt[t], (int)(x & (kProbScale - 1)), e);
-    advance(e.cum, e.freq);
-    count();
-    return c;
-  };
-  auto get_p = [&](int t) {
-    Ivl e;
-    int c = fixed_decode(pt[t], (int)(x & (kProbScale - 1)), e);
-    advance(e.cum, e.freq);
-    count();
-    return c;
-  };
-  const int W = g.W, H = g.H, S = g.S;
-  int r = 0, gg = 0, b = 0;
-  int t = 0, last_t = 0, i = 0, n = 1, k = 0, lasti = 0;
-  while (k < W + 1 && !bad) {
-    get_rgb(r, gg, b);
-    n = get_n(t);
-    if (n < 1 || k + n > W + 1) {
-      bad = true;
-      break;
-    }
-    for (int q = 0; q < n; q++) {
-      dst[i] = (u8)r;
-      dst[i + 1] = (u8)gg;
-      dst[i + 2] = (u8)b;
-      k++;
-      lasti = i;
-      i += 3;
-      if (i % S >= W * 3) i = (i / S + 1) * S;
-    }
-  }
-  const int off = -S - 3;
-  int xx = (i % S) / 3, y = i / S;
-  while (y < H && !bad) {
-    last_t = t;
-    t = get_p(last_t);
-    if (!t) get_rgb(r, gg, b);
-    n = get_n(t);
-    if (n < 1 || t == 3 || in > in_end) {
-      bad = true;
-      break;
-    }
-    i = y * S + xx * 3;
-    while (n-- > 0) {
-      switch (t) {
-        case 0:
-          dst[i] = (u8)r;
-          dst[i + 1] = (u8)gg;
-          dst[i + 2] = (u8)b;
-          break;
-        case 1:
-          dst[i] = dst[lasti];
-          dst[i + 1] = dst[lasti + 1];
-          dst[i + 2] = dst[lasti + 2];
-          break;
-        case 2:
-          dst[i] = dst[i + off + 3];
-          dst[i + 1] = dst[i + off + 4];
-          dst[i + 2] = dst[i + off + 5];
-          break;
-        case 4:
-          dst[i] = (u8)((int)dst[lasti] + (int)dst[i + off + 3] - (int)dst[i + off]);
-          dst[i + 1] = (u8)((int)dst[lasti + 1] + (int)dst[i + off + 4] - (int)dst[i + off + 1]);
-          dst[i + 2] = (u8)((int)dst[lasti + 2] + (int)dst[i + off + 5] - (int)dst[i + off + 2]);
-          break;
-        default:
-          dst[i] = dst[i + off];
-          dst[i + 1] = dst[i + off + 1];
-          dst[i + 2] = dst[i + off + 2];
-          break;
-      }
-      lasti = i;
-      xx++;
-      i += 3;
-      if (xx >= W) {
-        xx = 0;
-        y++;
-        i = y * S;
-      }
-      if (y >= H && n > 0) {
-        bad = true;
-        break;
-      }
-    }
-    gg = dst[lasti + 1];
-    b = dst[lasti + 2];
-    cx = (u32)gg >> 2;
-    next_cx(b);
-  }
-  if (bad) atomicOr(status, 4u);
-}
-
+// (the decoder proper is in scpr_wave.hpp)
 // flat key frame: every pixel = the 3 bytes after the header (screencap.cpp:1537-1553)
 __global__ __launch_bounds__(256) void k_fill_flat(u8* planes, Geom g, int slot, u32 rgb) {
   const int idx = blockIdx.x * 256 + threadIdx.x;

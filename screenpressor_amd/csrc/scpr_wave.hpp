@@ -54,16 +54,28 @@ __device__ __forceinline__ int shift_for(int tot) {  // number of doublings unti
 constexpr int WIN = 4096;     // input ring, bytes
 constexpr int CACHE_N = 256;  // colour records cached in LDS
 
-struct WaveLds {
-  u32 ring[WIN / 4];
-  u32 nfc[6][256];   // run-length models: freq | cum << 16
+struct FixedBlob {      // every fixed-alphabet model of the decoder: freq | cum << 16, counts, running totals
+  u32 nfc[6][256];     // run lengths, by pixel type (ntab)
   u32 ncnt[6][256];
-  u32 pfc[6][8];     // pixel-type models
+  u32 mfc[2][512];     // motion vector components (mvtab)
+  u32 mcnt[2][512];
+  u32 xfc[2][256];     // [0] changed-block index bytes (xxtab), [1] block-type run lengths (ntab2)
+  u32 xcnt[2][256];
+  u32 sfc[4][16];      // changed-rect coordinates (sxytab)
+  u32 scnt[4][16];
+  u32 pfc[6][8];       // pixel types, by previous type (ptypetab)
   u32 pcnt[6][8];
-  int ftot[12];  // running count totals: run-length tables 0-5, pixel-type tables 6-11
+  u32 bfc[8];          // block types (bttab)
+  u32 bcnt[8];
+  int ftot[24];        // totals: 0-5 run lengths, 6-11 pixel types, 12/13 mv, 14/15 index/length, 16-19 rect, 20 block type
+};
+struct __attribute__((aligned(16))) WaveLds {
+  u32 ring[WIN / 4];
+  FixedBlob fx;
   u32 crec[CACHE_N][16];
   u16 ctag[CACHE_N];
   u16 tmp[256];
+  u32 tile[17 * 17];   // P-frame block under reconstruction, with one row above and one column to the left
 };
 
 // The colour model of one context, operated by a whole wave.  The header is
@@ -422,13 +434,21 @@ struct WaveDec : WaveModel {
     }
     return v;
   }
-  __device__ __forceinline__ void stream_init() {
+  __device__ __forceinline__ void stream_init(const u8* s) {  // decodeBegin, screencap.h:295-301
+    wave_fence();
+    src = s;
+    rpos = 0;
+    buf = 0;
+    nb = 0;
+    have_pre = false;
+    ndec = 0;
     ((uint4*)L.ring)[lane] = load16(0);
     ((uint4*)L.ring)[64 + lane] = load16(1024);
     loaded = 2048;
     pend = load16(2048);
     issued = 3072;
     __syncthreads();
+    x = take_u32();
   }
   // once per symbol: keep >= 1 KiB of input in LDS and one word prefetched
   __device__ __forceinline__ void tick() {
@@ -484,18 +504,26 @@ struct WaveDec : WaveModel {
   }
 
   // ---------------------------------------------------------------- fixed ---
-  __device__ __forceinline__ void fixed_init() {
+  __device__ __forceinline__ void fixed_init() {  // renew() of every table (RenewI, screencap.cpp:178-198)
+    FixedBlob& F = L.fx;
+    auto fill = [&](u32* fc, u32* cnt, int nsym, int cap, int ti) __attribute__((always_inline)) {
+      const int fr = kProbScale / nsym, c0 = fr - (fr >> 1);
+      for (int j = lane; j < cap; j += 64) {
+        fc[j] = j < nsym ? ((u32)fr | ((u32)(fr * j) << 16)) : 0xFFFFFFFFu;
+        cnt[j] = j < nsym ? (u32)c0 : 0u;
+      }
+      if (lane == 0) F.ftot[ti] = c0 * nsym;
+    };
     for (int t = 0; t < 6; t++) {
-      for (int j = lane; j < 256; j += 64) {
-        L.nfc[t][j] = 16u | ((u32)(16 * j) << 16);
-        L.ncnt[t][j] = 8;
-      }
-      if (lane < 8) {
-        L.pfc[t][lane] = lane < 6 ? (682u | ((u32)(682 * lane) << 16)) : 0xFFFF0000u;
-        L.pcnt[t][lane] = lane < 6 ? 341u : 0u;
-      }
+      fill(F.nfc[t], F.ncnt[t], 256, 256, t);
+      fill(F.pfc[t], F.pcnt[t], 6, 8, 6 + t);
     }
-    if (lane < 12) L.ftot[lane] = lane < 6 ? 2048 : 2046;
+    for (int t = 0; t < 2; t++) {
+      fill(F.mfc[t], F.mcnt[t], 512, 512, 12 + t);
+      fill(F.xfc[t], F.xcnt[t], 256, 256, 14 + t);
+    }
+    for (int t = 0; t < 4; t++) fill(F.sfc[t], F.scnt[t], 16, 16, 16 + t);
+    fill(F.bfc, F.bcnt, 5, 8, 20);
   }
   template <int PER>
   __device__ __forceinline__ int fixed_rebuild(u32* fc, u32* cnt, int nsym) {  // incrCnt rebuild, ans_contexts.h:1075-1090
@@ -523,48 +551,48 @@ struct WaveDec : WaveModel {
     wave_fence();
     return wave_sum(ns);
   }
-  // symbol whose interval holds v; updates the table (decode + incrCnt, :1093-1112, :1070-1091)
-  __device__ __forceinline__ int fixed_n(int t) {
+  // Symbol whose interval holds the coder value, then the table update (decode + incrCnt,
+  // ans_contexts.h:1093-1112, :1070-1091).  PER entries per lane; entries past the alphabet hold ~0.
+  template <int PER>
+  __device__ __forceinline__ int fixed_any(u32* fc, u32* cnt, int nsym, int ti) {
     wave_fence();
-    u32* fc = L.nfc[t];
-    u32* cnt = L.ncnt[t];
-    const u32 v = x & (kProbScale - 1);
-    const uint4 e = ((const uint4*)fc)[lane];
-    const int tot0 = L.ftot[t];
-    const u64 m = __ballot((e.x >> 16) <= v);
+    const u32 v = x & (kProbScale - 1), lim = (v + 1) << 16;  // cum <= v  <=>  (freq | cum << 16) < lim
+    u32 e[PER];
+#pragma unroll
+    for (int q = 0; q < PER; q++) e[q] = (PER > 1 || lane < (nsym <= 8 ? 8 : 16)) ? fc[lane * PER + q] : 0xFFFFFFFFu;
+    const int tot0 = L.fx.ftot[ti];
+    const u64 m = __ballot(e[0] < lim);
     const int own = 63 - __builtin_clzll(m);
-    int k = ((e.y >> 16) <= v) + ((e.z >> 16) <= v) + ((e.w >> 16) <= v);
-    u32 sel = k == 0 ? e.x : k == 1 ? e.y : k == 2 ? e.z : e.w;
-    const int kk = (int)rdl((u32)k, own);
+    int k = 0;
+#pragma unroll
+    for (int q = 1; q < PER; q++) k += e[q] < lim;
+    u32 sel = e[0];
+#pragma unroll
+    for (int q = 1; q < PER; q++) sel = (k == q) ? e[q] : sel;
+    const int kk = PER > 1 ? (int)rdl((u32)k, own) : 0;
     const u32 s = rdl(sel, own);
-    const int sym = own * 4 + kk;
-    if (lane == own) cnt[sym] += kStepDense;
+    const int sym = own * PER + kk;
+    if (lane == own) __hip_atomic_fetch_add(&cnt[sym], (u32)kStepDense, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     wave_fence();
     int tot = (int)rfl((u32)tot0) + kStepDense;
     advance(s >> 16, s & 0xFFFF, v);
-    if (tot + kStepDense > kProbScale) tot = fixed_rebuild<4>(fc, cnt, 256);
-    if (lane == 0) L.ftot[t] = tot;
+    if (tot + kStepDense > kProbScale) tot = fixed_rebuild<PER>(fc, cnt, nsym);
+    if (lane == 0) L.fx.ftot[ti] = tot;
     count();
     return sym;
   }
-  __device__ __forceinline__ int fixed_p(int t) {
-    wave_fence();
-    u32* fc = L.pfc[t];
-    u32* cnt = L.pcnt[t];
+  __device__ __forceinline__ int fixed_n(int t) { return fixed_any<4>(L.fx.nfc[t], L.fx.ncnt[t], 256, t); }
+  __device__ __forceinline__ int fixed_p(int t) { return fixed_any<1>(L.fx.pfc[t], L.fx.pcnt[t], 6, 6 + t); }
+  __device__ __forceinline__ int fixed_mv(int t) { return fixed_any<8>(L.fx.mfc[t], L.fx.mcnt[t], 512, 12 + t); }
+  __device__ __forceinline__ int fixed_x(int t) { return fixed_any<4>(L.fx.xfc[t], L.fx.xcnt[t], 256, 14 + t); }
+  __device__ __forceinline__ int fixed_sxy(int t) { return fixed_any<1>(L.fx.sfc[t], L.fx.scnt[t], 16, 16 + t); }
+  __device__ __forceinline__ int fixed_bt() { return fixed_any<1>(L.fx.bfc, L.fx.bcnt, 5, 20); }
+  __device__ __forceinline__ bool get_bool() {  // decodeBool, screencap.h:411-421
     const u32 v = x & (kProbScale - 1);
-    const u32 e = lane < 8 ? fc[lane] : 0xFFFF0000u;
-    const int tot0 = L.ftot[6 + t];
-    const u64 m = __ballot((e >> 16) <= v);
-    const int sym = 63 - __builtin_clzll(m);
-    const u32 s = rdl(e, sym);
-    if (lane == sym) cnt[sym] += kStepDense;
-    wave_fence();
-    int tot = (int)rfl((u32)tot0) + kStepDense;
-    advance(s >> 16, s & 0xFFFF, v);
-    if (tot + kStepDense > kProbScale) tot = fixed_rebuild<1>(fc, cnt, 6);
-    if (lane == 0) L.ftot[6 + t] = tot;
+    const bool flag = v >= kProbScale / 2;
+    advance(flag ? kProbScale / 2 : 0, kProbScale / 2, v);
     count();
-    return sym;
+    return flag;
   }
 
   // --------------------------------------------------------------- colour ---
@@ -626,30 +654,45 @@ struct WaveDec : WaveModel {
   }
 };
 
-// One wave per key frame (DecompressI, screencap.cpp:414-498).
-// Decoded pixels go to an LDS ring that always holds the last two rows (the
-// predictors read "previous", "top" and "top-left" from it) and every finished
-// row is flushed to HBM with wide stores; the plane in HBM is never read back.
-__global__ __launch_bounds__(64) void k_decode_intra_w(const u8* __restrict__ packets, const u8* packets_end, const DecFrame* __restrict__ frames, u8* __restrict__ planes,
-                                                       Geom g, ColState* __restrict__ states, Arena arena, int f0, u32* __restrict__ status, int ring_bytes) {
-  __shared__ WaveLds L;
-  extern __shared__ __align__(16) u8 pix[];  // ring_bytes (power of two >= 2*S + 1024)
-  const DecFrame fr = frames[blockIdx.x];
-  u8* dst = planes + (size_t)fr.slot * g.plane_stride;
-  const int lane = lane_id();
+// ---------------------------------------------------------------------------------------
+// One wave per GOP: a key frame (or a flat frame that renews the models) and the P-frames
+// that depend on it, decoded in order by the same wave so that the models, the coder and
+// the previous plane never leave the CU between frames.
+struct DecFrame {
+  u64 src_off;   // packet offset in the packet buffer
+  u32 src_len;
+  int slot;      // destination plane
+  int kind;      // 0 coded key frame, 1 flat key frame (plane filled by k_fill_flat), 2 P-frame
+  int prev_slot; // P-frames: plane of the previous frame
+};
+struct DecGop {
+  int first, count;  // frames[first .. first+count)
+  int load;          // 1: the models continue from fixedstore[gop] / states (state of an earlier call)
+  int pad;
+};
+
+// three bytes at p, through L2 (bypasses this CU's vector L1, which may hold lines from before
+// the wave's own stores to the same plane)
+__device__ __forceinline__ u32 ld3_l2(const u8* p) {
+  const size_t a = (size_t)p;
+  const u32* w = (const u32*)(a & ~(size_t)3);
+  const u32 sh = (u32)(a & 3) * 8;
+  const u32 lo = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  u32 v = lo >> sh;
+  if (sh > 8) v |= __hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << (32 - sh);
+  return v & 0xFFFFFFu;
+}
+
+// Key frame (DecompressI, screencap.cpp:414-498).  Decoded pixels go to an LDS ring that always
+// holds the last two rows (the predictors read "previous", "top" and "top-left" from it) and every
+// finished row is flushed to HBM with wide stores; the plane in HBM is never read back.
+__device__ __forceinline__ void decode_intra_frame(WaveDec& D, const Geom& g, u8* __restrict__ dst, u8* pix, int ring_bytes) {
+  const int lane = D.lane;
   const u32 pmask = (u32)ring_bytes - 1u;
-  for (int i = lane; i < CACHE_N; i += 64) L.ctag[i] = 0;
-  const u8* payload = packets + fr.src_off + 1;  // after the frame header byte
-  WaveDec D(L, payload, packets_end, states + (size_t)blockIdx.x * NCOLCTX, arena, f0);
-  D.fixed_init();
-  wave_fence();
-  D.stream_init();
-  D.x = D.take_u32();
   const int W = g.W, H = g.H, S = g.S;
   const int chunk = W < 64 ? W : 64;
-
   auto ctx_c0 = [&](u32 lp) __attribute__((always_inline)) { return (int)(((lp >> 18) & 63) | (((lp >> 10) & 63) << 6)); };  // (b>>2) | (g>>2)<<6
-  auto get_rgb = [&](u32 lp) __attribute__((always_inline)) -> u32 {  // DecodeRGB, screencap.cpp:662-679; lp = pixel that sets the first context
+  auto get_rgb = [&](u32 lp) __attribute__((always_inline)) -> u32 {  // DecodeRGB, screencap.cpp:662-679
     const int c0 = D.colour(ctx_c0(lp));
     const int c1 = D.colour(4096 + ((c0 >> 2) | (((lp >> 18) & 63) << 6)));
     const int c2 = D.colour(8192 + ((c1 >> 2) | ((c0 >> 2) << 6)));
@@ -669,7 +712,7 @@ __global__ __launch_bounds__(64) void k_decode_intra_w(const u8* __restrict__ pa
       for (int q = W * 3; q < S; q++) pix[((u32)(yq * S + q)) & pmask] = 0;
   };
   auto get3 = [&](u32 i) __attribute__((always_inline)) -> u32 { return (u32)pix[i & pmask] | ((u32)pix[(i + 1) & pmask] << 8) | ((u32)pix[(i + 2) & pmask] << 16); };
-  // rows [from, to) are complete in the ring: copy them to the plane (row padding is zero, DecompressFrame :1524-1528)
+  // rows [flushed, to) are complete in the ring: copy them to the plane
   int flushed = 0;
   auto flush_rows = [&](int to) __attribute__((always_inline)) {
     wave_fence();
@@ -683,7 +726,7 @@ __global__ __launch_bounds__(64) void k_decode_intra_w(const u8* __restrict__ pa
             u32 w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-              const int keep = pad0 - (o + 4 * q);  // bytes of this word that are pixel data
+              const int keep = pad0 - (o + 4 * q);
               if (keep <= 0) w[q] = 0;
               else if (keep < 4) w[q] &= (1u << (8 * keep)) - 1u;
             }
@@ -701,7 +744,7 @@ __global__ __launch_bounds__(64) void k_decode_intra_w(const u8* __restrict__ pa
     }
   };
 
-  u32 lastpix = 0;  // last decoded pixel (3 bytes), wave-uniform; 0 gives context 0 for the first pixel (cx = cx1 = 0, :419)
+  u32 lastpix = 0;  // last decoded pixel; 0 gives context 0 for the first pixel (cx = cx1 = 0, :419)
   // One loop for both phases so that every model routine is instantiated once:
   //   header phase (k < W+1): literal + run length over the first row and pixel (0,1)  (:421-438)
   //   body: pixel type, literal if type 0, run length                                  (:443-494)
@@ -773,9 +816,231 @@ __global__ __launch_bounds__(64) void k_decode_intra_w(const u8* __restrict__ pa
     if (flushed < y) flush_rows(y);
   }
   if (!D.bad) flush_rows(H);
-  D.flush_records();
-  if (D.bad && lane == 0) atomicOr(status, 4u);
+}
 
+// P-frame (DecompressP, screencap.cpp:1275-1432).  The new plane starts as a copy of the previous
+// one; motion blocks are copied from the previous plane, pixel-coded rects are rebuilt in an LDS
+// tile (with the row above and the column to the left as predictor context) and written back.
+__device__ __forceinline__ void decode_inter_frame(WaveDec& D, const Geom& g, u8* __restrict__ cur, const u8* __restrict__ prv, const u8* head, u8* bts, int far_x, int far_y) {
+  const int lane = D.lane;
+  const int W = g.W, H = g.H, S = g.S;
+  const int nbx = (W + 15) >> 4, nby = (H + 15) >> 4, nblocks = nbx * nby;
+  __threadfence();  // the previous plane was written by this wave (or by another kernel): make it readable
+  {
+    const size_t bytes = (size_t)H * S;
+    for (size_t o = (size_t)lane * 16; o + 16 <= bytes; o += 1024) *(uint4*)(cur + o) = *(const uint4*)(prv + o);
+    for (size_t o = (bytes & ~(size_t)15) + lane; o < bytes; o += 64) cur[o] = prv[o];
+  }
+  const u32 first = *(const volatile u8*)head;
+  if (!(first & 1u)) return;  // nothing changed (:1286-1291)
+  D.stream_init(head + 1);
+  auto get_x = [&]() __attribute__((always_inline)) {
+    D.tick();
+    return D.fixed_x(0);
+  };
+  int lo = get_x(), hi = get_x();
+  const int xx1 = (hi << 8) + lo;
+  lo = get_x();
+  hi = get_x();
+  const int xx2 = (hi << 8) + lo;
+  if (xx2 >= nblocks || xx1 > xx2) {
+    D.bad = true;
+    return;
+  }
+  for (int i = lane; i < nblocks; i += 64) bts[i] = 0;
+  wave_fence();
+  for (int b = xx1; b <= xx2 && !D.bad;) {  // block types, run-length coded (:1306-1313)
+    D.tick();
+    const int c = D.fixed_bt();
+    D.tick();
+    const int n = D.fixed_x(1);
+    if (n < 1 || b + n > nblocks) {
+      D.bad = true;
+      break;
+    }
+    for (int q = lane; q < n; q += 64) bts[b + q] = (u8)c;
+    b += n;
+  }
+  wave_fence();
+  u32 lastpix = 0;  // cx = cx1 = 0 (:1317)
+  int lastmx = 0, lastmy = 0;
+  auto ctx_c0 = [&](u32 lp) __attribute__((always_inline)) { return (int)(((lp >> 18) & 63) | (((lp >> 10) & 63) << 6)); };
+  u32* tile = D.L.tile;
+  for (int b = 0, bx = 0, by = 0; b < nblocks && !D.bad; b++, bx++) {
+    if (bx == nbx) {
+      bx = 0;
+      by++;
+    }
+    const int t = (int)rfl((u32)bts[b]);
+    if (!t) continue;
+    int x1 = bx * 16, y1 = by * 16, x2 = min(x1 + 16, W), y2 = min(y1 + 16, H);
+    if ((t - 1) & 1) {  // changed rect inside the block (:1333-1346)
+      D.tick();
+      const int a0 = D.fixed_sxy(0);
+      D.tick();
+      const int a1 = D.fixed_sxy(1);
+      D.tick();
+      const int a2 = D.fixed_sxy(2);
+      D.tick();
+      const int a3 = D.fixed_sxy(3);
+      x2 = x1 + a2 + 1;
+      y2 = y1 + a3 + 1;
+      x1 += a0;
+      y1 += a1;
+      if (x2 > W || y2 > H || x1 >= x2 || y1 >= y2) {
+        D.bad = true;
+        break;
+      }
+    }
+    const int w = x2 - x1, h = y2 - y1;
+    if ((t - 1) & 2) {  // motion block (:1348-1368)
+      int mx = lastmx, my = lastmy;
+      D.tick();
+      if (!D.get_bool()) {
+        D.tick();
+        mx = D.fixed_mv(0) - far_x;
+        D.tick();
+        my = D.fixed_mv(1) - far_y;
+      }
+      lastmx = mx;
+      lastmy = my;
+      if (x1 + mx < 0 || y1 + my < 0 || x2 + mx > W || y2 + my > H) {
+        D.bad = true;
+        break;
+      }
+      for (int i = lane; i < w * h; i += 64) {
+        const int yy = i / w, xq = i - yy * w;
+        const u8* sp = prv + (size_t)(y1 + yy + my) * S + (x1 + xq + mx) * 3;
+        u8* dp = cur + (size_t)(y1 + yy) * S + (x1 + xq) * 3;
+        dp[0] = sp[0];
+        dp[1] = sp[1];
+        dp[2] = sp[2];
+      }
+      continue;
+    }
+    // pixel-coded rect (:1370-1421): context border from the plane, then runs inside the tile
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores to the plane have reached L2
+    for (int i = lane; i < 17 * 17; i += 64) {
+      const int ty = i / 17, tx = i - ty * 17;
+      u32 v = 0;
+      if ((ty == 0 || tx == 0) && ty <= h && tx <= w) {
+        const int xq = x1 - 1 + tx, yq = y1 - 1 + ty;
+        if (xq >= 0 && yq >= 0) v = ld3_l2(cur + (size_t)yq * S + xq * 3);
+      }
+      tile[i] = v;
+    }
+    wave_fence();
+    int x = x1, y = y1, pt = 0;
+    while (y < y2 && !D.bad) {
+      D.tick();
+      const int last_t = pt;
+      pt = D.fixed_p(last_t);
+      u32 px = lastpix;
+      if (pt == 0) {
+        const int c0 = D.colour(ctx_c0(lastpix));
+        const int c1 = D.colour(4096 + ((c0 >> 2) | (((lastpix >> 18) & 63) << 6)));
+        const int c2 = D.colour(8192 + ((c1 >> 2) | ((c0 >> 2) << 6)));
+        px = (u32)c0 | ((u32)c1 << 8) | ((u32)c2 << 16);
+      }
+      D.tick();
+      int rem = D.fixed_n(pt);
+      if (rem < 1) {
+        D.bad = true;
+        break;
+      }
+      while (rem > 0) {
+        if (y >= y2) {
+          D.bad = true;
+          break;
+        }
+        const int seg = min(rem, x2 - x);  // pixels of this run on the current rect row (<= 16)
+        const int ty = y - y1 + 1, tx0 = x - x1 + 1;
+        const bool act = lane < seg;
+        const int tx = tx0 + lane;
+        wave_fence();
+        u32 v = px;
+        if (pt == 1) {
+          v = tile[ty * 17 + tx0 - 1];
+        } else if (pt == 2) {
+          if (act) v = tile[(ty - 1) * 17 + tx];
+        } else if (pt == 3) {
+          if (act) v = ld3(prv + (size_t)y * S + (x + lane) * 3);
+        } else if (pt == 5) {
+          if (act) v = tile[(ty - 1) * 17 + tx - 1];
+        } else if (pt == 4) {
+          u32 tp = 0, tl = 0;
+          if (act) {
+            tp = tile[(ty - 1) * 17 + tx];
+            tl = tile[(ty - 1) * 17 + tx - 1];
+          }
+          const u32 base = tile[ty * 17 + tx0 - 1];
+          int d0 = (int)(tp & 255) - (int)(tl & 255), d1 = (int)((tp >> 8) & 255) - (int)((tl >> 8) & 255), d2 = (int)((tp >> 16) & 255) - (int)((tl >> 16) & 255);
+          if (!act) d0 = d1 = d2 = 0;
+          d0 = row_incl_scan(d0);
+          d1 = row_incl_scan(d1);
+          d2 = row_incl_scan(d2);
+          v = (u32)(((int)(base & 255) + d0) & 255) | ((u32)(((int)((base >> 8) & 255) + d1) & 255) << 8) | ((u32)(((int)((base >> 16) & 255) + d2) & 255) << 16);
+        }
+        if (act) tile[ty * 17 + tx] = v;
+        wave_fence();
+        lastpix = rdl(v, seg - 1) & 0xFFFFFFu;
+        rem -= seg;
+        x += seg;
+        if (x == x2) {
+          x = x1;
+          y++;
+        }
+      }
+    }
+    wave_fence();
+    for (int i = lane; i < w * h; i += 64) {  // the finished rect goes to the plane
+      const int yy = i / w, xq = i - yy * w;
+      const u32 v = tile[(yy + 1) * 17 + xq + 1];
+      u8* dp = cur + (size_t)(y1 + yy) * S + (x1 + xq) * 3;
+      dp[0] = (u8)v;
+      dp[1] = (u8)(v >> 8);
+      dp[2] = (u8)(v >> 16);
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void k_decode_gop_w(const u8* __restrict__ packets, const u8* packets_end, const DecFrame* __restrict__ frames, const DecGop* __restrict__ gops,
+                                                     u8* __restrict__ planes, Geom g, ColState* __restrict__ states, Arena arena, int f0, u32* __restrict__ status, int ring_bytes,
+                                                     FixedBlob* __restrict__ fixedstore, int far_x, int far_y) {
+  __shared__ WaveLds L;
+  extern __shared__ __align__(16) u8 pix[];  // ring_bytes (power of two >= 2*S + 1024), then one byte per 16x16 block
+  const DecGop gop = gops[blockIdx.x];
+  const int lane = lane_id();
+  for (int i = lane; i < CACHE_N; i += 64) L.ctag[i] = 0;
+  WaveDec D(L, packets, packets_end, states + (size_t)blockIdx.x * NCOLCTX, arena, f0);
+  if (gop.load) {
+    const u32* src = (const u32*)&fixedstore[blockIdx.x];
+    u32* dstw = (u32*)&L.fx;
+    for (int i = lane; i < (int)(sizeof(FixedBlob) / 4); i += 64) dstw[i] = src[i];
+  } else {
+    D.fixed_init();
+  }
+  wave_fence();
+  for (int fi = gop.first; fi < gop.first + gop.count && !D.bad; fi++) {
+    const DecFrame fr = frames[fi];
+    u8* dst = planes + (size_t)fr.slot * g.plane_stride;
+    if (fr.kind == 0) {
+      D.fixed_init();  // RenewI (:418); the colour records of the GOP start cleared
+      wave_fence();
+      D.stream_init(packets + fr.src_off + 1);
+      decode_intra_frame(D, g, dst, pix, ring_bytes);
+    } else if (fr.kind == 2) {
+      decode_inter_frame(D, g, dst, planes + (size_t)fr.prev_slot * g.plane_stride, packets + fr.src_off, pix + ring_bytes, far_x, far_y);
+    }
+  }
+  D.flush_records();
+  wave_fence();
+  {
+    u32* dstw = (u32*)&fixedstore[blockIdx.x];
+    const u32* src = (const u32*)&L.fx;
+    for (int i = lane; i < (int)(sizeof(FixedBlob) / 4); i += 64) dstw[i] = src[i];
+  }
+  if (D.bad && lane == 0) atomicOr(status, 4u);
 }
 
 // ------------------------------------------------------------- encoder chains ---

@@ -109,6 +109,7 @@ def test_batch_key_frames_1080p_roundtrip_and_hash():
 def _encode_sequence_both(frames, w, h, bpp=32, keys=(0,), **kw):
     """per-frame API on both sides; returns list of (gpu_bytes, oracle_bytes, ftype)"""
     gpu = _codec(w, h, bpp, **kw)
+    dec = _codec(w, h, bpp, **kw)
     ora = O.OracleCodec(w, h, bpp, **{k: v for k, v in kw.items() if k in ("loss", "workers")})
     out = []
     for t, f in enumerate(frames):
@@ -117,6 +118,8 @@ def _encode_sequence_both(frames, w, h, bpp=32, keys=(0,), **kw):
         if got != want and len(want) > 4:
             _check_entries(gpu, ora)
         assert gft == wft and got == want, (t, gft, wft, _first_diff(got, want))
+        r, back = dec.DecompressFrame(got, gft)   # the HIP decoder, frame by frame, state carried between calls
+        assert r == 1 and np.array_equal(back.reshape(np.asarray(f).shape), f), ("decode", t, gft)
         out.append((got, gft))
     return out
 
@@ -176,3 +179,11 @@ def test_p_frames_batch_api_1080p():
         g = got[off:off + sizes[t]]
         off += sizes[t]
         assert g == want[t], (t, _first_diff(g, want[t]))
+    # batch decode of the whole I+P stream in two calls (the GOP continues across them)
+    dec = _codec(w, h)
+    pk = torch.from_numpy(np.frombuffer(got, np.uint8).copy()).cuda()
+    fts = [0] + [1] * (n - 1)
+    r1, o1 = dec.DecompressBatch(pk[:sum(sizes[:3])].contiguous(), sizes[:3], fts[:3])
+    r2, o2 = dec.DecompressBatch(pk[sum(sizes[:3]):].contiguous(), sizes[3:], fts[3:])
+    assert r1 == 3 and r2 == n - 3
+    assert torch.equal(torch.cat([o1, o2]).reshape(n, -1), d)
