@@ -85,15 +85,9 @@ def main():
         t2 = time.perf_counter()
         td, sd = codec_d.last_timing()
         assert r == N
-        if world > 1:  # exchange step: compressed chunks to rank 0 (sizes first, then padded payloads)
-            tot = torch.tensor([out.numel()], device=dev, dtype=torch.int64)
-            alls = [torch.zeros_like(tot) for _ in range(world)]
-            dist.all_gather(alls, tot)
-            mx = int(max(int(a.item()) for a in alls))
-            pad = torch.zeros(mx, dtype=torch.uint8, device=dev)
-            pad[:out.numel()] = out
-            gl = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
-            dist.gather(pad, gl, dst=0)
+        if world > 1:  # exchange step: compressed chunks + sizes to rank 0, frame order (RCCL over xGMI)
+            from screenpressor_amd.sharding import gather_packets
+            gather_packets(dist, rank, world, out, sizes, device=dev)
         if timed:
             t_enc_acc += t1 - t0
             t_dec_acc += t2 - t1

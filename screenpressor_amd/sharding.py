@@ -1,0 +1,64 @@
+"""Frame sharding across the GPUs of one node.
+
+The unit of independence is the GOP (a key frame and the P-frames that depend on it): RenewI
+resets every model at a key frame (screencap.cpp:343).  A stream of G GOPs is cut into
+contiguous GOP ranges, one per rank; each rank encodes its range as an independent stream and
+the packets are gathered to rank 0 in frame order.  No collective touches the data path until
+that gather.
+
+Note: the reference's motion search also remembers, per block, the last vector found in ANY
+earlier frame (mvs[], screencap.cpp:96-97, :726-735, never reset), so a shard is byte-identical
+to the reference run on that shard's frames from a fresh codec, not to a single process that
+encoded the whole stream.  Key-frame-only streams have no such memory and shard exactly.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def gop_starts(ftypes_in) -> list[int]:
+    """indices where the caller asks for a key frame (ftype 0)"""
+    return [i for i, t in enumerate(ftypes_in) if t == 0]
+
+
+def shard_gops(ftypes_in, world: int) -> list[tuple[int, int]]:
+    """contiguous [lo, hi) frame ranges, one per rank, cut at GOP starts and balanced by frame count"""
+    n = len(ftypes_in)
+    starts = gop_starts(ftypes_in)
+    if not starts or starts[0] != 0:
+        starts = [0] + starts
+    cuts = [0]
+    for r in range(1, world):
+        target = n * r / world
+        best = min(starts, key=lambda s: (abs(s - target), s))
+        cuts.append(max(best, cuts[-1]))
+    cuts.append(n)
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
+def gather_packets(dist, rank: int, world: int, payload: np.ndarray, sizes: np.ndarray, device=None):
+    """Rank 0 receives every rank's packets and per-frame sizes, in rank (= frame) order.
+    `payload` is a uint8 array (numpy on CPU/gloo, or a torch tensor on the GPU for RCCL)."""
+    import torch
+    t_payload = payload if isinstance(payload, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(payload))
+    t_sizes = torch.as_tensor(np.asarray(sizes, dtype=np.int64))
+    if device is not None:
+        t_payload, t_sizes = t_payload.to(device), t_sizes.to(device)
+    meta = torch.tensor([t_payload.numel(), t_sizes.numel()], dtype=torch.int64, device=t_payload.device)
+    metas = [torch.zeros_like(meta) for _ in range(world)]
+    dist.all_gather(metas, meta)
+    max_bytes = int(max(int(m[0]) for m in metas))
+    max_frames = int(max(int(m[1]) for m in metas))
+    pad_p = torch.zeros(max_bytes, dtype=torch.uint8, device=t_payload.device)
+    pad_p[: t_payload.numel()] = t_payload
+    pad_s = torch.zeros(max_frames, dtype=torch.int64, device=t_payload.device)
+    pad_s[: t_sizes.numel()] = t_sizes
+    gp = [torch.empty_like(pad_p) for _ in range(world)] if rank == 0 else None
+    gs = [torch.empty_like(pad_s) for _ in range(world)] if rank == 0 else None
+    dist.gather(pad_p, gp, dst=0)
+    dist.gather(pad_s, gs, dst=0)
+    if rank != 0:
+        return None, None
+    out_p = torch.cat([gp[r][: int(metas[r][0])] for r in range(world)])
+    out_s = torch.cat([gs[r][: int(metas[r][1])] for r in range(world)])
+    return out_p, out_s

@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Generates the golden fixtures in this directory.
+
+Provenance: the reference cannot be built in this image (every translation unit needs
+<windows.h>), so these streams come from the ORACLE (oracle/libspo.so, the
+CPU restatement of the reference algorithm) on seeded synthetic input.  They pin the
+oracle against regressions and give the GPU box byte-level targets that do not depend on
+the oracle being rebuilt there.  Re-run:  python tests/golden/make_golden.py
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import oracle_api as O  # noqa: E402
+from screenpressor_amd.synth import DesktopSequence, pack24  # noqa: E402
+
+CASES = [
+    # name, width, height, bpp, frames, key frames, seed, noise, workers, loss, keep_bytes
+    ("desktop_64x48_ip", 64, 48, 32, 8, (0,), 3, 0.0, 1, 0, True),
+    ("desktop_100x37_ip_padded", 100, 37, 32, 6, (0,), 4, 0.0, 1, 0, True),
+    ("desktop_100x37_rgb24", 100, 37, 24, 6, (0,), 4, 0.0, 1, 0, False),
+    ("desktop_128x96_workers4_keys", 128, 96, 32, 3, (0, 1, 2), 9, 0.0, 4, 0, True),
+    ("desktop_100x37_loss2", 100, 37, 32, 4, (0,), 6, 0.0, 1, 2, True),
+    ("noise_320x240_multiblock", 320, 240, 32, 2, (0,), 5, 0.6, 1, 0, False),
+    ("desktop_640x480_c1", 640, 480, 32, 60, (0,), 1, 0.0, 1, 0, False),      # BASELINE configs[0]
+    ("desktop_1080p_keys", 1920, 1080, 32, 3, (0, 1, 2), 1, 0.0, 1, 0, False),  # BASELINE configs[1] content
+    ("desktop_1080p_ip", 1920, 1080, 32, 4, (0,), 1, 0.0, 1, 0, False),        # BASELINE configs[2] content
+]
+
+
+def frames_of(case):
+    name, w, h, bpp, n, keys, seed, noise, workers, loss, keep = case
+    seq = DesktopSequence(w, h, seed=seed, noise_fraction=noise)
+    for t in range(n):
+        yield t, (seq.frame(t) if bpp == 32 else pack24(seq.frame24(t)))
+
+
+def main():
+    manifest = {}
+    for case in CASES:
+        name, w, h, bpp, n, keys, seed, noise, workers, loss, keep = case
+        enc = O.OracleCodec(w, h, bpp, loss=loss, workers=workers)
+        packets, types = [], []
+        for t, f in frames_of(case):
+            data, ft = enc.compress(f, key=(t in keys))
+            packets.append(data)
+            types.append(ft)
+        blob = b"".join(packets)
+        entry = {"width": w, "height": h, "bpp": bpp, "frames": n, "keys": list(keys), "seed": seed, "noise": noise,
+                 "workers": workers, "loss": loss, "sizes": [len(p) for p in packets], "ftypes": types,
+                 "sha256": hashlib.sha256(blob).hexdigest(),
+                 "frame_sha256": [hashlib.sha256(p).hexdigest() for p in packets]}
+        if keep:
+            with open(os.path.join(HERE, name + ".bin"), "wb") as fh:
+                fh.write(blob)
+            entry["file"] = name + ".bin"
+        manifest[name] = entry
+        print(name, len(blob), entry["sha256"][:16])
+    with open(os.path.join(HERE, "manifest.json"), "w") as fh:
+        json.dump(manifest, fh, indent=1)
+
+
+if __name__ == "__main__":
+    main()
