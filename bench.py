@@ -36,6 +36,9 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--cpu-frames", type=int, default=24, help="frames of the same workload timed on the host CPU (oracle)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--workload", choices=["keys", "ip"], default="keys",
+                    help="keys: every frame a key frame (BASELINE configs[1], the headline); ip: key frame every --gop frames (configs[2])")
+    ap.add_argument("--gop", type=int, default=50)
     args = ap.parse_args()
 
     import torch
@@ -63,7 +66,7 @@ def main():
     codec_d = ScreenCodec(local_rank).Init(W, H, 32)
     packets = torch.empty(max(256 << 20, N * W * H // 2), dtype=torch.uint8, device=dev)
     decoded = torch.empty(N * H * W * 4, dtype=torch.uint8, device=dev)
-    ftypes = [0] * N
+    ftypes = [0] * N if args.workload == "keys" else [0 if t % args.gop == 0 else 1 for t in range(N)]
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -120,7 +123,7 @@ def main():
         dom = max(per_step, key=per_step.get)
         raw = N * W * H * 4
         # algorithmic bytes per SURVEY.md §8(d): encode I = raw + c, decode I = c + raw, per frame
-        alg_bytes = raw + comp_bytes
+        alg_bytes = raw + comp_bytes if args.workload == "keys" else 2 * raw + comp_bytes  # P-frames also read the previous frame
         dom_ms = per_step[dom]
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -131,7 +134,7 @@ def main():
             import oracle_api as O
             nf = min(args.cpu_frames, N)
             sample = np.stack([seq.frame(t) for t in range(nf)]).reshape(nf, -1)
-            r = O.time_stream(sample, W, H, 32, key_interval=1)
+            r = O.time_stream(sample, W, H, 32, key_interval=1 if args.workload == "keys" else args.gop)
             assert r["bad"] == 0
             cpu = {"value": round(nf * W * H / 1e6 / (r["t_enc"] + r["t_dec"]), 2), "unit": "MPix/s", "cores": 1, "kind": "port",
                    "sample": f"first {nf} frames of the same workload, encode+decode, oracle/libspo.so (single thread)",
@@ -140,7 +143,8 @@ def main():
             "metric": "MPix/s encode+decode, 1080p RGB32; bitstream byte-identical to ref", "value": round(value, 2), "unit": "MPix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"{W}x{H} RGB32 key-frame-only (I-frames), {N} frames per GPU, synthetic desktop seed 1+rank",
+            "config": {"workload": (f"{W}x{H} RGB32 key-frame-only (I-frames), {N} frames per GPU, synthetic desktop seed 1+rank" if args.workload == "keys"
+                                    else f"{W}x{H} RGB32 I+P (key frame every {args.gop}), {N} frames per GPU, synthetic desktop seed 1+rank"),
                        "frames_per_gpu": N, "parallelism": f"frame-sharded x{world}", "lossless_roundtrip": lossless,
                        "compressed_bytes_per_gpu": comp_bytes,
                        "enc_MPix_s_rank0": round(N * W * H / 1e6 / (t_enc_acc / args.steps), 2),

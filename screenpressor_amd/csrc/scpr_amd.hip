@@ -747,8 +747,11 @@ int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* 
       while (ring < 2 * g.S + 1024) ring <<= 1;
       const int nblocks = ((g.W + 15) / 16) * ((g.H + 15) / 16);
       const int dyn = ring + ((nblocks + 15) & ~15);
-      HIPCHK(hipFuncSetAttribute((const void*)k_decode_gop_w, hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
-      hipLaunchKernelGGL(k_decode_gop_w, dim3((unsigned)ng), dim3(64), dyn, st, (const u8*)d_packets, (const u8*)d_packets + offs[nframes] + 8, c->decframes.as<DecFrame>(),
+      bool has_p = false;
+      for (const DecFrame& d : fr) has_p |= d.kind == 2;
+      auto kern = has_p ? k_decode_gop_w<true> : k_decode_gop_w<false>;  // key-frame-only GOPs: smaller kernel (instruction cache)
+      HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
+      hipLaunchKernelGGL(kern, dim3((unsigned)ng), dim3(64), dyn, st, (const u8*)d_packets, (const u8*)d_packets + offs[nframes] + 8, c->decframes.as<DecFrame>(),
                          c->decgops.as<DecGop>(), c->planes.as<u8>(), g, c->decstates.as<ColState>(), ar, c->f0, c->err.as<u32>(), ring, c->decfixed.as<FixedBlob>(),
                          (int)std::min<u32>(c->prm.high_range_x, 256), (int)std::min<u32>(c->prm.high_range_y, 256));
       // keep the state of the last GOP and the last plane for the next call

@@ -405,7 +405,7 @@ struct WaveDec : WaveModel {
   // input stream
   const u8* src;
   const u8* src_end;
-  u32 rpos = 0, loaded = 0, issued = 0, pre = 0;
+  u32 rpos = 0, loaded = 0, issued = 0, pre = 0;  // pre: prefetched ring word, still per-lane (made uniform on use)
   u64 buf = 0;
   int nb = 0;
   bool have_pre = false;
@@ -461,7 +461,7 @@ struct WaveDec : WaveModel {
       wave_fence();
     }
     if (nb <= 4 && !have_pre) {
-      pre = rfl(L.ring[(rpos & (WIN - 1)) >> 2]);
+      pre = L.ring[(rpos & (WIN - 1)) >> 2];  // consumed (and waited for) in need()
       rpos += 4;
       have_pre = true;
     }
@@ -470,10 +470,10 @@ struct WaveDec : WaveModel {
     wave_fence();
     while (nb < k) {
       if (!have_pre) {
-        pre = rfl(L.ring[(rpos & (WIN - 1)) >> 2]);
+        pre = L.ring[(rpos & (WIN - 1)) >> 2];
         rpos += 4;
       }
-      buf |= (u64)pre << (8 * nb);
+      buf |= (u64)rfl(pre) << (8 * nb);
       nb += 4;
       have_pre = false;
     }
@@ -693,10 +693,16 @@ __device__ __forceinline__ void decode_intra_frame(WaveDec& D, const Geom& g, u8
   const int chunk = W < 64 ? W : 64;
   auto ctx_c0 = [&](u32 lp) __attribute__((always_inline)) { return (int)(((lp >> 18) & 63) | (((lp >> 10) & 63) << 6)); };  // (b>>2) | (g>>2)<<6
   auto get_rgb = [&](u32 lp) __attribute__((always_inline)) -> u32 {  // DecodeRGB, screencap.cpp:662-679
-    const int c0 = D.colour(ctx_c0(lp));
-    const int c1 = D.colour(4096 + ((c0 >> 2) | (((lp >> 18) & 63) << 6)));
-    const int c2 = D.colour(8192 + ((c1 >> 2) | ((c0 >> 2) << 6)));
-    return (u32)c0 | ((u32)c1 << 8) | ((u32)c2 << 16);
+    // contexts: two previous bytes >> 2 (MAKECX1, screencap.h:35-36); one code copy for the three planes
+    u32 a = (lp >> 18) & 63, b = (lp >> 10) & 63, px = 0;
+#pragma unroll 1
+    for (int plane = 0; plane < 3; plane++) {
+      const u32 c = (u32)D.colour(plane * 4096 + (int)(a | (b << 6)));
+      px |= c << (8 * plane);
+      b = a;
+      a = c >> 2;
+    }
+    return px;
   };
   auto put3 = [&](u32 i, u32 v) __attribute__((always_inline)) {
     pix[i & pmask] = (u8)v;
@@ -937,10 +943,15 @@ __device__ __forceinline__ void decode_inter_frame(WaveDec& D, const Geom& g, u8
       pt = D.fixed_p(last_t);
       u32 px = lastpix;
       if (pt == 0) {
-        const int c0 = D.colour(ctx_c0(lastpix));
-        const int c1 = D.colour(4096 + ((c0 >> 2) | (((lastpix >> 18) & 63) << 6)));
-        const int c2 = D.colour(8192 + ((c1 >> 2) | ((c0 >> 2) << 6)));
-        px = (u32)c0 | ((u32)c1 << 8) | ((u32)c2 << 16);
+        u32 a = (lastpix >> 18) & 63, bb = (lastpix >> 10) & 63;
+        px = 0;
+#pragma unroll 1
+        for (int plane = 0; plane < 3; plane++) {
+          const u32 c = (u32)D.colour(plane * 4096 + (int)(a | (bb << 6)));
+          px |= c << (8 * plane);
+          bb = a;
+          a = c >> 2;
+        }
       }
       D.tick();
       int rem = D.fixed_n(pt);
@@ -1004,6 +1015,7 @@ __device__ __forceinline__ void decode_inter_frame(WaveDec& D, const Geom& g, u8
   }
 }
 
+template <bool HAS_P>
 __global__ __launch_bounds__(64) void k_decode_gop_w(const u8* __restrict__ packets, const u8* packets_end, const DecFrame* __restrict__ frames, const DecGop* __restrict__ gops,
                                                      u8* __restrict__ planes, Geom g, ColState* __restrict__ states, Arena arena, int f0, u32* __restrict__ status, int ring_bytes,
                                                      FixedBlob* __restrict__ fixedstore, int far_x, int far_y) {
@@ -1029,7 +1041,7 @@ __global__ __launch_bounds__(64) void k_decode_gop_w(const u8* __restrict__ pack
       wave_fence();
       D.stream_init(packets + fr.src_off + 1);
       decode_intra_frame(D, g, dst, pix, ring_bytes);
-    } else if (fr.kind == 2) {
+    } else if (HAS_P && fr.kind == 2) {
       decode_inter_frame(D, g, dst, planes + (size_t)fr.prev_slot * g.plane_stride, packets + fr.src_off, pix + ring_bytes, far_x, far_y);
     }
   }
