@@ -220,17 +220,136 @@ __global__ __launch_bounds__(64) void k_mvsearch(const u8* __restrict__ planes, 
 }
 __device__ __forceinline__ u32 smv_to_mv(u32 s) { return mv_pack((int)(s & 0x3FF) - 512, (int)((s >> 10) & 0x3FF) - 512); }
 
+// The vectors most often found by the search in a frame (and in the frame before it, whose
+// vectors reach this frame through mvs[]): the candidates FindMV's two predicted tries
+// (:715-735) will almost always ask about.  dict[pi][0..7] = mv_pack or 0xFFFFFFFF.
+constexpr int MVDICT = 8;
+__global__ __launch_bounds__(256) void k_mvdict(Geom g, const u32* __restrict__ binfo, const u32* __restrict__ smv, u32* __restrict__ dict) {
+  __shared__ u32 hkey[1024];
+  __shared__ u32 hcnt[1024];
+  __shared__ u32 best[256];
+  __shared__ u32 bidx[256];
+  const int pi = blockIdx.x, tid = threadIdx.x;
+  const int nbx = (g.W + 15) >> 4, nby = (g.H + 15) >> 4, nblocks = nbx * nby;
+  for (int i = tid; i < 1024; i += 256) {
+    hkey[i] = 0xFFFFFFFFu;
+    hcnt[i] = 0;
+  }
+  __syncthreads();
+  for (int f = max(0, pi - 1); f <= pi; f++)
+    for (int b = tid; b < nblocks; b += 256) {
+      const u32 sv = smv[(size_t)f * nblocks + b];
+      if (!(binfo[(size_t)f * nblocks + b] & 1u) || !(sv >> 31)) continue;
+      const u32 key = smv_to_mv(sv);
+      u32 h = (key * 2654435761u) >> 22;
+      for (int probe = 0; probe < 1024; probe++, h = (h + 1) & 1023) {
+        const u32 old = atomicCAS(&hkey[h], 0xFFFFFFFFu, key);
+        if (old == 0xFFFFFFFFu || old == key) {
+          atomicAdd(&hcnt[h], 1u);
+          break;
+        }
+      }
+    }
+  __syncthreads();
+  for (int k = 0; k < MVDICT; k++) {  // repeated arg-max
+    u32 bc = 0, bi = 0;
+    for (int i = tid; i < 1024; i += 256)
+      if (hcnt[i] > bc) {
+        bc = hcnt[i];
+        bi = (u32)i;
+      }
+    best[tid] = bc;
+    bidx[tid] = bi;
+    __syncthreads();
+    for (int d = 128; d >= 1; d >>= 1) {
+      if (tid < d && best[tid + d] > best[tid]) {
+        best[tid] = best[tid + d];
+        bidx[tid] = bidx[tid + d];
+      }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      dict[pi * MVDICT + k] = best[0] ? hkey[bidx[0]] : 0xFFFFFFFFu;
+      if (best[0]) hcnt[bidx[0]] = 0;
+    }
+    __syncthreads();
+  }
+}
+
+// row r of the rect at (x1,y1) in the current plane == row r of the rect at (x,y) in the previous plane
+__device__ __forceinline__ bool same_row(const u8* cur, const u8* prv, int S, const Rect& r, int x, int y, int row) {
+  const int wb = (r.x2 - r.x1) * 3;
+  const u8* a = cur + (size_t)(r.y1 + row) * S + r.x1 * 3;
+  const u8* b = prv + (size_t)(y + row) * S + x * 3;
+  u32 diff = 0;
+#pragma unroll
+  for (int k = 0; k < 12; k++)
+    if (k * 4 < wb) {
+      u32 va, vb;
+      __builtin_memcpy(&va, a + k * 4, 4);
+      __builtin_memcpy(&vb, b + k * 4, 4);
+      u32 d = va ^ vb;
+      const int rem = wb - k * 4;
+      if (rem < 4) d &= (1u << (8 * rem)) - 1u;
+      diff |= d;
+    }
+  return diff == 0;
+}
+
+// pre[pi][b]: bit k set when dictionary vector k lies in the far window and matches exactly.
+// Four blocks per wave, one rect row per lane.
+__global__ __launch_bounds__(64) void k_mvpretest(const u8* __restrict__ planes, Geom g, const PFrame* __restrict__ pf, const u32* __restrict__ binfo, MvParams mp,
+                                                  const u32* __restrict__ dict, u32* __restrict__ pre) {
+  const int pi = blockIdx.y, lane = threadIdx.x;
+  const int nbx = (g.W + 15) >> 4, nby = (g.H + 15) >> 4, nblocks = nbx * nby;
+  const int b = blockIdx.x * 4 + (lane >> 4), row = lane & 15;
+  const bool vb = b < nblocks;
+  const u32 info = vb ? binfo[(size_t)pi * nblocks + b] : 0;
+  const bool changed = info & 1u;
+  if (!__ballot(changed)) return;
+  const u8* cur = planes + (size_t)pf[pi].slot * g.plane_stride;
+  const u8* prv = planes + (size_t)pf[pi].prev_slot * g.plane_stride;
+  const int by = vb ? b / nbx : 0, bx = vb ? b - by * nbx : 0;
+  const Rect r = binfo_rect(info, bx, by);
+  const Windows w = mv_windows(r, g, mp.far_x, mp.far_y, mp.near_x, mp.near_y);
+  u32 bits = 0;
+  for (int k = 0; k < MVDICT; k++) {
+    const u32 mv = dict[pi * MVDICT + k];
+    bool bad = false;  // this row differs (or the candidate is unusable)
+    if (changed) {
+      const int x = r.x1 + mv_x(mv), y = r.y1 + mv_y(mv);
+      const bool inwin = mv != 0xFFFFFFFFu && x >= w.fx1 && x < w.fx2 && y >= w.fy1 && y < w.fy2;
+      if (!inwin) bad = true;
+      else if (row < r.y2 - r.y1) bad = !same_row(cur, prv, g.S, r, x, y, row);
+    }
+    const u64 m = __ballot(bad);
+    if (!((m >> (16 * (lane >> 4))) & 0xFFFFull)) bits |= 1u << k;
+  }
+  if (vb && row == 0) pre[(size_t)pi * nblocks + b] = changed ? bits : 0;
+}
+
 // Serial resolution over the P-frames of the chunk, in order (mvs[] carries over).
 // btype: 0 unchanged, 1/2 pixel-coded (whole/partial), 3/4 motion (whole/partial).
 // pinfo[pi] = {xx1, xx2}: bounding box corners of the changed blocks as block indices (:1145-1150)
 __global__ __launch_bounds__(64) void k_mvresolve(const u8* __restrict__ planes, Geom g, const PFrame* __restrict__ pf, int npf, const u32* __restrict__ binfo,
-                                                  const u32* __restrict__ smv, MvParams mp, u32* mvs, u8* __restrict__ btype, u32* __restrict__ bmv, int* __restrict__ pinfo) {
+                                                  const u32* __restrict__ smv, const u32* __restrict__ dict, const u32* __restrict__ pre, MvParams mp, u32* mvs,
+                                                  u8* __restrict__ btype, u32* __restrict__ bmv, int* __restrict__ pinfo) {
   const int lane = threadIdx.x;
   const int nbx = (g.W + 15) >> 4, nby = (g.H + 15) >> 4, nblocks = nbx * nby;
   const int G = min(64, nbx);
   for (int pi = 0; pi < npf; pi++) {
     const u8* cur = planes + (size_t)pf[pi].slot * g.plane_stride;
     const u8* prv = planes + (size_t)pf[pi].prev_slot * g.plane_stride;
+    u32 dk[MVDICT];
+#pragma unroll
+    for (int k = 0; k < MVDICT; k++) dk[k] = dict[pi * MVDICT + k];
+    auto dict_index = [&](u32 mv) __attribute__((always_inline)) {
+      int idx = -1;
+#pragma unroll
+      for (int k = 0; k < MVDICT; k++)
+        if (dk[k] == mv && idx < 0) idx = k;
+      return idx;
+    };
     u32 last = 0;  // last vector found by search (0,0), wave-uniform
     int bx1 = nbx, bx2 = -1, by1 = nby, by2 = -1;
     for (int base = 0; base < nblocks; base += G) {
@@ -253,19 +372,22 @@ __global__ __launch_bounds__(64) void k_mvresolve(const u8* __restrict__ planes,
         const Rect r = binfo_rect(info, bx, by);
         const Windows w = mv_windows(r, g, mp.far_x, mp.far_y, mp.near_x, mp.near_y);
         const u32 s = changed ? smv[(size_t)pi * nblocks + b] : 0;
+        const u32 pbits = changed ? pre[(size_t)pi * nblocks + b] : 0;
         const u32 umv = (changed && by > 0) ? __hip_atomic_load(&mvs[b - nbx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        const int ui = dict_index(umv);
+        auto exact = [&](u32 mv) __attribute__((always_inline)) {  // window test + SameBlocks for a vector outside the dictionary
+          const int x = r.x1 + mv_x(mv), y = r.y1 + mv_y(mv);
+          return x >= w.fx1 && x < w.fx2 && y >= w.fy1 && y < w.fy2 && same_rect(cur, prv, g.S, r, x, y);
+        };
         while (unresolved) {
           const bool mine = changed && ((unresolved >> lane) & 1ull);
+          const int li = dict_index(last);
           bool ta = false, tb = false;
           if (mine) {
-            const int sx = r.x1 + mv_x(last), sy = r.y1 + mv_y(last);
-            ta = sx >= w.fx1 && sx < w.fx2 && sy >= w.fy1 && sy < w.fy2 && same_rect(cur, prv, g.S, r, sx, sy);
-            if (!ta && by > 0 && umv != last) {
-              const int ux = r.x1 + mv_x(umv), uy = r.y1 + mv_y(umv);
-              tb = ux >= w.fx1 && ux < w.fx2 && uy >= w.fy1 && uy < w.fy2 && same_rect(cur, prv, g.S, r, ux, uy);
-            }
+            ta = li >= 0 ? ((pbits >> li) & 1u) : exact(last);
+            if (!ta && by > 0 && umv != last) tb = ui >= 0 ? ((pbits >> ui) & 1u) : exact(umv);
           }
-          const u64 A = __ballot(ta), B = __ballot(tb), Sm = __ballot(mine && !ta && !tb && (s >> 31));
+          const u64 Sm = __ballot(mine && !ta && !tb && (s >> 31));
           const int f = Sm ? __builtin_ctzll(Sm) : 64;
           const u64 upto = f >= 63 ? ~0ull : ((2ull << f) - 1ull);
           if (mine && ((upto >> lane) & 1ull)) {
@@ -282,8 +404,6 @@ __global__ __launch_bounds__(64) void k_mvresolve(const u8* __restrict__ planes,
           }
           if (f < 64) last = __shfl(my_mv, f);
           unresolved &= ~upto;
-          (void)A;
-          (void)B;
         }
       }
       if (vb) {

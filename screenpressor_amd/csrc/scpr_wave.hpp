@@ -76,6 +76,7 @@ struct __attribute__((aligned(16))) WaveLds {
   u16 ctag[CACHE_N];
   u16 tmp[256];
   u32 tile[17 * 17];   // P-frame block under reconstruction, with one row above and one column to the left
+  uint2 jobs[256];     // deferred motion-block copies of the current P-frame
 };
 
 // The colour model of one context, operated by a whole wave.  The header is
@@ -834,8 +835,16 @@ __device__ __forceinline__ void decode_inter_frame(WaveDec& D, const Geom& g, u8
   __threadfence();  // the previous plane was written by this wave (or by another kernel): make it readable
   {
     const size_t bytes = (size_t)H * S;
-    for (size_t o = (size_t)lane * 16; o + 16 <= bytes; o += 1024) *(uint4*)(cur + o) = *(const uint4*)(prv + o);
-    for (size_t o = (bytes & ~(size_t)15) + lane; o < bytes; o += 64) cur[o] = prv[o];
+    size_t o = (size_t)lane * 16;
+    for (; o + 7 * 1024 + 16 <= bytes; o += 8192) {  // 8 KiB per trip, eight 16-byte loads in flight per lane
+      uint4 v[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) v[k] = *(const uint4*)(prv + o + k * 1024);
+#pragma unroll
+      for (int k = 0; k < 8; k++) *(uint4*)(cur + o + k * 1024) = v[k];
+    }
+    for (; o + 16 <= bytes; o += 1024) *(uint4*)(cur + o) = *(const uint4*)(prv + o);
+    for (size_t q = (bytes & ~(size_t)15) + lane; q < bytes; q += 64) cur[q] = prv[q];
   }
   const u32 first = *(const volatile u8*)head;
   if (!(first & 1u)) return;  // nothing changed (:1286-1291)
@@ -872,13 +881,47 @@ __device__ __forceinline__ void decode_inter_frame(WaveDec& D, const Geom& g, u8
   int lastmx = 0, lastmy = 0;
   auto ctx_c0 = [&](u32 lp) __attribute__((always_inline)) { return (int)(((lp >> 18) & 63) | (((lp >> 10) & 63) << 6)); };
   u32* tile = D.L.tile;
-  for (int b = 0, bx = 0, by = 0; b < nblocks && !D.bad; b++, bx++) {
-    if (bx == nbx) {
-      bx = 0;
-      by++;
+  uint2* jobs = D.L.jobs;
+  int njobs = 0;
+  // motion-block copies are queued and executed four blocks at a time (one row per lane, a row's
+  // bytes in flight together); the source is the previous plane, which this frame never modifies
+  auto flush_jobs = [&]() __attribute__((always_inline)) {
+    wave_fence();
+    for (int base = 0; base < njobs; base += 4) {
+      const int jb = base + (lane >> 4), r = lane & 15;
+      if (jb < njobs) {
+        const uint2 j = jobs[jb];
+        const int jx1 = (int)(j.x & 0x1FFF), jy1 = (int)((j.x >> 13) & 0x1FFF), jw = (int)((j.x >> 26) & 15) + 1;
+        const int jh = (int)(j.y & 15) + 1, jmx = (int)((j.y >> 4) & 0x3FF) - 512, jmy = (int)((j.y >> 14) & 0x3FF) - 512;
+        if (r < jh) {
+          const u8* sp = prv + (size_t)(jy1 + r + jmy) * S + (jx1 + jmx) * 3;
+          u8* dp = cur + (size_t)(jy1 + r) * S + jx1 * 3;
+          const int wb = jw * 3;
+          u32 v[12];
+#pragma unroll
+          for (int k = 0; k < 12; k++)
+            if (k * 4 < wb) __builtin_memcpy(&v[k], sp + k * 4, 4);
+#pragma unroll
+          for (int k = 0; k < 12; k++) {
+            if (k * 4 + 4 <= wb) __builtin_memcpy(dp + k * 4, &v[k], 4);
+            else if (k * 4 < wb)
+              for (int q = 0; q < wb - k * 4; q++) dp[k * 4 + q] = (u8)(v[k] >> (8 * q));
+          }
+        }
+      }
     }
-    const int t = (int)rfl((u32)bts[b]);
-    if (!t) continue;
+    njobs = 0;
+    wave_fence();
+  };
+  for (int gbase = 0; gbase < nblocks && !D.bad; gbase += 64) {
+   const u32 tb = gbase + lane < nblocks ? bts[gbase + lane] : 0u;
+   u64 bm = __ballot(tb != 0);
+   while (bm && !D.bad) {
+    const int bj = __builtin_ctzll(bm);
+    bm &= bm - 1;
+    const int b = gbase + bj;
+    const int t = (int)rdl(tb, bj);
+    const int by = b / nbx, bx = b - by * nbx;
     int x1 = bx * 16, y1 = by * 16, x2 = min(x1 + 16, W), y2 = min(y1 + 16, H);
     if ((t - 1) & 1) {  // changed rect inside the block (:1333-1346)
       D.tick();
@@ -914,16 +957,11 @@ __device__ __forceinline__ void decode_inter_frame(WaveDec& D, const Geom& g, u8
         D.bad = true;
         break;
       }
-      for (int i = lane; i < w * h; i += 64) {
-        const int yy = i / w, xq = i - yy * w;
-        const u8* sp = prv + (size_t)(y1 + yy + my) * S + (x1 + xq + mx) * 3;
-        u8* dp = cur + (size_t)(y1 + yy) * S + (x1 + xq) * 3;
-        dp[0] = sp[0];
-        dp[1] = sp[1];
-        dp[2] = sp[2];
-      }
+      if (lane == 0) jobs[njobs] = make_uint2((u32)x1 | ((u32)y1 << 13) | ((u32)(w - 1) << 26), (u32)(h - 1) | ((u32)(mx + 512) << 4) | ((u32)(my + 512) << 14));
+      if (++njobs == 256) flush_jobs();
       continue;
     }
+    if (njobs) flush_jobs();  // a copied block may be this rect's left/top context
     // pixel-coded rect (:1370-1421): context border from the plane, then runs inside the tile
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores to the plane have reached L2
     for (int i = lane; i < 17 * 17; i += 64) {
@@ -1012,7 +1050,9 @@ __device__ __forceinline__ void decode_inter_frame(WaveDec& D, const Geom& g, u8
       dp[1] = (u8)(v >> 8);
       dp[2] = (u8)(v >> 16);
     }
+   }
   }
+  if (njobs) flush_jobs();
 }
 
 template <bool HAS_P>
