@@ -61,23 +61,40 @@ __device__ __forceinline__ u64 lanemask_lt() { return (1ull << lane_id()) - 1ull
 // ------------------------------------------------------------------ pack ---
 // RGB32 -> RGB24 plane (alpha dropped), 4 pixels (16 B in, 12 B out) per lane.
 // flat[f] is set when any pixel differs from pixel 0; first[f] = pixel 0.
-__global__ __launch_bounds__(256) void k_pack32(const u8* __restrict__ src, u8* __restrict__ planes, Geom g, u32* flat, u32* first) {
-  const int f = blockIdx.y, G = (g.W + 3) >> 2;
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= g.H * G) return;
+__device__ __forceinline__ bool pack32_item(const u8* __restrict__ src, u8* __restrict__ planes, const Geom& g, int f, int idx, int G, u32* first) {
   const int y = idx / G, gx = idx - y * G;
   const u32* s = (const u32*)(src + (size_t)f * g.W * g.H * 4 + (size_t)y * g.W * 4) + gx * 4;
   const u32 px0 = *(const u32*)(src + (size_t)f * g.W * g.H * 4) & 0xFFFFFFu;
   const int nv = min(4, g.W - gx * 4);
-  u32 a = s[0] & 0xFFFFFFu, b = nv > 1 ? s[1] & 0xFFFFFFu : 0, c = nv > 2 ? s[2] & 0xFFFFFFu : 0, d = nv > 3 ? s[3] & 0xFFFFFFu : 0;
-  bool diff = a != px0 || (nv > 1 && b != px0) || (nv > 2 && c != px0) || (nv > 3 && d != px0);
-  if (diff && flat[f] == 0) atomicOr(&flat[f], 1u);
+  u32 a, b, c, d;
+  if ((g.W & 3) == 0) {  // rows are 16-byte aligned: one 16-byte load per lane, 1 KiB per wave instruction
+    const uint4 v = *(const uint4*)s;
+    a = v.x & 0xFFFFFFu;
+    b = v.y & 0xFFFFFFu;
+    c = v.z & 0xFFFFFFu;
+    d = v.w & 0xFFFFFFu;
+  } else {
+    a = s[0] & 0xFFFFFFu;
+    b = nv > 1 ? s[1] & 0xFFFFFFu : 0;
+    c = nv > 2 ? s[2] & 0xFFFFFFu : 0;
+    d = nv > 3 ? s[3] & 0xFFFFFFu : 0;
+  }
+  const bool diff = a != px0 || (nv > 1 && b != px0) || (nv > 2 && c != px0) || (nv > 3 && d != px0);
   if (idx == 0) first[f] = px0;
   u32* o = (u32*)(planes + (size_t)f * g.plane_stride + (size_t)y * g.S) + gx * 3;
   const int room = g.S - gx * 12;  // bytes left in the row: 4, 8 or >= 12
   o[0] = a | (b << 24);
   if (room > 4) o[1] = (b >> 8) | (c << 16);
   if (room > 8) o[2] = (c >> 16) | (d << 8);
+  return diff;
+}
+__global__ __launch_bounds__(256) void k_pack32(const u8* __restrict__ src, u8* __restrict__ planes, Geom g, u32* flat, u32* first) {
+  const int f = blockIdx.y, G = (g.W + 3) >> 2;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  bool diff = false;
+  if (idx < g.H * G) diff = pack32_item(src, planes, g, f, idx, G, first);
+  // flat detection: one relaxed L2 read and at most one atomic per wave
+  if (__ballot(diff) && lane_id() == 0 && __hip_atomic_load(&flat[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) atomicOr(&flat[f], 1u);
 }
 
 // RGB24 rows (pitch = S) -> plane copy with zeroed row padding
@@ -724,27 +741,28 @@ struct RansBlock {
 // One lane per block of <= 131072 entries, processed last to first; bytes are
 // written backwards into the block's scratch (ransmt.h:116-134).  x / freq uses
 // the exact 32-bit reciprocal (rans_byte.h:171-240).
-__device__ __forceinline__ void rans_put(u32& x, u8*& p, u32 v, const RansRcp* rcp) {
+// One coder entry, loop-free: the renormalisation emits at most two bytes (x < 2^31 and
+// x_max = freq << 19 >= 2^19), so both the count and the bytes follow from two compares.
+// `r` is the reciprocal of the entry's frequency (fetched ahead of the dependent chain).
+__device__ __forceinline__ void rans_put(u32& x, u8*& p, u32 v, const RansRcp r) {
   const u32 fr = v & 0xFFFF, cf = v >> 16;
-  if (fr) {
-    const u32 x_max = fr << 19;  // ((L >> 12) << 8) * freq
-    while (x >= x_max) {
-      *--p = (u8)x;
-      x >>= 8;
-    }
-    const RansRcp r = rcp[fr];
-    const u32 q = fr == 1 ? x : (__umulhi(x, r.rcp) >> r.shift);
-    x = (q << kProbBits) + (x - q * fr) + cf;
-  } else {
-    *--p = (u8)cf;
-  }
+  const bool coded = fr != 0;
+  const u32 f1 = coded ? fr : 1u;
+  const u32 x_max = f1 << 19;  // ((L >> 12) << 8) * freq
+  const int n = coded ? (int)(x >= x_max) + (int)((x >> 8) >= x_max) : 0;
+  if (n >= 1) p[-1] = (u8)x;
+  if (n == 2) p[-2] = (u8)(x >> 8);
+  if (!coded) p[-1] = (u8)cf;  // raw byte (ransmt.h:128)
+  p -= coded ? n : 1;
+  const u32 xs = x >> (8 * n);
+  const u32 q = f1 == 1 ? xs : (__umulhi(xs, r.rcp) >> r.shift);
+  x = coded ? (q << kProbBits) + (xs - q * f1) + cf : x;
 }
 __global__ __launch_bounds__(64) void k_rans(const u32* __restrict__ entries, const RansBlock* __restrict__ blocks, int nblocks, const RansRcp* __restrict__ rcp_g,
                                              u8* __restrict__ scratch, u32* __restrict__ blksize) {
   __shared__ RansRcp lrcp[kProbScale + 1];  // reciprocals in LDS: the lookup is off the HBM path
   for (int i = threadIdx.x; i <= kProbScale; i += 64) lrcp[i] = rcp_g[i];
   __syncthreads();
-  const RansRcp* rcp = lrcp;
   const int b = blockIdx.x * 64 + threadIdx.x;
   if (b >= nblocks) return;
   const RansBlock blk = blocks[b];
@@ -753,16 +771,23 @@ __global__ __launch_bounds__(64) void k_rans(const u32* __restrict__ entries, co
   u32 x = kRansL;
   const u32* e = entries + blk.begin;
   int i = (int)blk.len;
-  for (int r = i & 15; r > 0; r--) rans_put(x, p, e[--i], rcp);  // ragged top
-  while (i > 0) {  // 16 entries per trip: the loads do not depend on the coder state
-    i -= 16;
-    u32 v[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) v[k] = e[i + k];
-#pragma unroll
-    for (int k = 15; k >= 0; k--) rans_put(x, p, v[k], rcp);
+  for (int r = i & 15; r > 0; r--) {  // ragged top
+    const u32 v = e[--i];
+    rans_put(x, p, v, lrcp[(v & 0xFFFF) ? (v & 0xFFFF) : 1]);
   }
-  p -= 4;
+  while (i > 0) {  // 16 entries per trip: neither the entry loads nor the reciprocal lookups depend on the coder state
+    i -= 16;
+    uint4 v4[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) __builtin_memcpy(&v4[k], e + i + 4 * k, 16);
+    const u32 v[16] = {v4[0].x, v4[0].y, v4[0].z, v4[0].w, v4[1].x, v4[1].y, v4[1].z, v4[1].w, v4[2].x, v4[2].y, v4[2].z, v4[2].w, v4[3].x, v4[3].y, v4[3].z, v4[3].w};
+    RansRcp r[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) r[k] = lrcp[(v[k] & 0xFFFF) ? (v[k] & 0xFFFF) : 1];
+#pragma unroll
+    for (int k = 15; k >= 0; k--) rans_put(x, p, v[k], r[k]);
+  }
+  p -= 4;  // RansEncFlush, rans_byte.h:90-102
   p[0] = (u8)x;
   p[1] = (u8)(x >> 8);
   p[2] = (u8)(x >> 16);

@@ -187,3 +187,26 @@ def test_p_frames_batch_api_1080p():
     r2, o2 = dec.DecompressBatch(pk[sum(sizes[:3]):].contiguous(), sizes[3:], fts[3:])
     assert r1 == 3 and r2 == n - 3
     assert torch.equal(torch.cat([o1, o2]).reshape(n, -1), d)
+
+
+def test_4k_key_and_p_frames():
+    """BASELINE configs[3] frame size: 3840x2160 (32400 blocks, 32 KiB pixel ring in the decoder)"""
+    w, h = 3840, 2160
+    seq = DesktopSequence(w, h, seed=2)
+    _encode_sequence_both([seq.frame(t) for t in range(3)], w, h)
+
+
+def test_rgb16_and_loss_per_frame_api():
+    w, h = 100, 37
+    rng = np.random.default_rng(8)
+    px = rng.integers(0, 1 << 15, (h, w), dtype=np.uint16)
+    px[:, : w // 2] = 0x1234
+    pitch = (w * 2 + 3) & ~3
+    f = np.zeros((h, pitch), np.uint8)
+    f[:, : w * 2] = px.view(np.uint8).reshape(h, w * 2)
+    gpu = _codec(w, h, 16)
+    want, _ = O.OracleCodec(w, h, 16).compress(f, key=True)
+    got, ft = gpu.CompressFrame(f, 0)
+    assert got == want
+    r, out = _codec(w, h, 16).DecompressFrame(got, ft)
+    assert r == 1 and np.array_equal(out.reshape(h, pitch)[:, : w * 2], f[:, : w * 2])
