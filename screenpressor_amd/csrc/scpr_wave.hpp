@@ -12,7 +12,7 @@
 //     write-back to HBM); small tables use one lane per symbol and a 16-lane
 //     scan (SmallContext, :155-290); dense tables use four symbols per lane
 //     (Cx6/Cx7, :377-998);
-//   * the input bytes come through an LDS ring that is refilled 1 KiB ahead;
+//   * the input bytes are fetched with wave-uniform (scalar) loads, one word ahead of use;
 //   * runs are written by all lanes at once; the gradient predictor is a wave
 //     prefix sum of (top - topleft) deltas.
 #pragma once
@@ -51,7 +51,6 @@ __device__ __forceinline__ int shift_for(int tot) {  // number of doublings unti
   return max(0, __builtin_clz((u32)(tot - 1)) - 20);
 }
 
-constexpr int WIN = 4096;     // input ring, bytes
 constexpr int CACHE_N = 256;  // colour records cached in LDS
 
 struct FixedBlob {      // every fixed-alphabet model of the decoder: freq | cum << 16, counts, running totals
@@ -70,7 +69,6 @@ struct FixedBlob {      // every fixed-alphabet model of the decoder: freq | cum
   int ftot[24];        // totals: 0-5 run lengths, 6-11 pixel types, 12/13 mv, 14/15 index/length, 16-19 rect, 20 block type
 };
 struct __attribute__((aligned(16))) WaveLds {
-  u32 ring[WIN / 4];
   FixedBlob fx;
   u32 crec[CACHE_N][16];
   u16 ctag[CACHE_N];
@@ -406,11 +404,10 @@ struct WaveDec : WaveModel {
   // input stream
   const u8* src;
   const u8* src_end;
-  u32 rpos = 0, loaded = 0, issued = 0, pre = 0;  // pre: prefetched ring word, still per-lane (made uniform on use)
+  const u32* wbase = nullptr;  // 4-byte aligned base of the current packet
+  u32 wpos = 0, wmax = 0, nextw = 0;
   u64 buf = 0;
   int nb = 0;
-  bool have_pre = false;
-  uint4 pend;
   // coder
   u32 x = 0;
   int ndec = 0;
@@ -421,62 +418,33 @@ struct WaveDec : WaveModel {
   __device__ __forceinline__ WaveDec(WaveLds& l, const u8* s, const u8* e, ColState* gs, Arena a, int f0_) : WaveModel(l.tmp, a, f0_), L(l), src(s), src_end(e), gstates(gs) {}
 
   // ---------------------------------------------------------------- input ---
-  __device__ __forceinline__ uint4 load16(u32 off) {
-    const u8* p = src + off + 16 * lane;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (p + 16 <= src_end) {
-      __builtin_memcpy(&v, p, 16);
-    } else {
-      u32 w[4] = {0, 0, 0, 0};
-#pragma unroll
-      for (int i = 0; i < 16; i++)
-        if (p + i < src_end) w[i >> 2] |= (u32)p[i] << (8 * (i & 3));
-      v = make_uint4(w[0], w[1], w[2], w[3]);
-    }
-    return v;
+  // The packet bytes are read with wave-uniform 4-byte loads straight from the packet buffer
+  // (scalar cache), one word ahead of use, into a 64-bit shift buffer.
+  __device__ __forceinline__ u32 fetch_word(u32 i) {
+    const u32 m = i < wmax ? i : wmax;
+    return wbase[m];
   }
   __device__ __forceinline__ void stream_init(const u8* s) {  // decodeBegin, screencap.h:295-301
     wave_fence();
-    src = s;
-    rpos = 0;
-    buf = 0;
-    nb = 0;
-    have_pre = false;
+    const size_t a = (size_t)s;
+    wbase = (const u32*)(a & ~(size_t)3);
+    const u32 skip = (u32)(a & 3);
+    wmax = (u32)(((size_t)src_end - (a & ~(size_t)3)) >> 2);
+    wmax = wmax ? wmax - 1 : 0;
+    buf = (u64)(fetch_word(0) >> (8 * skip));
+    nb = 4 - (int)skip;
+    wpos = 1;
+    nextw = fetch_word(1);
     ndec = 0;
-    ((uint4*)L.ring)[lane] = load16(0);
-    ((uint4*)L.ring)[64 + lane] = load16(1024);
-    loaded = 2048;
-    pend = load16(2048);
-    issued = 3072;
-    __syncthreads();
     x = take_u32();
   }
-  // once per symbol: keep >= 1 KiB of input in LDS and one word prefetched
-  __device__ __forceinline__ void tick() {
-    wave_fence();
-    if (rpos + 1024 > loaded) {
-      ((uint4*)L.ring)[((loaded & (WIN - 1)) >> 4) + lane] = pend;
-      loaded += 1024;
-      pend = load16(issued);
-      issued += 1024;
-      wave_fence();
-    }
-    if (nb <= 4 && !have_pre) {
-      pre = L.ring[(rpos & (WIN - 1)) >> 2];  // consumed (and waited for) in need()
-      rpos += 4;
-      have_pre = true;
-    }
-  }
+  __device__ __forceinline__ void tick() {}
   __device__ __forceinline__ void need(int k) {
-    wave_fence();
     while (nb < k) {
-      if (!have_pre) {
-        pre = L.ring[(rpos & (WIN - 1)) >> 2];
-        rpos += 4;
-      }
-      buf |= (u64)rfl(pre) << (8 * nb);
+      buf |= (u64)nextw << (8 * nb);
       nb += 4;
-      have_pre = false;
+      wpos++;
+      nextw = fetch_word(wpos);
     }
   }
   __device__ __forceinline__ u32 take_byte() {
@@ -573,7 +541,10 @@ struct WaveDec : WaveModel {
     const int kk = PER > 1 ? (int)rdl((u32)k, own) : 0;
     const u32 s = rdl(sel, own);
     const int sym = own * PER + kk;
-    if (lane == own) __hip_atomic_fetch_add(&cnt[sym], (u32)kStepDense, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (lane == own) {
+      const u32 addr = (u32)(size_t)&cnt[sym];  // LDS offset = low 32 bits of the flat address
+      asm volatile("ds_add_u32 %0, %1" ::"v"(addr), "v"((u32)kStepDense) : "memory");
+    }
     wave_fence();
     int tot = (int)rfl((u32)tot0) + kStepDense;
     advance(s >> 16, s & 0xFFFF, v);
@@ -603,7 +574,8 @@ struct WaveDec : WaveModel {
     const int slot = (ctxid ^ (ctxid >> 7)) & (CACHE_N - 1);
     u32* r = L.crec[slot];
     const u32 tg = L.ctag[slot];
-    u32 a = r[0], b = r[1], c2 = r[2];
+    const uint4 hw = *(const uint4*)r;
+    u32 a = hw.x, b = hw.y, c2 = hw.z;
     u32 sy = lane < 16 ? ((const u8*)r)[16 + lane] : 0, fv = lane < 16 ? ((const u16*)r)[16 + lane] : 0;
     const int tag = (int)rfl(tg);
     if (tag != ctxid + 1) {
