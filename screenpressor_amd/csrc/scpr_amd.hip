@@ -748,8 +748,8 @@ int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* 
       HIPCHK(hipMemcpyAsync(c->decframes.p, fr.data(), fr.size() * sizeof(DecFrame), hipMemcpyHostToDevice, st));
       HIPCHK(hipMemcpyAsync(c->decgops.p, gops.data(), ng * sizeof(DecGop), hipMemcpyHostToDevice, st));
       Arena ar{c->arena.as<DenseTab>(), c->arena_top.as<u32>(), (u32)arena_cap, c->err.as<u32>()};
-      int ring = 4096;
-      while (ring < 2 * g.S + 1024) ring <<= 1;
+      int ring = 4096;  // bytes: 32-bit pixels, a power of two that holds two rows and a run
+      while (ring < 4 * (2 * g.W + 512)) ring <<= 1;
       const int nblocks = ((g.W + 15) / 16) * ((g.H + 15) / 16);
       const int dyn = ring + ((nblocks + 15) & ~15);
       bool has_p = false;

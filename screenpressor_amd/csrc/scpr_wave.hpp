@@ -27,6 +27,7 @@ namespace scpr {
 // forbids exactly that.
 __device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
 __device__ __forceinline__ u32 rfl(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ u64 rfl64(u64 v) { return (u64)rfl((u32)v) | ((u64)rfl((u32)(v >> 32)) << 32); }
 __device__ __forceinline__ u32 rdl(u32 v, int lane) { return (u32)__builtin_amdgcn_readlane((int)v, lane); }
 // inclusive scan inside each row of 16 lanes: four DPP row_shr adds (no LDS traffic)
 __device__ __forceinline__ int row_incl_scan(int v) {
@@ -422,14 +423,14 @@ struct WaveDec : WaveModel {
   // (scalar cache), one word ahead of use, into a 64-bit shift buffer.
   __device__ __forceinline__ u32 fetch_word(u32 i) {
     const u32 m = i < wmax ? i : wmax;
-    return wbase[m];
+    return rfl(wbase[m]);
   }
   __device__ __forceinline__ void stream_init(const u8* s) {  // decodeBegin, screencap.h:295-301
     wave_fence();
-    const size_t a = (size_t)s;
+    const size_t a = (size_t)rfl64((u64)(size_t)s);  // wave-uniform: keeps the whole stream state in scalar registers
     wbase = (const u32*)(a & ~(size_t)3);
     const u32 skip = (u32)(a & 3);
-    wmax = (u32)(((size_t)src_end - (a & ~(size_t)3)) >> 2);
+    wmax = (u32)(((size_t)rfl64((u64)(size_t)src_end) - (a & ~(size_t)3)) >> 2);
     wmax = wmax ? wmax - 1 : 0;
     buf = (u64)(fetch_word(0) >> (8 * skip));
     nb = 4 - (int)skip;
@@ -656,15 +657,16 @@ __device__ __forceinline__ u32 ld3_l2(const u8* p) {
   return v & 0xFFFFFFu;
 }
 
-// Key frame (DecompressI, screencap.cpp:414-498).  Decoded pixels go to an LDS ring that always
-// holds the last two rows (the predictors read "previous", "top" and "top-left" from it) and every
-// finished row is flushed to HBM with wide stores; the plane in HBM is never read back.
-__device__ __forceinline__ void decode_intra_frame(WaveDec& D, const Geom& g, u8* __restrict__ dst, u8* pix, int ring_bytes) {
+// Key frame (DecompressI, screencap.cpp:414-498).  Decoded pixels go to an LDS ring of 32-bit
+// pixels indexed by raster position (it always holds the last two rows: the predictors read
+// "previous", "top" and "top-left" from it); every finished row is packed to RGB24 and flushed
+// to HBM four pixels per lane.  The plane in HBM is never read back.
+__device__ __forceinline__ void decode_intra_frame(WaveDec& D, const Geom& g, u8* __restrict__ dst, u32* ring, int ring_pixels) {
   const int lane = D.lane;
-  const u32 pmask = (u32)ring_bytes - 1u;
-  const int W = g.W, H = g.H, S = g.S;
+  const u32 pm = (u32)ring_pixels - 1u;
+  const int W = g.W, H = g.H, S = g.S, NP = g.NP;
+  const int pad = S - 3 * W;  // 0..3 zero bytes after each row
   const int chunk = W < 64 ? W : 64;
-  auto ctx_c0 = [&](u32 lp) __attribute__((always_inline)) { return (int)(((lp >> 18) & 63) | (((lp >> 10) & 63) << 6)); };  // (b>>2) | (g>>2)<<6
   auto get_rgb = [&](u32 lp) __attribute__((always_inline)) -> u32 {  // DecodeRGB, screencap.cpp:662-679
     // contexts: two previous bytes >> 2 (MAKECX1, screencap.h:35-36); one code copy for the three planes
     u32 a = (lp >> 18) & 63, b = (lp >> 10) & 63, px = 0;
@@ -677,122 +679,88 @@ __device__ __forceinline__ void decode_intra_frame(WaveDec& D, const Geom& g, u8
     }
     return px;
   };
-  auto put3 = [&](u32 i, u32 v) __attribute__((always_inline)) {
-    pix[i & pmask] = (u8)v;
-    pix[(i + 1) & pmask] = (u8)(v >> 8);
-    pix[(i + 2) & pmask] = (u8)(v >> 16);
-  };
-  // pixel (xq, yq); the last pixel of a row also clears the row padding, which the
-  // top-left predictor of the row after next reads (screencap.cpp:881, DecompressFrame :1524-1528)
-  auto put_px = [&](int xq, int yq, u32 v) __attribute__((always_inline)) {
-    const u32 i = (u32)(yq * S + xq * 3);
-    put3(i, v);
-    if (xq == W - 1)
-      for (int q = W * 3; q < S; q++) pix[((u32)(yq * S + q)) & pmask] = 0;
-  };
-  auto get3 = [&](u32 i) __attribute__((always_inline)) -> u32 { return (u32)pix[i & pmask] | ((u32)pix[(i + 1) & pmask] << 8) | ((u32)pix[(i + 2) & pmask] << 16); };
-  // rows [flushed, to) are complete in the ring: copy them to the plane
+  // rows [flushed, to) are complete in the ring: pack them to RGB24 and store them (row padding = 0)
   int flushed = 0;
   auto flush_rows = [&](int to) __attribute__((always_inline)) {
     wave_fence();
     for (; flushed < to; flushed++) {
-      const u32 rb = (u32)flushed * (u32)S;
-      const int pad0 = W * 3;
-      if (((S | ring_bytes) & 15) == 0 && (rb & 15) == 0) {
-        for (int o = lane * 16; o < S; o += 1024) {
-          uint4 v = *(const uint4*)(pix + ((rb + o) & pmask));
-          if (o + 16 > pad0) {  // zero the padding bytes of the last vector
-            u32 w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-              const int keep = pad0 - (o + 4 * q);
-              if (keep <= 0) w[q] = 0;
-              else if (keep < 4) w[q] &= (1u << (8 * keep)) - 1u;
-            }
-            v = make_uint4(w[0], w[1], w[2], w[3]);
-          }
-          *(uint4*)(dst + rb + o) = v;
-        }
-      } else {
-        for (int o = lane * 4; o < S; o += 256) {
-          u32 v = *(const u32*)(pix + ((rb + o) & pmask));
-          if (o + 4 > pad0) v &= (o >= pad0) ? 0u : ((1u << (8 * (pad0 - o))) - 1u);
-          *(u32*)(dst + rb + o) = v;
-        }
+      const u32 p0 = (u32)flushed * (u32)W;
+      u8* row = dst + (size_t)flushed * S;
+      for (int gq = lane; gq * 4 < W; gq += 64) {
+        const u32 q = p0 + 4u * gq;
+        const int nv = min(4, W - 4 * gq);
+        const u32 a = ring[q & pm], b = nv > 1 ? ring[(q + 1) & pm] : 0u, c = nv > 2 ? ring[(q + 2) & pm] : 0u, d = nv > 3 ? ring[(q + 3) & pm] : 0u;
+        u32* o = (u32*)row + gq * 3;
+        const int room = S - gq * 12;
+        o[0] = a | (b << 24);
+        if (room > 4) o[1] = (b >> 8) | (c << 16);
+        if (room > 8) o[2] = (c >> 16) | (d << 8);
       }
     }
   };
 
   u32 lastpix = 0;  // last decoded pixel; 0 gives context 0 for the first pixel (cx = cx1 = 0, :419)
   // One loop for both phases so that every model routine is instantiated once:
-  //   header phase (k < W+1): literal + run length over the first row and pixel (0,1)  (:421-438)
+  //   header phase (p <= W): literal + run length over the first row and pixel (0,1)  (:421-438)
   //   body: pixel type, literal if type 0, run length                                  (:443-494)
-  int k = 0, xx = 0, y = 0, t = 0;
-  while (y < H && !D.bad) {
-    const bool hdr = k < W + 1;
-    if (!hdr) {
-      D.tick();
-      t = D.fixed_p(t);
-    }
+  int p = 0, xx = 0, t = 0;  // next pixel (raster index) and its column
+  while (p < NP && !D.bad) {
+    const bool hdr = p < W + 1;
+    if (!hdr) t = D.fixed_p(t);
     u32 px = lastpix;
     if (hdr || t == 0) px = get_rgb(lastpix);
-    D.tick();
     const int n = D.fixed_n(hdr ? 0 : t);
-    if (n < 1 || t == 3 || (long long)y * W + xx + n > (long long)H * W || (hdr && k + n > W + 1)) {
+    if (n < 1 || t == 3 || p + n > NP || (hdr && p + n > W + 1)) {
       D.bad = true;
       break;
     }
-    if (hdr) k += n;
     if (hdr || t <= 1) {  // literal, or copy of the previous pixel: every pixel of the run has the same value
-      for (int q = lane; q < n; q += 64) {
-        int xq = xx + q, yq = y;
-        while (xq >= W) {
-          xq -= W;
-          yq++;
-        }
-        put_px(xq, yq, px);
-      }
+      for (int q = lane; q < n; q += 64) ring[(u32)(p + q) & pm] = px;
       lastpix = px;
     } else {
       for (int q0 = 0; q0 < n; q0 += chunk) {
         wave_fence();  // pixels written by other lanes are read below
         const int m = min(chunk, n - q0);
-        int xq = xx + q0 + lane, yq = y;
-        while (xq >= W) {
-          xq -= W;
-          yq++;
-        }
         const bool act = lane < m;
-        const u32 i = (u32)(yq * S + xq * 3);
+        const u32 pq = (u32)(p + q0 + lane);
+        int xq = xx + q0 + lane;
+        while (xq >= W) xq -= W;
         u32 v = 0;
         if (t == 2) {
-          if (act) v = get3(i - S);
-        } else if (t == 5) {
-          if (act) v = get3(i - S - 3);
-        } else {  // gradient: previous + top - topleft, a running sum along the run (mod 256 per channel)
-          u32 tp = 0, tl = 0;
+          if (act) v = ring[(pq - W) & pm];
+        } else {
+          // top-left; in column 0 it is the bytes just before the row above in memory: the tail of the
+          // last pixel two rows up followed by that row's padding (screencap.cpp:881)
+          u32 tl = 0;
           if (act) {
-            tp = get3(i - S);
-            tl = get3(i - S - 3);
+            tl = ring[(pq - W - 1) & pm];
+            if (xq == 0) tl >>= 8 * pad;
           }
-          int d0 = (int)(tp & 255) - (int)(tl & 255), d1 = (int)((tp >> 8) & 255) - (int)((tl >> 8) & 255), d2 = (int)((tp >> 16) & 255) - (int)((tl >> 16) & 255);
-          if (!act) d0 = d1 = d2 = 0;
-          d0 = wave_incl_scan(d0);
-          d1 = wave_incl_scan(d1);
-          d2 = wave_incl_scan(d2);
-          v = (u32)(((int)(lastpix & 255) + d0) & 255) | ((u32)(((int)((lastpix >> 8) & 255) + d1) & 255) << 8) | ((u32)(((int)((lastpix >> 16) & 255) + d2) & 255) << 16);
+          if (t == 5) {
+            v = tl;
+          } else {  // gradient: previous + top - topleft, a running sum along the run (mod 256 per channel)
+            const u32 tp = act ? ring[(pq - W) & pm] : 0u;
+            int d0 = (int)(tp & 255) - (int)(tl & 255), d1 = (int)((tp >> 8) & 255) - (int)((tl >> 8) & 255), d2 = (int)((tp >> 16) & 255) - (int)((tl >> 16) & 255);
+            if (!act) d0 = d1 = d2 = 0;
+            d0 = wave_incl_scan(d0);
+            d1 = wave_incl_scan(d1);
+            d2 = wave_incl_scan(d2);
+            v = (u32)(((int)(lastpix & 255) + d0) & 255) | ((u32)(((int)((lastpix >> 8) & 255) + d1) & 255) << 8) | ((u32)(((int)((lastpix >> 16) & 255) + d2) & 255) << 16);
+          }
         }
-        if (act) put_px(xq, yq, v);
+        if (act) ring[pq & pm] = v;
         wave_fence();
         lastpix = rdl(v, m - 1);
       }
     }
+    p += n;
     xx += n;
-    while (xx >= W) {
-      xx -= W;
-      y++;
+    while (xx >= W) xx -= W;
+    if ((flushed + 1) * W <= p) {
+      int done = flushed + 1;
+      while ((done + 1) * W <= p) done++;
+      flush_rows(done);
     }
-    if (flushed < y) flush_rows(y);
   }
   if (!D.bad) flush_rows(H);
 }
@@ -1032,7 +1000,7 @@ __global__ __launch_bounds__(64) void k_decode_gop_w(const u8* __restrict__ pack
                                                      u8* __restrict__ planes, Geom g, ColState* __restrict__ states, Arena arena, int f0, u32* __restrict__ status, int ring_bytes,
                                                      FixedBlob* __restrict__ fixedstore, int far_x, int far_y) {
   __shared__ WaveLds L;
-  extern __shared__ __align__(16) u8 pix[];  // ring_bytes (power of two >= 2*S + 1024), then one byte per 16x16 block
+  extern __shared__ __align__(16) u8 pix[];  // ring_bytes = 4 * (power of two >= 2*W + 512) pixels, then one byte per 16x16 block
   const DecGop gop = gops[blockIdx.x];
   const int lane = lane_id();
   for (int i = lane; i < CACHE_N; i += 64) L.ctag[i] = 0;
@@ -1052,7 +1020,7 @@ __global__ __launch_bounds__(64) void k_decode_gop_w(const u8* __restrict__ pack
       D.fixed_init();  // RenewI (:418); the colour records of the GOP start cleared
       wave_fence();
       D.stream_init(packets + fr.src_off + 1);
-      decode_intra_frame(D, g, dst, pix, ring_bytes);
+      decode_intra_frame(D, g, dst, (u32*)pix, ring_bytes >> 2);
     } else if (HAS_P && fr.kind == 2) {
       decode_inter_frame(D, g, dst, planes + (size_t)fr.prev_slot * g.plane_stride, packets + fr.src_off, pix + ring_bytes, far_x, far_y);
     }
