@@ -406,7 +406,7 @@ static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int n
   HIPCHK(hipMemcpyAsync(c->ranges.p, rg.data(), ngens * sizeof(GenRange), hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(c->miscranges.p, mr.data(), ngens * sizeof(MiscRange), hipMemcpyHostToDevice, st));
   stage_begin(c, ST_FIXED);
-  hipLaunchKernelGGL(k_fixed_chain, dim3(NFIXED_I, ngens), dim3(64), 0, st, c->runs.as<u32>(), c->runpos.as<u32>(), c->ranges.as<GenRange>(), ngens, load_first ? 1 : 0,
+  hipLaunchKernelGGL(k_fixed_chain, dim3(ngens), dim3(768), 0, st, c->runs.as<u32>(), c->runpos.as<u32>(), c->ranges.as<GenRange>(), ngens, load_first ? 1 : 0,
                      c->fixed_persist.as<FixedPersist>(), c->entries.as<u32>());
   if (Mtot)
     hipLaunchKernelGGL(k_misc_chain, dim3(MC_COUNT, ngens), dim3(64), 0, st, c->misc.as<u32>(), c->miscpos.as<u32>(), c->miscranges.as<MiscRange>(), ngens, load_first ? 1 : 0,
@@ -423,7 +423,7 @@ static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int n
     HIPCHK(c->chainlists.reserve((size_t)cap * 8 + 64));
     HIPCHK(c->chaincounts.reserve(16));
     HIPCHK(hipMemsetAsync(c->chaincounts.p, 0, 8, st));
-    hipLaunchKernelGGL(k_chain_lists, dim3((unsigned)((nchains + 255) / 256)), dim3(256), 0, st, c->cstart.as<u32>(), (int)nchains, 192u, c->chainlists.as<u32>(), cap,
+    hipLaunchKernelGGL(k_chain_lists, dim3((unsigned)((nchains + 1023) / 1024)), dim3(1024), 0, st, c->cstart.as<u32>(), (int)nchains, 192u, c->chainlists.as<u32>(), cap,
                        c->chaincounts.as<u32>());
     for (int which = 0; which < 2; which++) {  // long chains first
       const unsigned grid = (unsigned)std::min<u32>(cap, which == 0 ? 16384u : 32768u);
@@ -748,12 +748,15 @@ int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* 
       HIPCHK(hipMemcpyAsync(c->decframes.p, fr.data(), fr.size() * sizeof(DecFrame), hipMemcpyHostToDevice, st));
       HIPCHK(hipMemcpyAsync(c->decgops.p, gops.data(), ng * sizeof(DecGop), hipMemcpyHostToDevice, st));
       Arena ar{c->arena.as<DenseTab>(), c->arena_top.as<u32>(), (u32)arena_cap, c->err.as<u32>()};
-      int ring = 4096;  // bytes: 32-bit pixels, a power of two that holds two rows and a run
-      while (ring < 4 * (2 * g.W + 512)) ring <<= 1;
+      // LDS ring of 32-bit pixels: the predictors look back one row + 1 pixel, a finished row is flushed at most
+      // one run after it ends, and a run writes up to 255 pixels ahead: a power of two >= W + 512 pixels.
+      // (Keeping static + dynamic LDS under 64 KiB lets two GOPs share a CU.)
+      int ring = 4096;
+      while (ring < 4 * (g.W + 512)) ring <<= 1;
       const int nblocks = ((g.W + 15) / 16) * ((g.H + 15) / 16);
-      const int dyn = ring + ((nblocks + 15) & ~15);
       bool has_p = false;
       for (const DecFrame& d : fr) has_p |= d.kind == 2;
+      const int dyn = ring + (has_p ? ((nblocks + 15) & ~15) : 0);  // + one byte per block for P-frames
       auto kern = has_p ? k_decode_gop_w<true> : k_decode_gop_w<false>;  // key-frame-only GOPs: smaller kernel (instruction cache)
       HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
       hipLaunchKernelGGL(kern, dim3((unsigned)ng), dim3(64), dyn, st, (const u8*)d_packets, (const u8*)d_packets + offs[nframes] + 8, c->decframes.as<DecFrame>(),

@@ -602,10 +602,16 @@ struct FixedPersist {  // one fixed-alphabet table as kept between calls (P-fram
   u32 freq[512], cum[512], cnt[512];
   int total, valid, pad0, pad1;
 };
-__global__ __launch_bounds__(64) void k_fixed_chain(const u32* __restrict__ runs, const u32* __restrict__ runpos, const GenRange* __restrict__ ranges, int ngens, int load_first,
-                                                    FixedPersist* __restrict__ persist /* [12] */, u32* __restrict__ entries) {
-  __shared__ u32 freq[256], cum[256], cnt[256];
-  const int cls = blockIdx.x, gen = blockIdx.y, lane = threadIdx.x;
+__global__ __launch_bounds__(768) void k_fixed_chain(const u32* __restrict__ runs, const u32* __restrict__ runpos, const GenRange* __restrict__ ranges, int ngens, int load_first,
+                                                     FixedPersist* __restrict__ persist /* [12] */, u32* __restrict__ entries) {
+  // One workgroup per generation, one wave per model (cls 0..5 pixel types, 6..11 run lengths): the
+  // twelve waves walk the same run list, so it is fetched into this CU's L1 once.  Each wave owns its
+  // table; lanes of a wave talk through LDS in program order (wavefront fences only, no barriers).
+  __shared__ u32 tab[12][3][256];
+  const int cls = threadIdx.x >> 6, gen = blockIdx.x, lane = threadIdx.x & 63;
+  u32* freq = tab[cls][0];
+  u32* cum = tab[cls][1];
+  u32* cnt = tab[cls][2];
   const bool is_n = cls >= 6;
   const int key = is_n ? cls - 6 : cls, nsym = is_n ? 256 : 6;
   int total;
@@ -625,7 +631,7 @@ __global__ __launch_bounds__(64) void k_fixed_chain(const u32* __restrict__ runs
     }
     total = c0 * nsym;
   }
-  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   const GenRange rg = ranges[gen];
   for (u32 base = rg.run_begin; base < rg.run_end; base += 64) {
     const u32 i = base + lane;
@@ -657,7 +663,7 @@ __global__ __launch_bounds__(64) void k_fixed_chain(const u32* __restrict__ runs
       }
       total += kStepDense * take;
       done += take;
-      __syncthreads();
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       if (take == room) {  // counts become the frequencies (incrCnt, ans_contexts.h:1075-1090)
         const int per = (nsym + 63) >> 6, j0 = lane * per;
         int s = 0;
@@ -681,12 +687,12 @@ __global__ __launch_bounds__(64) void k_fixed_chain(const u32* __restrict__ runs
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) ns += __shfl_xor(ns, d);
         total = ns;
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       }
     }
   }
   if (gen == ngens - 1) {  // the last generation of the call is the live one
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     for (int j = lane; j < nsym; j += 64) {
       persist[cls].freq[j] = freq[j];
       persist[cls].cum[j] = cum[j];

@@ -1000,7 +1000,7 @@ __global__ __launch_bounds__(64) void k_decode_gop_w(const u8* __restrict__ pack
                                                      u8* __restrict__ planes, Geom g, ColState* __restrict__ states, Arena arena, int f0, u32* __restrict__ status, int ring_bytes,
                                                      FixedBlob* __restrict__ fixedstore, int far_x, int far_y) {
   __shared__ WaveLds L;
-  extern __shared__ __align__(16) u8 pix[];  // ring_bytes = 4 * (power of two >= 2*W + 512) pixels, then one byte per 16x16 block
+  extern __shared__ __align__(16) u8 pix[];  // ring_bytes = 4 * (power of two >= W + 512) pixels, then (P-frames) one byte per 16x16 block
   const DecGop gop = gops[blockIdx.x];
   const int lane = lane_id();
   for (int i = lane; i < CACHE_N; i += 64) L.ctag[i] = 0;
@@ -1037,14 +1037,23 @@ __global__ __launch_bounds__(64) void k_decode_gop_w(const u8* __restrict__ pack
 
 // ------------------------------------------------------------- encoder chains ---
 // Non-empty colour chains, split by length so that the long ones start first.
-__global__ __launch_bounds__(256) void k_chain_lists(const u32* __restrict__ cstart, int nchains, u32 thresh, u32* __restrict__ lists, u32 cap, u32* __restrict__ counts) {
-  const int q = blockIdx.x * 256 + threadIdx.x;
-  if (q >= nchains) return;
-  const u32 len = cstart[q + 1] - cstart[q];
-  if (!len) return;
+__global__ __launch_bounds__(1024) void k_chain_lists(const u32* __restrict__ cstart, int nchains, u32 thresh, u32* __restrict__ lists, u32 cap, u32* __restrict__ counts) {
+  __shared__ u32 cnt[2], base[2];
+  const int q = blockIdx.x * 1024 + threadIdx.x;
+  if (threadIdx.x < 2) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  u32 len = 0;
+  if (q < nchains) len = cstart[q + 1] - cstart[q];
   const int which = len >= thresh ? 0 : 1;
-  const u32 idx = atomicAdd(&counts[which], 1u);
-  if (idx < cap) lists[(size_t)which * cap + idx] = (u32)q;
+  u32 local = 0;
+  if (len) local = atomicAdd(&cnt[which], 1u);  // LDS: position inside this block's share
+  __syncthreads();
+  if (threadIdx.x < 2) base[threadIdx.x] = cnt[threadIdx.x] ? atomicAdd(&counts[threadIdx.x], cnt[threadIdx.x]) : 0u;  // one global atomic per list per block
+  __syncthreads();
+  if (len) {
+    const u32 idx = base[which] + local;
+    if (idx < cap) lists[(size_t)which * cap + idx] = (u32)q;
+  }
 }
 
 // One wave per colour chain (Context::encode over the symbols of one context in stream
