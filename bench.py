@@ -126,9 +126,23 @@ def main():
         alg_bytes = raw + comp_bytes if args.workload == "keys" else 2 * raw + comp_bytes  # P-frames also read the previous frame
         dom_ms = per_step[dom]
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
+        # HBM bytes per launch of that kernel from the PMC passes recorded under profiles/ (rocprofv3 --pmc
+        # FETCH_SIZE / WRITE_SIZE in separate runs of this same command, FETCH doubled for gfx950); only
+        # quoted when the recorded run used this workload
+        traffic = None
+        kernel_of = {"decode": "k_decode_gop_w", "rans": "k_rans", "colour_chain": "k_colour_chain_w", "pack": "k_pack32"}
+        try:
+            rec = json.load(open(os.path.join(ROOT, "profiles", "r1d_pmc_hbm_traffic.json")))
+            if args.workload == "keys" and N == 300 and (W, H) == (1920, 1080):
+                for kq in rec["kernels"]:
+                    if kernel_of.get(dom, "?") in kq["kernel"]:
+                        traffic = round(kq["hbm_bytes_per_launch"])
+        except Exception:
+            traffic = None
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "launch_ms": round(dom_ms, 3),
-                    "algorithmic_bytes_per_launch": alg_bytes}
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "launch_ms": round(dom_ms, 3),
+                    "algorithmic_bytes_per_launch": alg_bytes,
+                    "note": "the dominant kernel is a serial per-GOP chain (issue-bound), not bandwidth-shaped; see DESIGN.md §5"}
         cpu = None
         if not args.no_cpu:
             import oracle_api as O
