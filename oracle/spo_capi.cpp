@@ -135,6 +135,12 @@ void spo_chain_fixed(int nsym, const uint16_t* syms, int n, uint16_t* out) {
 
 // ---- stand-alone rANS block (ransmt.h:116-134) ------------------------------
 // entries: n pairs (freq,cum); returns bytes written to out (cap >= 2n+4)
+void spo_kind_hist(uint64_t* out, int reset) {  // colour symbols seen per context kind since the last reset
+  for (int i = 0; i < 8; i++) {
+    out[i] = kind_hist()[i];
+    if (reset) kind_hist()[i] = 0;
+  }
+}
 int spo_rans_block(const uint16_t* entries, int n, uint8_t* out) {
   std::vector<uint8_t> tmp((size_t)2 * n + 8);
   uint8_t* end = tmp.data() + tmp.size();

@@ -607,6 +607,11 @@ struct DenseTab {
 };
 
 // ---------------------------------------------------------------------------
+// diagnostics: how many colour symbols met each kind on the encoder side (tests / design notes only)
+inline uint64_t* kind_hist() {
+  static uint64_t h[8];
+  return h;
+}
 // One colour context: the 7-kind state machine.
 // ans_contexts.h:98-150 (kinds 1-3), :1018-1051, ans_contexts.cpp:3-84
 // ---------------------------------------------------------------------------
@@ -757,6 +762,7 @@ struct ColourCtx {
 
   // Context::encode: false => symbol goes out raw.  ans_contexts.cpp:34-50
   bool encode(uint8_t c, Ivl& out, int f0) {
+    kind_hist()[kind]++;
     switch (kind) {
       case 0: case 1: case 2: case 3:
         note_raw(c, false, f0);

@@ -729,14 +729,14 @@ int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* 
     if (ng) {
       HIPCHK(c->decframes.reserve(fr.size() * sizeof(DecFrame)));
       HIPCHK(c->decgops.reserve(ng * sizeof(DecGop)));
-      HIPCHK(c->decstates.reserve(ng * NCOLCTX * sizeof(ColState)));
+      HIPCHK(c->decstates.reserve(ng * NCOLCTX * sizeof(DecRec)));
       HIPCHK(c->decfixed.reserve(ng * sizeof(FixedBlob)));
       HIPCHK(c->dec_fixed_persist.reserve(sizeof(FixedBlob)));
-      HIPCHK(c->dec_colour_persist.reserve((size_t)NCOLCTX * sizeof(ColState)));
-      HIPCHK(hipMemsetAsync(c->decstates.p, 0, ng * NCOLCTX * sizeof(ColState), st));  // kind 0 everywhere (RenewI)
+      HIPCHK(c->dec_colour_persist.reserve((size_t)NCOLCTX * sizeof(DecRec)));
+      HIPCHK(hipMemsetAsync(c->decstates.p, 0, ng * NCOLCTX * sizeof(DecRec), st));  // kind 0 everywhere (RenewI)
       const bool cont = gops[0].load != 0;
       if (cont) {  // the first GOP continues the state kept from the previous call
-        HIPCHK(hipMemcpyAsync(c->decstates.p, c->dec_colour_persist.p, (size_t)NCOLCTX * sizeof(ColState), hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync(c->decstates.p, c->dec_colour_persist.p, (size_t)NCOLCTX * sizeof(DecRec), hipMemcpyDeviceToDevice, st));
         HIPCHK(hipMemcpyAsync(c->decfixed.p, c->dec_fixed_persist.p, sizeof(FixedBlob), hipMemcpyDeviceToDevice, st));
       } else {
         c->arena_used_bound = 0;
@@ -760,10 +760,10 @@ int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* 
       auto kern = has_p ? k_decode_gop_w<true> : k_decode_gop_w<false>;  // key-frame-only GOPs: smaller kernel (instruction cache)
       HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
       hipLaunchKernelGGL(kern, dim3((unsigned)ng), dim3(64), dyn, st, (const u8*)d_packets, (const u8*)d_packets + offs[nframes] + 8, c->decframes.as<DecFrame>(),
-                         c->decgops.as<DecGop>(), c->planes.as<u8>(), g, c->decstates.as<ColState>(), ar, c->f0, c->err.as<u32>(), ring, c->decfixed.as<FixedBlob>(),
+                         c->decgops.as<DecGop>(), c->planes.as<u8>(), g, c->decstates.as<DecRec>(), ar, c->f0, c->err.as<u32>(), ring, c->decfixed.as<FixedBlob>(),
                          (int)std::min<u32>(c->prm.high_range_x, 256), (int)std::min<u32>(c->prm.high_range_y, 256));
       // keep the state of the last GOP and the last plane for the next call
-      HIPCHK(hipMemcpyAsync(c->dec_colour_persist.p, c->decstates.as<ColState>() + (ng - 1) * NCOLCTX, (size_t)NCOLCTX * sizeof(ColState), hipMemcpyDeviceToDevice, st));
+      HIPCHK(hipMemcpyAsync(c->dec_colour_persist.p, c->decstates.as<DecRec>() + (ng - 1) * NCOLCTX, (size_t)NCOLCTX * sizeof(DecRec), hipMemcpyDeviceToDevice, st));
       HIPCHK(hipMemcpyAsync(c->dec_fixed_persist.p, c->decfixed.as<FixedBlob>() + (ng - 1), sizeof(FixedBlob), hipMemcpyDeviceToDevice, st));
       c->dec_live = true;
     }
@@ -836,6 +836,15 @@ int scpr_last_timing(scpr_codec* c, float* total_ms, float* stage_ms, int cap) {
   return ST_COUNT;
 }
 
+#ifdef SCPR_PROFILE
+// design work only (libscpr_amd_prof.so): s_memtime ticks per decoder section summed over all GOPs since the last call
+extern "C" int scpr_debug_profile(unsigned long long* out) {
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(scpr::g_prof), sizeof z) != hipSuccess) return -1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(scpr::g_prof), z, sizeof z) != hipSuccess) return -1;
+  return 8;
+}
+#endif
 int scpr_debug_colour_chain(int device, const uint8_t* syms, int n, int f0, uint16_t* out) {
   if (hipSetDevice(device) != hipSuccess) return SCPR_E_DEVICE;
   std::vector<u32> keys(n), vals(n);

@@ -54,7 +54,7 @@ __device__ __forceinline__ int shift_for(int tot) {  // number of doublings unti
 
 constexpr int CACHE_N = 256;  // colour records cached in LDS
 
-struct FixedBlob {      // every fixed-alphabet model of the decoder: freq | cum << 16, counts, running totals
+struct FixedBlob {      // every fixed-alphabet model of the decoder (its image in HBM): freq | cum << 16, counts, running totals
   u32 nfc[6][256];     // run lengths, by pixel type (ntab)
   u32 ncnt[6][256];
   u32 mfc[2][512];     // motion vector components (mvtab)
@@ -69,10 +69,32 @@ struct FixedBlob {      // every fixed-alphabet model of the decoder: freq | cum
   u32 bcnt[8];
   int ftot[24];        // totals: 0-5 run lengths, 6-11 pixel types, 12/13 mv, 14/15 index/length, 16-19 rect, 20 block type
 };
+// A colour context as the decoder keeps it (LDS cache line and HBM backing store, 80 bytes):
+//   w[0..2] header (kind | maxpos << 8 | fshift << 16, d | total << 16, dense table index), w[3] cache tag,
+//   w[4..11] the 256-bit symbol set (kinds 1-3 and 6), or
+//   w[4 + i] small-table entry i (kinds 4/5), see SmallTab.
+struct DecRec {
+  u32 w[20];
+};
+constexpr int DECREC_WORDS = 20;
+// What of the fixed models sits in LDS while a wave decodes (the pixel-type tables live in registers).
+constexpr int NTAB_STRIDE = 320;  // words per run-length table: 256 entries, the running total, padding (three reads share one address)
+struct FixedLds {
+  u32 ntab[6][NTAB_STRIDE];
+  u32 ncnt[6][256];
+  u32 mfc[2][512];
+  u32 mcnt[2][512];
+  u32 xfc[2][256];
+  u32 xcnt[2][256];
+  u32 sfc[4][16];
+  u32 scnt[4][16];
+  u32 bfc[8];
+  u32 bcnt[8];
+  int ftot[24];        // same numbering as FixedBlob::ftot; 0-11 are unused here
+};
 struct __attribute__((aligned(16))) WaveLds {
-  FixedBlob fx;
-  u32 crec[CACHE_N][16];
-  u16 ctag[CACHE_N];
+  FixedLds fx;
+  u32 crec[CACHE_N][DECREC_WORDS];
   u16 tmp[256];
   u32 tile[17 * 17];   // P-frame block under reconstruction, with one row above and one column to the left
   uint2 jobs[256];     // deferred motion-block copies of the current P-frame
@@ -80,13 +102,26 @@ struct __attribute__((aligned(16))) WaveLds {
 
 // The colour model of one context, operated by a whole wave.  The header is
 // wave-uniform (scalar registers), a small table is one entry per lane (lanes
-// 0..15), the 256-bit symbol set lives in the 64-byte LDS record (words 4..11,
-// layout = ColState) and dense tables live in the HBM arena.  Shared by the
-// decoder (symbol from coder value) and the encoder chains (interval from symbol).
+// 0..15), the 256-bit symbol set lives in words 4..11 of the context's record
+// and dense tables live in the HBM arena.  Shared by the decoder (symbol from
+// coder value) and the encoder chains (interval from symbol).
 struct ColHdr {
-  int kind, maxpos, fshift, d, total;
+  int kind, maxpos, fshift, d, total;  // total: cached sum of kinds 4-7 (kind 4: kept exact, the reference recomputes it per symbol)
   u32 dense;
 };
+// Small table (kinds 4/5): entry i in lane i, sorted by symbol, one packed word per lane:
+//   symbol | count << 8 | P << 20,   P = sum of the counts of the entries before it.
+// The entry's interval starts at symbol - i (the unmet symbols below it, one slot each) + P
+// (+ the bonus when it sits above the top entry).  Keeping P up to date costs one masked add
+// per symbol and saves the prefix scan.  Counts and P stay below 4096 (the total does).
+// Unused lanes hold kSmallNone: count 0 and a start above every coder value.
+constexpr u32 kSmallNone = 0xFFF000FFu;
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int dpp_row_shr1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true); }
+__device__ __forceinline__ u32 sm_sym(u32 w) { return w & 255u; }
+__device__ __forceinline__ u32 sm_fq(u32 w) { return (w >> 8) & 4095u; }
+__device__ __forceinline__ u32 sm_p(u32 w) { return w >> 20; }
+
 struct WaveModel {
   const int lane;
   u16* tmp;  // 256 x u16 LDS scratch
@@ -104,23 +139,31 @@ struct WaveModel {
     h.dense = h2;
     return h;
   }
-  __device__ __forceinline__ void store_header(u32* r, const ColHdr& h) {
-    if (lane == 0) {
-      r[0] = (u32)h.kind | ((u32)h.maxpos << 8) | ((u32)h.fshift << 16);
-      r[1] = (u32)h.d | ((u32)h.total << 16);
-      r[2] = h.dense;
+  static __device__ __forceinline__ u32 pack0(const ColHdr& h) { return (u32)h.kind | ((u32)h.maxpos << 8) | ((u32)h.fshift << 16); }
+  static __device__ __forceinline__ u32 pack1(const ColHdr& h) { return (u32)h.d | ((u32)h.total << 16); }
+  // packed table from per-lane symbols and counts (after a rebuild of the counts, or a load); returns the exact total
+  __device__ __forceinline__ int small_pack(u32& w, int sym, int fq, int d) {
+    fq = lane < d ? fq : 0;
+    const int incl = row_incl_scan(fq);
+    w = lane < d ? ((u32)sym | ((u32)fq << 8) | ((u32)(incl - fq) << 20)) : kSmallNone;
+    return 256 - d + (int)rdl((u32)incl, 15);
+  }
+  // ColState image (encoder persistence): entry i <-> record bytes 16+i (symbol) and 32+2i (count)
+  __device__ __forceinline__ void load_small(const u32* r, int d, u32& w) {
+    const bool act = lane < d;
+    small_pack(w, act ? ((const u8*)r)[16 + lane] : 0, act ? ((const u16*)r)[16 + lane] : 0, d);
+  }
+  __device__ __forceinline__ void store_small(u32* r, int d, u32 w) {
+    if (lane < d) {
+      ((u8*)r)[16 + lane] = (u8)sm_sym(w);
+      ((u16*)r)[16 + lane] = (u16)sm_fq(w);
     }
   }
-  // small-table entry of this lane <-> record bytes 16+lane (symbol) and 32+2*lane (count)
-  __device__ __forceinline__ void load_small(const u32* r, int d, int& sym, int& fq) {
-    const bool act = lane < d;
-    sym = act ? ((const u8*)r)[16 + lane] : 0;
-    fq = act ? ((const u16*)r)[16 + lane] : 0;
-  }
-  __device__ __forceinline__ void store_small(u32* r, int d, int sym, int fq) {
-    if (lane < d) {
-      ((u8*)r)[16 + lane] = (u8)sym;
-      ((u16*)r)[16 + lane] = (u16)fq;
+  __device__ __forceinline__ void store_header(u32* r, const ColHdr& h) {
+    if (lane == 0) {
+      r[0] = pack0(h);
+      r[1] = pack1(h);
+      r[2] = h.dense;
     }
   }
   __device__ __forceinline__ u32 alloc_dense() {
@@ -149,8 +192,8 @@ struct WaveModel {
   }
 
   // Context::update for kinds 0-3 (ans_contexts.cpp:3-31, :52-59): c arrived raw.
-  // On promotion to a small table (kind 4/5) the entries are returned in sym/fq.
-  __device__ __forceinline__ void note_raw(u32* r, ColHdr& h, int c, int& sym, int& fq) {
+  // On promotion to a small table (kind 4/5) the packed entries are returned in w.
+  __device__ __forceinline__ void note_raw(u32* r, ColHdr& h, int c, u32& w) {
     wave_fence();
     if (h.kind == 0) {
       if (lane < 8) r[4 + lane] = (lane == (c >> 5)) ? (1u << (c & 31)) : 0u;
@@ -158,9 +201,9 @@ struct WaveModel {
       h.d = 1;
       return;
     }
-    const u32 w = rfl(r[4 + (c >> 5)]);
-    if (!((w >> (c & 31)) & 1u)) {
-      if (lane == 0) r[4 + (c >> 5)] = w | (1u << (c & 31));
+    const u32 sw = rfl(r[4 + (c >> 5)]);
+    if (!((sw >> (c & 31)) & 1u)) {
+      if (lane == 0) r[4 + (c >> 5)] = sw | (1u << (c & 31));
       h.d++;
       if (h.kind == 1 && h.d == 15) h.kind = 2;
       else if (h.kind == 2 && h.d == 65) h.kind = 3;
@@ -177,11 +220,10 @@ struct WaveModel {
       for (int q = 0; q < 4; q++)
         if ((bits >> q) & 1u) tmp[base + __builtin_popcount(bits & ((1u << q) - 1u))] = (u16)(lane * 4 + q);
       wave_fence();
-      sym = lane < d ? tmp[lane] : 0;
+      const int sym = lane < d ? (int)tmp[lane] : 0;
       wave_fence();
-      fq = lane < d ? (sym == c ? 2 * kStepSmall : kStepSmall) : 0;
       h.kind = d <= 4 ? 4 : 5;
-      h.total = h.kind == 5 ? 256 - d + kStepSmall * d + kStepSmall : 0;
+      h.total = small_pack(w, sym, sym == c ? 2 * kStepSmall : kStepSmall, d);
       return;
     }
     h.dense = alloc_dense();
@@ -219,79 +261,85 @@ struct WaveModel {
     }
   }
 
-  // kinds 4/5: SmallContext::decode / ::encode (ans_contexts.h:195-283), one lane per table entry
-  // (sym, fq in lanes 0..d-1, zero elsewhere).
+  // kinds 4/5: SmallContext::decode / ::encode (ans_contexts.h:195-283), on the packed table w.
   // DEC: `in` is the coder value (state & 4095), the symbol is returned; else `in` is the symbol.
+  // Both directions come down to the lane p of the last entry at or below the input (by interval
+  // start when decoding, by symbol when encoding): the input is that entry, or the unmet symbol
+  // (in - its end) slots above it.
   // When a full 16-table meets a 17th symbol the context becomes kind 6 (Cx6::create(Cx5&, c),
   // :454-489): the set goes to r[4..11], the table to the arena.
   template <bool DEC>
-  __device__ __forceinline__ int small_op(u32* r, ColHdr& h, int& sym, int& fq, int in, u32& ofr, u32& ocf) {
+  __device__ __forceinline__ int small_op(u32* r, ColHdr& h, u32& w, int in, u32& ofr, u32& ocf) {
     int d = h.d;
-    const bool act = lane < d;
-    int tot = h.kind == 4 ? 256 - d + row16_sum(fq) : h.total;
-    const int sh = shift_for(tot), bonus = (kProbScale - (tot << sh)) >> sh;
+    int tot = h.total;
+    const int sh = shift_for(tot), bonus = (kProbScale - (tot << sh)) >> sh;  // spare code space goes to the top entry
     const int vv = DEC ? in >> sh : 0;
-    const int f = act ? ((fq + (lane == h.maxpos ? bonus : 0)) & 0xFFFF) : 0;
-    const int incl = row_incl_scan(f), P = incl - f;
-    const int start = sym - lane + P, end = start + f;
-    const u64 hit = DEC ? __ballot(act && start <= vv && vv < end) : __ballot(act && sym == in);
-    const int cap = h.kind == 4 ? 4 : 16;
-    int c;
-    if (hit) {
-      const int p = __builtin_ctzll(hit);
-      c = DEC ? (int)rdl((u32)sym, p) : in;
-      ofr = rdl((u32)f, p) << sh;
-      ocf = rdl((u32)start, p) << sh;
-      const int fmax = (int)rdl((u32)fq, h.maxpos);
-      if (lane == p) fq += kStepSmall;
-      tot += kStepSmall;
-      if (p != h.maxpos && (int)rdl((u32)fq, p) > fmax) h.maxpos = p;
-      if (tot + kStepSmall > kProbScale) {  // rescale, :186-193
-        fq -= fq >> 1;
-        tot = 256 - d + row16_sum(fq);
-      }
-      h.total = h.kind == 5 ? tot : 0;
-      return c;
+    const int above = (lane > h.maxpos ? bonus : 0) - lane;
+    const int st = (int)sm_sym(w) + (int)sm_p(w) + above;  // where this lane's interval starts
+    const u32 m = DEC ? (u32)__ballot(st <= vv) & 0xFFFFu : (u32)__ballot((int)sm_sym(w) <= in) & ((1u << d) - 1u);
+    int p = -1, sp = -1, endp = 0, ap = 0, fpr = 0, pp = 0;
+    if (m) {
+      p = 31 - __builtin_clz(m);
+      const u32 wp = rdl(w, p);
+      sp = (int)sm_sym(wp);
+      fpr = (int)sm_fq(wp);
+      pp = (int)sm_p(wp);
+      ap = sp + pp - p + (p > h.maxpos ? bonus : 0);
+      endp = ap + fpr + (p == h.maxpos ? bonus : 0);
     }
-    const int pos = __builtin_popcountll(DEC ? __ballot(act && end <= vv) : __ballot(act && sym < in));
-    const int Ppos = pos < d ? (int)rdl((u32)P, pos) : (int)rdl((u32)incl, d - 1);
-    c = DEC ? vv - Ppos + pos : in;
-    ofr = 1u << sh;
-    ocf = (u32)(DEC ? vv : c - pos + Ppos) << sh;
-    if (d < cap || h.kind == 4) {  // addSymb (:174-184), or Cx5::create(Cx4&, c) (:350-369) when the 4-table is full
-      const int usym = __shfl_up(sym, 1), ufq = __shfl_up(fq, 1);
-      if (lane > pos && lane <= d) {
-        sym = usym;
-        fq = ufq;
-      } else if (lane == pos) {
-        sym = c;
-        fq = kStepSmall;
+    const bool hit = DEC ? vv < endp : sp == in;
+    if (hit) {
+      ofr = (u32)(endp - ap) << sh;
+      ocf = (u32)ap << sh;
+      const int fmax = (int)sm_fq(rdl(w, h.maxpos));
+      const u32 add = lane == p ? (u32)kStepSmall << 8 : ((u32)(lane - p - 1) < (u32)(d - p - 1) ? (u32)kStepSmall << 20 : 0u);  // the count of p, the P of p+1 .. d-1
+      w += add;
+      tot += kStepSmall;
+      if (p != h.maxpos && fpr + kStepSmall > fmax) h.maxpos = p;
+      if (tot + kStepSmall > kProbScale) {  // rescale, :186-193
+        const int fq = (int)sm_fq(w);
+        tot = small_pack(w, (int)sm_sym(w), fq - (fq >> 1), d);
       }
+      h.total = tot;
+      return sp;
+    }
+    const int c = DEC ? sp + 1 + vv - endp : in;
+    ofr = 1u << sh;
+    ocf = (u32)(DEC ? vv : c - sp - 1 + endp) << sh;
+    const int pos = p + 1;
+    const int cap = h.kind == 4 ? 4 : 16;
+    if (d < cap || h.kind == 4) {  // addSymb (:174-184), or Cx5::create(Cx4&, c) (:350-369) when the 4-table is full
+      const u32 up = (u32)dpp_row_shr1((int)w);
+      if (lane > pos && lane <= d) w = up + ((u32)kStepSmall << 20);
+      else if (lane == pos) w = (u32)c | ((u32)kStepSmall << 8) | ((u32)(pp + fpr) << 20);
       const bool grow = d == cap;  // kind 4 -> 5: maxpos restarts at 0 (value-initialised in the reference)
       d++;
       if (grow) {
         h.maxpos = 0;
         h.kind = 5;
-        tot = 256 - d + row16_sum(fq);
+        tot += kStepSmall - 1;  // the exact total of the grown table
       } else {
         if (h.maxpos >= pos) h.maxpos++;
-        tot += kStepSmall;
-        if (tot + kStepSmall > kProbScale) {
-          fq -= fq >> 1;
-          tot = 256 - d + row16_sum(fq);
+        if (tot + 2 * kStepSmall > kProbScale) {
+          const int fq = (int)sm_fq(w);
+          tot = small_pack(w, (int)sm_sym(w), fq - (fq >> 1), d);
+        } else {
+          tot += h.kind == 4 ? kStepSmall - 1 : kStepSmall;  // kind 5 counts the step only (its total drifts, :174-184)
         }
       }
       h.d = d;
-      h.total = h.kind == 5 ? tot : 0;
+      h.total = tot;
       return c;
     }
     // kind 5 full
+    const bool act = lane < d;
+    const int fqv = act ? (int)sm_fq(w) : 0;
     wave_fence();
     for (int q = 0; q < 4; q++) tmp[lane * 4 + q] = 0;
     wave_fence();
-    if (act) tmp[sym] = (u16)fq;
+    if (act) tmp[sm_sym(w)] = (u16)fqv;
     wave_fence();
-    const int tex = 256 - d + row16_sum(fq), s2 = shift_for(tex), wdt = 1 << s2, base = wdt - (wdt >> 1);
+    const int tex = 256 - d + row16_sum(fqv), s2 = shift_for(tex), wdt = 1 << s2, base = wdt - (wdt >> 1);
     int fr[4], cn[4];
     u32 bits = 0;
     for (int q = 0; q < 4; q++) {
@@ -400,6 +448,9 @@ struct WaveModel {
   }
 };
 
+#ifdef SCPR_PROFILE
+__device__ u64 g_prof[8];
+#endif
 struct WaveDec : WaveModel {
   WaveLds& L;
   // input stream
@@ -412,11 +463,13 @@ struct WaveDec : WaveModel {
   // coder
   u32 x = 0;
   int ndec = 0;
+  // pixel-type tables (ptypetab) in registers: table t in lanes 8t..8t+5 (entries) and 8t+7 (the running total, in pcnt)
+  u32 pfc = 0xFFFFFFFFu, pcnt = 0;
   // models
-  ColState* gstates;
+  DecRec* gstates;
   bool bad = false;
 
-  __device__ __forceinline__ WaveDec(WaveLds& l, const u8* s, const u8* e, ColState* gs, Arena a, int f0_) : WaveModel(l.tmp, a, f0_), L(l), src(s), src_end(e), gstates(gs) {}
+  __device__ __forceinline__ WaveDec(WaveLds& l, const u8* s, const u8* e, DecRec* gs, Arena a, int f0_) : WaveModel(l.tmp, a, f0_), L(l), src(s), src_end(e), gstates(gs) {}
 
   // ---------------------------------------------------------------- input ---
   // The packet bytes are read with wave-uniform 4-byte loads straight from the packet buffer
@@ -440,6 +493,19 @@ struct WaveDec : WaveModel {
     x = take_u32();
   }
   __device__ __forceinline__ void tick() {}
+  // section timing for design work (only with -DSCPR_PROFILE): time since the previous stamp goes to section `sec`
+#ifdef SCPR_PROFILE
+  u64 prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prof_last = 0;
+  template <int SEC>
+  __device__ __forceinline__ void stamp() {
+    const u64 t = __builtin_readcyclecounter();
+    prof[SEC] += t - prof_last;
+    prof_last = t;
+  }
+#else
+  template <int SEC>
+  __device__ __forceinline__ void stamp() {}
+#endif
   __device__ __forceinline__ void need(int k) {
     while (nb < k) {
       buf |= (u64)nextw << (8 * nb);
@@ -463,7 +529,9 @@ struct WaveDec : WaveModel {
     return v;
   }
   __device__ __forceinline__ void advance(u32 cf, u32 fr, u32 v) {  // RansDecAdvance, rans_byte.h:130-146
-    x = fr * (x >> kProbBits) + v - cf;
+    u32 hi = x >> kProbBits;
+    asm("s_mul_i32 %0, %1, %2" : "=s"(hi) : "s"(hi), "s"(fr));  // the state is wave-uniform: keep it on the scalar unit
+    x = hi + (v - cf);
     while (x < kRansL) x = (x << 8) | take_byte();
   }
   __device__ __forceinline__ void count() {  // screencap.h:327-331
@@ -474,8 +542,9 @@ struct WaveDec : WaveModel {
   }
 
   // ---------------------------------------------------------------- fixed ---
-  __device__ __forceinline__ void fixed_init() {  // renew() of every table (RenewI, screencap.cpp:178-198)
-    FixedBlob& F = L.fx;
+  // renew() of every table (RenewI, screencap.cpp:178-198)
+  __device__ __forceinline__ void fixed_init() {
+    FixedLds& F = L.fx;
     auto fill = [&](u32* fc, u32* cnt, int nsym, int cap, int ti) __attribute__((always_inline)) {
       const int fr = kProbScale / nsym, c0 = fr - (fr >> 1);
       for (int j = lane; j < cap; j += 64) {
@@ -484,9 +553,15 @@ struct WaveDec : WaveModel {
       }
       if (lane == 0) F.ftot[ti] = c0 * nsym;
     };
+    wave_fence();
     for (int t = 0; t < 6; t++) {
-      fill(F.nfc[t], F.ncnt[t], 256, 256, t);
-      fill(F.pfc[t], F.pcnt[t], 6, 8, 6 + t);
+      for (int j = lane; j < NTAB_STRIDE; j += 64) F.ntab[t][j] = j < 256 ? (16u | ((u32)(16 * j) << 16)) : j == 256 ? 8u * 256u : 0u;
+      for (int j = lane; j < 256; j += 64) F.ncnt[t][j] = 8u;
+    }
+    {
+      const int j = lane & 7, fr = kProbScale / 6, c0 = fr - (fr >> 1);
+      pfc = (lane < 48 && j < 6) ? ((u32)fr | ((u32)(fr * j) << 16)) : 0xFFFFFFFFu;
+      pcnt = lane < 48 ? (j < 6 ? (u32)c0 : j == 7 ? (u32)(c0 * 6) : 0u) : 0u;
     }
     for (int t = 0; t < 2; t++) {
       fill(F.mfc[t], F.mcnt[t], 512, 512, 12 + t);
@@ -494,7 +569,147 @@ struct WaveDec : WaveModel {
     }
     for (int t = 0; t < 4; t++) fill(F.sfc[t], F.scnt[t], 16, 16, 16 + t);
     fill(F.bfc, F.bcnt, 5, 8, 20);
+    wave_fence();
   }
+  // the models of an earlier call, from their image in HBM
+  __device__ __forceinline__ void fixed_load(const FixedBlob* __restrict__ B) {
+    FixedLds& F = L.fx;
+    wave_fence();
+    for (int t = 0; t < 6; t++) {
+      for (int j = lane; j < NTAB_STRIDE; j += 64) F.ntab[t][j] = j < 256 ? B->nfc[t][j] : j == 256 ? (u32)B->ftot[t] : 0u;
+      for (int j = lane; j < 256; j += 64) F.ncnt[t][j] = B->ncnt[t][j];
+    }
+    {
+      const int t = lane >> 3, j = lane & 7;
+      pfc = lane < 48 ? B->pfc[t][j] : 0xFFFFFFFFu;
+      pcnt = lane < 48 ? (j == 7 ? (u32)B->ftot[6 + t] : B->pcnt[t][j]) : 0u;
+    }
+    for (int i = lane; i < 1024; i += 64) {
+      (&F.mfc[0][0])[i] = (&B->mfc[0][0])[i];
+      (&F.mcnt[0][0])[i] = (&B->mcnt[0][0])[i];
+    }
+    for (int i = lane; i < 512; i += 64) {
+      (&F.xfc[0][0])[i] = (&B->xfc[0][0])[i];
+      (&F.xcnt[0][0])[i] = (&B->xcnt[0][0])[i];
+    }
+    (&F.sfc[0][0])[lane] = (&B->sfc[0][0])[lane];
+    (&F.scnt[0][0])[lane] = (&B->scnt[0][0])[lane];
+    if (lane < 8) {
+      F.bfc[lane] = B->bfc[lane];
+      F.bcnt[lane] = B->bcnt[lane];
+    }
+    if (lane < 24) F.ftot[lane] = B->ftot[lane];
+    wave_fence();
+  }
+  __device__ __forceinline__ void fixed_store(FixedBlob* __restrict__ B) {
+    FixedLds& F = L.fx;
+    wave_fence();
+    for (int t = 0; t < 6; t++) {
+      for (int j = lane; j < 256; j += 64) {
+        B->nfc[t][j] = F.ntab[t][j];
+        B->ncnt[t][j] = F.ncnt[t][j];
+      }
+      if (lane == 0) B->ftot[t] = (int)F.ntab[t][256];
+    }
+    for (int i = lane; i < 1024; i += 64) {
+      (&B->mfc[0][0])[i] = (&F.mfc[0][0])[i];
+      (&B->mcnt[0][0])[i] = (&F.mcnt[0][0])[i];
+    }
+    for (int i = lane; i < 512; i += 64) {
+      (&B->xfc[0][0])[i] = (&F.xfc[0][0])[i];
+      (&B->xcnt[0][0])[i] = (&F.xcnt[0][0])[i];
+    }
+    (&B->sfc[0][0])[lane] = (&F.sfc[0][0])[lane];
+    (&B->scnt[0][0])[lane] = (&F.scnt[0][0])[lane];
+    if (lane < 8) {
+      B->bfc[lane] = F.bfc[lane];
+      B->bcnt[lane] = F.bcnt[lane];
+    }
+    if (lane < 48) {
+      const int t = lane >> 3, j = lane & 7;
+      B->pfc[t][j] = pfc;
+      B->pcnt[t][j] = j == 7 ? 0u : pcnt;
+      if (j == 7) B->ftot[6 + t] = (int)pcnt;
+    }
+    if (lane >= 12 && lane < 24) B->ftot[lane] = F.ftot[lane];
+  }
+
+  // Run length after a pixel of type t (decode + incrCnt, ans_contexts.h:1093-1112, :1070-1091).
+  // Symbol j of a table is LDS word j: the first 64 symbols (almost every run) are one per lane and
+  // are found with one compare and a population count; word 64 tells whether that is enough, word
+  // 256 is the running total.  The three words come back from one wait.
+  __device__ __forceinline__ int fixed_n(int t) {
+    wave_fence();
+    const u32 v = x & (kProbScale - 1), lim = (v + 1) << 16;  // cum <= v  <=>  (freq | cum << 16) < lim
+    u32* tab = L.fx.ntab[t];
+    const u32 addr = (u32)(size_t)tab + 4u * (u32)lane;  // LDS offset = low 32 bits of the flat address
+    u32 e0, e1, et;
+    asm volatile("ds_read_b32 %0, %3\n\tds_read_b32 %1, %3 offset:256\n\tds_read_b32 %2, %3 offset:1024\n\ts_waitcnt lgkmcnt(0)" : "=v"(e0), "=v"(e1), "=v"(et) : "v"(addr) : "memory");
+    const int tot0 = (int)rfl(et);
+    int sym;
+    u32 s;
+    if (rfl(e1) >= lim) {  // cum of symbol 64 is above v
+      sym = __builtin_popcountll(__ballot(e0 < lim)) - 1;
+      s = rdl(e0, sym);
+    } else {
+      const u32 e2 = tab[128 + lane], e3 = tab[192 + lane];
+      sym = 63 + __builtin_popcountll(__ballot(e1 < lim)) + __builtin_popcountll(__ballot(e2 < lim)) + __builtin_popcountll(__ballot(e3 < lim));
+      const int q = sym >> 6, l = sym & 63;
+      s = q == 1 ? rdl(e1, l) : q == 2 ? rdl(e2, l) : rdl(e3, l);
+    }
+    if (lane == 0) {
+      const u32 a1 = (u32)(size_t)&L.fx.ncnt[t][sym], a2 = (u32)(size_t)&tab[256];
+      asm volatile("ds_add_u32 %0, %2\n\tds_add_u32 %1, %2" ::"v"(a1), "v"(a2), "v"((u32)kStepDense) : "memory");
+    }
+    advance(s >> 16, s & 0xFFFF, v);
+    if (tot0 + 2 * kStepDense > kProbScale) {  // rebuild from the counts, ans_contexts.h:1075-1090
+      wave_fence();
+      u32* cnt = L.fx.ncnt[t];
+      int base = 0, ns = 0;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int c = (int)cnt[lane + 64 * q];
+        const int inc = wave_incl_scan(c);
+        tab[lane + 64 * q] = (u32)c | ((u32)(base + inc - c) << 16);
+        base += (int)rdl((u32)inc, 63);
+        const int h = c - (c >> 1);
+        cnt[lane + 64 * q] = (u32)h;
+        ns += h;
+      }
+      ns = wave_sum(ns);
+      if (lane == 0) tab[256] = (u32)ns;
+      wave_fence();
+    }
+    count();
+    return sym;
+  }
+  // Pixel type after a pixel of type t: all six tables are searched by the same compare
+  __device__ __forceinline__ int fixed_p(int t) {
+    const u32 v = x & (kProbScale - 1), lim = (v + 1) << 16;
+    const u64 m = __ballot(pfc < lim);
+    const u32 mt = (u32)(m >> (8 * t)) & 0xFFu;  // never 0: the first cum is 0
+    const int j = 31 - __builtin_clz(mt);
+    const int own = 8 * t + j, tl = 8 * t + 7;
+    const u32 s = rdl(pfc, own);
+    const int tot = (int)rdl(pcnt, tl) + kStepDense;
+    pcnt += (lane == own || lane == tl) ? (u32)kStepDense : 0u;
+    advance(s >> 16, s & 0xFFFF, v);
+    if (tot + kStepDense > kProbScale) {
+      const bool in = (lane >> 3) == t && (lane & 7) < 6;
+      const int c = in ? (int)pcnt : 0;
+      const int inc = wave_incl_scan(c);
+      const int h = c - (c >> 1);
+      const int nt = wave_sum(h);
+      if (in) {
+        pfc = (u32)c | ((u32)(inc - c) << 16);
+        pcnt = (u32)h;
+      }
+      if (lane == tl) pcnt = (u32)nt;
+    }
+    count();
+    return j;
+  }
+
   template <int PER>
   __device__ __forceinline__ int fixed_rebuild(u32* fc, u32* cnt, int nsym) {  // incrCnt rebuild, ans_contexts.h:1075-1090
     wave_fence();
@@ -521,12 +736,12 @@ struct WaveDec : WaveModel {
     wave_fence();
     return wave_sum(ns);
   }
-  // Symbol whose interval holds the coder value, then the table update (decode + incrCnt,
-  // ans_contexts.h:1093-1112, :1070-1091).  PER entries per lane; entries past the alphabet hold ~0.
+  // The P-frame tables (searched in LDS): symbol whose interval holds the coder value, then the
+  // table update.  PER entries per lane; entries past the alphabet hold ~0.
   template <int PER>
   __device__ __forceinline__ int fixed_any(u32* fc, u32* cnt, int nsym, int ti) {
     wave_fence();
-    const u32 v = x & (kProbScale - 1), lim = (v + 1) << 16;  // cum <= v  <=>  (freq | cum << 16) < lim
+    const u32 v = x & (kProbScale - 1), lim = (v + 1) << 16;
     u32 e[PER];
 #pragma unroll
     for (int q = 0; q < PER; q++) e[q] = (PER > 1 || lane < (nsym <= 8 ? 8 : 16)) ? fc[lane * PER + q] : 0xFFFFFFFFu;
@@ -543,7 +758,7 @@ struct WaveDec : WaveModel {
     const u32 s = rdl(sel, own);
     const int sym = own * PER + kk;
     if (lane == own) {
-      const u32 addr = (u32)(size_t)&cnt[sym];  // LDS offset = low 32 bits of the flat address
+      const u32 addr = (u32)(size_t)&cnt[sym];
       asm volatile("ds_add_u32 %0, %1" ::"v"(addr), "v"((u32)kStepDense) : "memory");
     }
     wave_fence();
@@ -554,8 +769,6 @@ struct WaveDec : WaveModel {
     count();
     return sym;
   }
-  __device__ __forceinline__ int fixed_n(int t) { return fixed_any<4>(L.fx.nfc[t], L.fx.ncnt[t], 256, t); }
-  __device__ __forceinline__ int fixed_p(int t) { return fixed_any<1>(L.fx.pfc[t], L.fx.pcnt[t], 6, 6 + t); }
   __device__ __forceinline__ int fixed_mv(int t) { return fixed_any<8>(L.fx.mfc[t], L.fx.mcnt[t], 512, 12 + t); }
   __device__ __forceinline__ int fixed_x(int t) { return fixed_any<4>(L.fx.xfc[t], L.fx.xcnt[t], 256, 14 + t); }
   __device__ __forceinline__ int fixed_sxy(int t) { return fixed_any<1>(L.fx.sfc[t], L.fx.scnt[t], 16, 16 + t); }
@@ -569,59 +782,53 @@ struct WaveDec : WaveModel {
   }
 
   // --------------------------------------------------------------- colour ---
-  // the record of a context in the LDS cache (one LDS wait on a hit: tag, header and table entry are read together)
-  __device__ __forceinline__ u32* record(int ctxid, ColHdr& h, int& sym, int& fq) {
+  // The record of a context in the LDS cache: header + tag (one broadcast read) and the small
+  // table (one word per lane, lanes 16.. mirror lanes 0..15) come back from one wait.
+  __device__ __forceinline__ u32* record(int ctxid, ColHdr& h, u32& w) {
     wave_fence();
     const int slot = (ctxid ^ (ctxid >> 7)) & (CACHE_N - 1);
     u32* r = L.crec[slot];
-    const u32 tg = L.ctag[slot];
-    const uint4 hw = *(const uint4*)r;
-    u32 a = hw.x, b = hw.y, c2 = hw.z;
-    u32 sy = lane < 16 ? ((const u8*)r)[16 + lane] : 0, fv = lane < 16 ? ((const u16*)r)[16 + lane] : 0;
-    const int tag = (int)rfl(tg);
+    const u32 ra = (u32)(size_t)r, ea = ra + 16u + 4u * (u32)(lane & 15);
+    u32x4 hw;
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=v"(hw), "=v"(w) : "v"(ra), "v"(ea) : "memory");
+    const int tag = (int)rfl(hw.w);
     if (tag != ctxid + 1) {
-      if (tag && lane < 16) ((u32*)&gstates[tag - 1])[lane] = r[lane];
-      if (lane < 16) r[lane] = ((const u32*)&gstates[ctxid])[lane];
-      if (lane == 0) L.ctag[slot] = (u16)(ctxid + 1);
+      if (lane < DECREC_WORDS) {
+        if (tag) gstates[tag - 1].w[lane] = r[lane];
+        r[lane] = lane == 3 ? (u32)(ctxid + 1) : gstates[ctxid].w[lane];
+      }
       wave_fence();
-      a = r[0];
-      b = r[1];
-      c2 = r[2];
-      sy = lane < 16 ? ((const u8*)r)[16 + lane] : 0;
-      fv = lane < 16 ? ((const u16*)r)[16 + lane] : 0;
+      asm volatile("ds_read_b128 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=v"(hw), "=v"(w) : "v"(ra), "v"(ea) : "memory");
     }
-    h = unpack(rfl(a), rfl(b), rfl(c2));
-    const bool act = lane < h.d && (h.kind == 4 || h.kind == 5);
-    sym = act ? (int)sy : 0;
-    fq = act ? (int)fv : 0;
+    h = unpack(rfl(hw.x), rfl(hw.y), rfl(hw.z));
     return r;
   }
   __device__ __forceinline__ void flush_records() {
     wave_fence();
     for (int slot = 0; slot < CACHE_N; slot++) {
-      const int tag = (int)rfl((u32)L.ctag[slot]);
-      if (tag && lane < 16) ((u32*)&gstates[tag - 1])[lane] = L.crec[slot][lane];
+      const int tag = (int)rfl(L.crec[slot][3]);
+      if (tag && lane < DECREC_WORDS) gstates[tag - 1].w[lane] = L.crec[slot][lane];
     }
   }
   // decodeC (screencap.h:318-333)
   __device__ __forceinline__ int colour(int ctxid) {
-    tick();
     ColHdr h;
-    int sym, fq;
-    u32* r = record(ctxid, h, sym, fq);
+    u32 w;
+    u32* r = record(ctxid, h, w);
     int c;
     if (h.kind < 4) {
       c = (int)take_byte();
-      note_raw(r, h, c, sym, fq);
+      note_raw(r, h, c, w);
     } else {
       u32 fr, cf;
       const u32 v = x & (kProbScale - 1);
-      c = h.kind <= 5 ? small_op<true>(r, h, sym, fq, (int)v, fr, cf) : dense_op<true>(r, h, (int)v, fr, cf);
+      c = h.kind <= 5 ? small_op<true>(r, h, w, (int)v, fr, cf) : dense_op<true>(r, h, (int)v, fr, cf);
       advance(cf, fr, v);
     }
     wave_fence();
-    if (h.kind == 4 || h.kind == 5) store_small(r, h.d, sym, fq);
-    store_header(r, h);
+    if (lane < 16 && (h.kind == 4 || h.kind == 5)) r[4 + lane] = w;
+    if (lane == 0) *(uint2*)r = make_uint2(pack0(h), pack1(h));
+    if (lane == 0) r[2] = h.dense;
     wave_fence();
     count();
     return c;
@@ -666,25 +873,13 @@ __device__ __forceinline__ void decode_intra_frame(WaveDec& D, const Geom& g, u8
   const u32 pm = (u32)ring_pixels - 1u;
   const int W = g.W, H = g.H, S = g.S, NP = g.NP;
   const int pad = S - 3 * W;  // 0..3 zero bytes after each row
-  const int chunk = W < 64 ? W : 64;
-  auto get_rgb = [&](u32 lp) __attribute__((always_inline)) -> u32 {  // DecodeRGB, screencap.cpp:662-679
-    // contexts: two previous bytes >> 2 (MAKECX1, screencap.h:35-36); one code copy for the three planes
-    u32 a = (lp >> 18) & 63, b = (lp >> 10) & 63, px = 0;
-#pragma unroll 1
-    for (int plane = 0; plane < 3; plane++) {
-      const u32 c = (u32)D.colour(plane * 4096 + (int)(a | (b << 6)));
-      px |= c << (8 * plane);
-      b = a;
-      a = c >> 2;
-    }
-    return px;
-  };
+  const int chunk = W < 64 ? W : 64;  // pixels of a predicted run rebuilt together: never more than a row, they read the row above
   // rows [flushed, to) are complete in the ring: pack them to RGB24 and store them (row padding = 0)
-  int flushed = 0;
+  int flushed = 0, rowbase = 0;  // rowbase = flushed * W: first pixel of the row being decoded
   auto flush_rows = [&](int to) __attribute__((always_inline)) {
     wave_fence();
-    for (; flushed < to; flushed++) {
-      const u32 p0 = (u32)flushed * (u32)W;
+    for (; flushed < to; flushed++, rowbase += W) {
+      const u32 p0 = (u32)rowbase;
       u8* row = dst + (size_t)flushed * S;
       for (int gq = lane; gq * 4 < W; gq += 64) {
         const u32 q = p0 + 4u * gq;
@@ -703,60 +898,75 @@ __device__ __forceinline__ void decode_intra_frame(WaveDec& D, const Geom& g, u8
   // One loop for both phases so that every model routine is instantiated once:
   //   header phase (p <= W): literal + run length over the first row and pixel (0,1)  (:421-438)
   //   body: pixel type, literal if type 0, run length                                  (:443-494)
-  int p = 0, xx = 0, t = 0;  // next pixel (raster index) and its column
+  int p = 0, t = 0;  // next pixel (raster index), type of the previous run
   while (p < NP && !D.bad) {
-    const bool hdr = p < W + 1;
+    const bool hdr = p <= W;
+    D.stamp<4>();
     if (!hdr) t = D.fixed_p(t);
+    D.stamp<0>();
     u32 px = lastpix;
-    if (hdr || t == 0) px = get_rgb(lastpix);
-    const int n = D.fixed_n(hdr ? 0 : t);
-    if (n < 1 || t == 3 || p + n > NP || (hdr && p + n > W + 1)) {
+    if (t == 0) {  // DecodeRGB, screencap.cpp:662-679: contexts are the two previous bytes >> 2 (MAKECX1, screencap.h:35-36)
+      u32 a = (lastpix >> 18) & 63, b = (lastpix >> 10) & 63;
+      px = 0;
+#pragma unroll 1
+      for (int plane = 0; plane < 3; plane++) {
+        const u32 c = (u32)D.colour(plane * 4096 + (int)(a | (b << 6)));
+        px |= c << (8 * plane);
+        b = a;
+        a = c >> 2;
+      }
+      D.stamp<1>();
+    }
+    const int n = D.fixed_n(t);
+    D.stamp<2>();
+    if ((u32)(n - 1) >= (u32)((hdr ? W + 1 : NP) - p)) {  // empty, or longer than what is left (of the header row)
       D.bad = true;
       break;
     }
-    if (hdr || t <= 1) {  // literal, or copy of the previous pixel: every pixel of the run has the same value
+    if (t <= 1) {  // literal, or copy of the previous pixel: every pixel of the run has the same value
       for (int q = lane; q < n; q += 64) ring[(u32)(p + q) & pm] = px;
       lastpix = px;
+    } else if (t == 3) {
+      D.bad = true;
+      break;
     } else {
+      u32 v = 0;
+      int m = 0;
       for (int q0 = 0; q0 < n; q0 += chunk) {
-        wave_fence();  // pixels written by other lanes are read below
-        const int m = min(chunk, n - q0);
-        const bool act = lane < m;
+        wave_fence();  // pixels written by other lanes are read here (a run may be longer than a row)
+        m = min(chunk, n - q0);
         const u32 pq = (u32)(p + q0 + lane);
-        int xq = xx + q0 + lane;
-        while (xq >= W) xq -= W;
-        u32 v = 0;
-        if (t == 2) {
-          if (act) v = ring[(pq - W) & pm];
+        if (t == 2) {  // copy of the pixel above
+          v = ring[(pq - W) & pm];
         } else {
-          // top-left; in column 0 it is the bytes just before the row above in memory: the tail of the
-          // last pixel two rows up followed by that row's padding (screencap.cpp:881)
-          u32 tl = 0;
-          if (act) {
-            tl = ring[(pq - W - 1) & pm];
+          u32 tl = ring[(pq - W - 1) & pm];
+          if (pad) {  // in column 0 "above-left" is the bytes just before the row above in memory: the tail of the
+                      // last pixel two rows up followed by that row's padding (screencap.cpp:881)
+            int xq = (int)pq - rowbase;
+            while (xq >= W) xq -= W;
             if (xq == 0) tl >>= 8 * pad;
           }
           if (t == 5) {
             v = tl;
           } else {  // gradient: previous + top - topleft, a running sum along the run (mod 256 per channel)
-            const u32 tp = act ? ring[(pq - W) & pm] : 0u;
+            const u32 tp = ring[(pq - W) & pm];
             int d0 = (int)(tp & 255) - (int)(tl & 255), d1 = (int)((tp >> 8) & 255) - (int)((tl >> 8) & 255), d2 = (int)((tp >> 16) & 255) - (int)((tl >> 16) & 255);
-            if (!act) d0 = d1 = d2 = 0;
+            if (lane >= m) d0 = d1 = d2 = 0;
             d0 = wave_incl_scan(d0);
             d1 = wave_incl_scan(d1);
             d2 = wave_incl_scan(d2);
             v = (u32)(((int)(lastpix & 255) + d0) & 255) | ((u32)(((int)((lastpix >> 8) & 255) + d1) & 255) << 8) | ((u32)(((int)((lastpix >> 16) & 255) + d2) & 255) << 16);
+            lastpix = rdl(v, m - 1);
           }
         }
-        if (act) ring[pq & pm] = v;
-        wave_fence();
-        lastpix = rdl(v, m - 1);
+        if (lane < m) ring[pq & pm] = v;
       }
+      wave_fence();
+      lastpix = rdl(v, m - 1);
     }
+    D.stamp<3>();
     p += n;
-    xx += n;
-    while (xx >= W) xx -= W;
-    if ((flushed + 1) * W <= p) {
+    if (p >= rowbase + W) {
       int done = flushed + 1;
       while ((done + 1) * W <= p) done++;
       flush_rows(done);
@@ -997,28 +1207,21 @@ __device__ __forceinline__ void decode_inter_frame(WaveDec& D, const Geom& g, u8
 
 template <bool HAS_P>
 __global__ __launch_bounds__(64) void k_decode_gop_w(const u8* __restrict__ packets, const u8* packets_end, const DecFrame* __restrict__ frames, const DecGop* __restrict__ gops,
-                                                     u8* __restrict__ planes, Geom g, ColState* __restrict__ states, Arena arena, int f0, u32* __restrict__ status, int ring_bytes,
+                                                     u8* __restrict__ planes, Geom g, DecRec* __restrict__ states, Arena arena, int f0, u32* __restrict__ status, int ring_bytes,
                                                      FixedBlob* __restrict__ fixedstore, int far_x, int far_y) {
   __shared__ WaveLds L;
   extern __shared__ __align__(16) u8 pix[];  // ring_bytes = 4 * (power of two >= W + 512) pixels, then (P-frames) one byte per 16x16 block
   const DecGop gop = gops[blockIdx.x];
   const int lane = lane_id();
-  for (int i = lane; i < CACHE_N; i += 64) L.ctag[i] = 0;
+  for (int i = lane; i < CACHE_N; i += 64) L.crec[i][3] = 0;  // empty cache
   WaveDec D(L, packets, packets_end, states + (size_t)blockIdx.x * NCOLCTX, arena, f0);
-  if (gop.load) {
-    const u32* src = (const u32*)&fixedstore[blockIdx.x];
-    u32* dstw = (u32*)&L.fx;
-    for (int i = lane; i < (int)(sizeof(FixedBlob) / 4); i += 64) dstw[i] = src[i];
-  } else {
-    D.fixed_init();
-  }
-  wave_fence();
+  if (gop.load) D.fixed_load(&fixedstore[blockIdx.x]);
+  else D.fixed_init();
   for (int fi = gop.first; fi < gop.first + gop.count && !D.bad; fi++) {
     const DecFrame fr = frames[fi];
     u8* dst = planes + (size_t)fr.slot * g.plane_stride;
     if (fr.kind == 0) {
       D.fixed_init();  // RenewI (:418); the colour records of the GOP start cleared
-      wave_fence();
       D.stream_init(packets + fr.src_off + 1);
       decode_intra_frame(D, g, dst, (u32*)pix, ring_bytes >> 2);
     } else if (HAS_P && fr.kind == 2) {
@@ -1026,13 +1229,12 @@ __global__ __launch_bounds__(64) void k_decode_gop_w(const u8* __restrict__ pack
     }
   }
   D.flush_records();
-  wave_fence();
-  {
-    u32* dstw = (u32*)&fixedstore[blockIdx.x];
-    const u32* src = (const u32*)&L.fx;
-    for (int i = lane; i < (int)(sizeof(FixedBlob) / 4); i += 64) dstw[i] = src[i];
-  }
+  D.fixed_store(&fixedstore[blockIdx.x]);
   if (D.bad && lane == 0) atomicOr(status, 4u);
+#ifdef SCPR_PROFILE
+  if (lane == 0)
+    for (int i = 0; i < 8; i++) atomicAdd((unsigned long long*)&g_prof[i], (unsigned long long)D.prof[i]);
+#endif
 }
 
 // ------------------------------------------------------------- encoder chains ---
@@ -1080,7 +1282,7 @@ __global__ __launch_bounds__(64) void k_colour_chain_w(const u32* __restrict__ s
     const u32 start = cstart[q], len = cstart[q + 1] - start;
     const int gen = (int)(q / NCOLCTX), ctx = (int)(q - (u32)gen * NCOLCTX);
     ColHdr h = WaveModel::unpack(0, 0, 0);
-    int sym = 0, fq = 0;
+    u32 T = kSmallNone;
     wave_fence();
     if (gen == 0 && cp.load_first) {  // continue the model of this context from the previous call
       const u32* src = (const u32*)&cp.states[ctx];
@@ -1089,7 +1291,7 @@ __global__ __launch_bounds__(64) void k_colour_chain_w(const u32* __restrict__ s
         if (lane < 16) rec[lane] = w;
         wave_fence();
         h = WaveModel::unpack(rdl(w, 0), rdl(w, 1), rdl(w, 2));
-        if (h.kind == 4 || h.kind == 5) M.load_small(rec, h.d, sym, fq);
+        if (h.kind == 4 || h.kind == 5) M.load_small(rec, h.d, T);
       }
     }
     for (u32 base = 0; base < len; base += 64) {
@@ -1104,9 +1306,9 @@ __global__ __launch_bounds__(64) void k_colour_chain_w(const u32* __restrict__ s
         u32 fr = 0, cf = (u32)c;
         wave_fence();
         if (h.kind < 4)
-          M.note_raw(rec, h, c, sym, fq);
+          M.note_raw(rec, h, c, T);
         else if (h.kind <= 5)
-          M.small_op<false>(rec, h, sym, fq, c, fr, cf);
+          M.small_op<false>(rec, h, T, c, fr, cf);
         else
           M.dense_op<false>(rec, h, c, fr, cf);
         if (lane == j) mine = (fr & 0xFFFFu) | (cf << 16);
@@ -1115,7 +1317,7 @@ __global__ __launch_bounds__(64) void k_colour_chain_w(const u32* __restrict__ s
     }
     if (gen == cp.ngens - 1) {  // live generation: keep the state for the next call
       wave_fence();
-      if (h.kind == 4 || h.kind == 5) M.store_small(rec, h.d, sym, fq);
+      if (h.kind == 4 || h.kind == 5) M.store_small(rec, h.d, T);
       M.store_header(rec, h);
       if (lane == 0) rec[3] = cp.stamp_out;
       wave_fence();

@@ -1,0 +1,41 @@
+"""Design tool: where one decoder wave spends its time (s_memtime ticks per section).
+
+Builds screenpressor_amd/libscpr_amd_prof.so (-DSCPR_PROFILE), decodes N synthetic 1080p key
+frames and prints the share of each section of decode_intra_frame.  Not part of the product.
+"""
+import ctypes as C, os, subprocess, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+LIB = os.path.join(ROOT, "screenpressor_amd", "libscpr_amd_prof.so")
+src = os.path.join(ROOT, "screenpressor_amd", "csrc", "scpr_amd.hip")
+if "--build" in sys.argv or not os.path.exists(LIB):
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-strict-aliasing", "-fPIC", "-shared", "-DSCPR_PROFILE",
+                           "-Wno-unused-result", "-o", LIB, src])
+    if "--build" in sys.argv:
+        sys.exit(0)
+import torch
+from screenpressor_amd import codec as K
+from screenpressor_amd.synth import DesktopSequence
+K._LIB_PATH = LIB
+n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 16
+W, H = 1920, 1080
+seq = DesktopSequence(W, H, seed=1)
+frames = torch.from_numpy(seq.frames(n)).cuda().reshape(n, -1)
+c = K.ScreenCodec()
+c.Init(W, H, 32)
+pk, sizes, ft = c.CompressBatch(frames, [0] * n)
+L = K.load_library()
+out = (C.c_ulonglong * 8)()
+L.scpr_debug_profile(out)
+r, dec = c.DecompressBatch(pk, sizes, ft)
+torch.cuda.synchronize()
+assert torch.equal(dec.reshape(-1), frames.reshape(-1))
+L.scpr_debug_profile(out)
+v = np.array(list(out), dtype=np.float64)
+names = ["P", "colour", "N", "fill", "rows/loop", "-", "-", "-"]
+tot = v.sum()
+print("ticks per frame: %.0f" % (tot / n))
+for nm, x in zip(names, v):
+    if x:
+        print("%-10s %5.1f %%   %.0f ticks/frame" % (nm, 100 * x / tot, x / n))
