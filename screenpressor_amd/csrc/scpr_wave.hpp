@@ -20,6 +20,11 @@
 
 namespace scpr {
 
+// Block placement hints: the decoder is one serial chain per wave, a taken branch costs it about
+// two extra instruction slots, so the common case of every test should fall through.
+#define SCPR_LIKELY(c) __builtin_expect(!!(c), 1)
+#define SCPR_UNLIKELY(c) __builtin_expect(!!(c), 0)
+
 // Lanes of one wave exchange data through LDS in program order (DS operations of a
 // wave execute in order), but to the compiler each lane is a thread of its own: without
 // a fence it may forward a lane's own earlier store to its later load and miss what
@@ -278,7 +283,7 @@ struct WaveModel {
     const int st = (int)sm_sym(w) + (int)sm_p(w) + above;  // where this lane's interval starts
     const u32 m = DEC ? (u32)__ballot(st <= vv) & 0xFFFFu : (u32)__ballot((int)sm_sym(w) <= in) & ((1u << d) - 1u);
     int p = -1, sp = -1, endp = 0, ap = 0, fpr = 0, pp = 0;
-    if (m) {
+    if (SCPR_LIKELY(m)) {
       p = 31 - __builtin_clz(m);
       const u32 wp = rdl(w, p);
       sp = (int)sm_sym(wp);
@@ -288,7 +293,7 @@ struct WaveModel {
       endp = ap + fpr + (p == h.maxpos ? bonus : 0);
     }
     const bool hit = DEC ? vv < endp : sp == in;
-    if (hit) {
+    if (SCPR_LIKELY(hit)) {
       ofr = (u32)(endp - ap) << sh;
       ocf = (u32)ap << sh;
       const int fmax = (int)sm_fq(rdl(w, h.maxpos));
@@ -296,7 +301,7 @@ struct WaveModel {
       w += add;
       tot += kStepSmall;
       if (p != h.maxpos && fpr + kStepSmall > fmax) h.maxpos = p;
-      if (tot + kStepSmall > kProbScale) {  // rescale, :186-193
+      if (SCPR_UNLIKELY(tot + kStepSmall > kProbScale)) {  // rescale, :186-193
         const int fq = (int)sm_fq(w);
         tot = small_pack(w, (int)sm_sym(w), fq - (fq >> 1), d);
       }
@@ -499,7 +504,7 @@ struct WaveDec : WaveModel {
   template <int SEC>
   __device__ __forceinline__ void stamp() {
     const u64 t = __builtin_readcyclecounter();
-    prof[SEC] += t - prof_last;
+    if (prof_last) prof[SEC] += t - prof_last;
     prof_last = t;
   }
 #else
@@ -507,7 +512,7 @@ struct WaveDec : WaveModel {
   __device__ __forceinline__ void stamp() {}
 #endif
   __device__ __forceinline__ void need(int k) {
-    while (nb < k) {
+    while (SCPR_UNLIKELY(nb < k)) {
       buf |= (u64)nextw << (8 * nb);
       nb += 4;
       wpos++;
@@ -532,10 +537,10 @@ struct WaveDec : WaveModel {
     u32 hi = x >> kProbBits;
     asm("s_mul_i32 %0, %1, %2" : "=s"(hi) : "s"(hi), "s"(fr));  // the state is wave-uniform: keep it on the scalar unit
     x = hi + (v - cf);
-    while (x < kRansL) x = (x << 8) | take_byte();
+    while (SCPR_UNLIKELY(x < kRansL)) x = (x << 8) | take_byte();
   }
   __device__ __forceinline__ void count() {  // screencap.h:327-331
-    if (++ndec == kBlockEntries) {
+    if (SCPR_UNLIKELY(++ndec == kBlockEntries)) {
       x = take_u32();
       ndec = 0;
     }
@@ -648,7 +653,7 @@ struct WaveDec : WaveModel {
     const int tot0 = (int)rfl(et);
     int sym;
     u32 s;
-    if (rfl(e1) >= lim) {  // cum of symbol 64 is above v
+    if (SCPR_LIKELY(rfl(e1) >= lim)) {  // cum of symbol 64 is above v
       sym = __builtin_popcountll(__ballot(e0 < lim)) - 1;
       s = rdl(e0, sym);
     } else {
@@ -662,7 +667,7 @@ struct WaveDec : WaveModel {
       asm volatile("ds_add_u32 %0, %2\n\tds_add_u32 %1, %2" ::"v"(a1), "v"(a2), "v"((u32)kStepDense) : "memory");
     }
     advance(s >> 16, s & 0xFFFF, v);
-    if (tot0 + 2 * kStepDense > kProbScale) {  // rebuild from the counts, ans_contexts.h:1075-1090
+    if (SCPR_UNLIKELY(tot0 + 2 * kStepDense > kProbScale)) {  // rebuild from the counts, ans_contexts.h:1075-1090
       wave_fence();
       u32* cnt = L.fx.ncnt[t];
       int base = 0, ns = 0;
@@ -694,7 +699,7 @@ struct WaveDec : WaveModel {
     const int tot = (int)rdl(pcnt, tl) + kStepDense;
     pcnt += (lane == own || lane == tl) ? (u32)kStepDense : 0u;
     advance(s >> 16, s & 0xFFFF, v);
-    if (tot + kStepDense > kProbScale) {
+    if (SCPR_UNLIKELY(tot + kStepDense > kProbScale)) {
       const bool in = (lane >> 3) == t && (lane & 7) < 6;
       const int c = in ? (int)pcnt : 0;
       const int inc = wave_incl_scan(c);
@@ -792,7 +797,7 @@ struct WaveDec : WaveModel {
     u32x4 hw;
     asm volatile("ds_read_b128 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=v"(hw), "=v"(w) : "v"(ra), "v"(ea) : "memory");
     const int tag = (int)rfl(hw.w);
-    if (tag != ctxid + 1) {
+    if (SCPR_UNLIKELY(tag != ctxid + 1)) {
       if (lane < DECREC_WORDS) {
         if (tag) gstates[tag - 1].w[lane] = r[lane];
         r[lane] = lane == 3 ? (u32)(ctxid + 1) : gstates[ctxid].w[lane];
@@ -816,17 +821,20 @@ struct WaveDec : WaveModel {
     u32 w;
     u32* r = record(ctxid, h, w);
     int c;
-    if (h.kind < 4) {
+    if (SCPR_UNLIKELY(h.kind < 4)) {
       c = (int)take_byte();
       note_raw(r, h, c, w);
     } else {
       u32 fr, cf;
       const u32 v = x & (kProbScale - 1);
-      c = h.kind <= 5 ? small_op<true>(r, h, w, (int)v, fr, cf) : dense_op<true>(r, h, (int)v, fr, cf);
+      if (SCPR_LIKELY(h.kind <= 5)) c = small_op<true>(r, h, w, (int)v, fr, cf);
+      else c = dense_op<true>(r, h, (int)v, fr, cf);
       advance(cf, fr, v);
     }
     wave_fence();
-    if (lane < 16 && (h.kind == 4 || h.kind == 5)) r[4 + lane] = w;
+    if (SCPR_LIKELY(h.kind == 4 || h.kind == 5)) {
+      if (lane < 16) r[4 + lane] = w;
+    }
     if (lane == 0) *(uint2*)r = make_uint2(pack0(h), pack1(h));
     if (lane == 0) r[2] = h.dense;
     wave_fence();
@@ -899,10 +907,10 @@ __device__ __forceinline__ void decode_intra_frame(WaveDec& D, const Geom& g, u8
   //   header phase (p <= W): literal + run length over the first row and pixel (0,1)  (:421-438)
   //   body: pixel type, literal if type 0, run length                                  (:443-494)
   int p = 0, t = 0;  // next pixel (raster index), type of the previous run
-  while (p < NP && !D.bad) {
+  while (SCPR_LIKELY(p < NP && !D.bad)) {
     const bool hdr = p <= W;
     D.stamp<4>();
-    if (!hdr) t = D.fixed_p(t);
+    if (SCPR_LIKELY(!hdr)) t = D.fixed_p(t);
     D.stamp<0>();
     u32 px = lastpix;
     if (t == 0) {  // DecodeRGB, screencap.cpp:662-679: contexts are the two previous bytes >> 2 (MAKECX1, screencap.h:35-36)
@@ -919,45 +927,55 @@ __device__ __forceinline__ void decode_intra_frame(WaveDec& D, const Geom& g, u8
     }
     const int n = D.fixed_n(t);
     D.stamp<2>();
-    if ((u32)(n - 1) >= (u32)((hdr ? W + 1 : NP) - p)) {  // empty, or longer than what is left (of the header row)
+    if (SCPR_UNLIKELY((u32)(n - 1) >= (u32)((hdr ? W + 1 : NP) - p))) {  // empty, or longer than what is left (of the header row)
       D.bad = true;
       break;
     }
     if (t <= 1) {  // literal, or copy of the previous pixel: every pixel of the run has the same value
-      for (int q = lane; q < n; q += 64) ring[(u32)(p + q) & pm] = px;
+      for (int q0 = 0; q0 < n; q0 += 64)
+        if (q0 + lane < n) ring[(u32)(p + q0 + lane) & pm] = px;
       lastpix = px;
-    } else if (t == 3) {
-      D.bad = true;
-      break;
-    } else {
+    } else if (SCPR_LIKELY(t == 2 || (t == 5 && pad == 0))) {  // copy of the pixel above (2) or above-left (5)
+      const u32 back = t == 2 ? (u32)W : (u32)W + 1u;
       u32 v = 0;
       int m = 0;
       for (int q0 = 0; q0 < n; q0 += chunk) {
         wave_fence();  // pixels written by other lanes are read here (a run may be longer than a row)
         m = min(chunk, n - q0);
         const u32 pq = (u32)(p + q0 + lane);
-        if (t == 2) {  // copy of the pixel above
-          v = ring[(pq - W) & pm];
-        } else {
-          u32 tl = ring[(pq - W - 1) & pm];
-          if (pad) {  // in column 0 "above-left" is the bytes just before the row above in memory: the tail of the
-                      // last pixel two rows up followed by that row's padding (screencap.cpp:881)
-            int xq = (int)pq - rowbase;
-            while (xq >= W) xq -= W;
-            if (xq == 0) tl >>= 8 * pad;
-          }
-          if (t == 5) {
-            v = tl;
-          } else {  // gradient: previous + top - topleft, a running sum along the run (mod 256 per channel)
-            const u32 tp = ring[(pq - W) & pm];
-            int d0 = (int)(tp & 255) - (int)(tl & 255), d1 = (int)((tp >> 8) & 255) - (int)((tl >> 8) & 255), d2 = (int)((tp >> 16) & 255) - (int)((tl >> 16) & 255);
-            if (lane >= m) d0 = d1 = d2 = 0;
-            d0 = wave_incl_scan(d0);
-            d1 = wave_incl_scan(d1);
-            d2 = wave_incl_scan(d2);
-            v = (u32)(((int)(lastpix & 255) + d0) & 255) | ((u32)(((int)((lastpix >> 8) & 255) + d1) & 255) << 8) | ((u32)(((int)((lastpix >> 16) & 255) + d2) & 255) << 16);
-            lastpix = rdl(v, m - 1);
-          }
+        v = ring[(pq - back) & pm];
+        if (lane < m) ring[pq & pm] = v;
+      }
+      wave_fence();
+      lastpix = rdl(v, m - 1);
+    } else if (SCPR_UNLIKELY(t == 3)) {
+      D.bad = true;
+      break;
+    } else {  // above-left with row padding in the way, or the gradient predictor
+      u32 v = 0;
+      int m = 0;
+      for (int q0 = 0; q0 < n; q0 += chunk) {
+        wave_fence();
+        m = min(chunk, n - q0);
+        const u32 pq = (u32)(p + q0 + lane);
+        u32 tl = ring[(pq - W - 1) & pm];
+        if (pad) {  // in column 0 "above-left" is the bytes just before the row above in memory: the tail of the
+                    // last pixel two rows up followed by that row's padding (screencap.cpp:881)
+          int xq = (int)pq - rowbase;
+          while (xq >= W) xq -= W;
+          if (xq == 0) tl >>= 8 * pad;
+        }
+        if (t == 5) {
+          v = tl;
+        } else {  // gradient: previous + top - topleft, a running sum along the run (mod 256 per channel)
+          const u32 tp = ring[(pq - W) & pm];
+          int d0 = (int)(tp & 255) - (int)(tl & 255), d1 = (int)((tp >> 8) & 255) - (int)((tl >> 8) & 255), d2 = (int)((tp >> 16) & 255) - (int)((tl >> 16) & 255);
+          if (lane >= m) d0 = d1 = d2 = 0;
+          d0 = wave_incl_scan(d0);
+          d1 = wave_incl_scan(d1);
+          d2 = wave_incl_scan(d2);
+          v = (u32)(((int)(lastpix & 255) + d0) & 255) | ((u32)(((int)((lastpix >> 8) & 255) + d1) & 255) << 8) | ((u32)(((int)((lastpix >> 16) & 255) + d2) & 255) << 16);
+          lastpix = rdl(v, m - 1);
         }
         if (lane < m) ring[pq & pm] = v;
       }
@@ -966,7 +984,7 @@ __device__ __forceinline__ void decode_intra_frame(WaveDec& D, const Geom& g, u8
     }
     D.stamp<3>();
     p += n;
-    if (p >= rowbase + W) {
+    if (SCPR_UNLIKELY(p >= rowbase + W)) {
       int done = flushed + 1;
       while ((done + 1) * W <= p) done++;
       flush_rows(done);

@@ -53,10 +53,12 @@ def gather_packets(dist, rank: int, world: int, payload: np.ndarray, sizes: np.n
     pad_p[: t_payload.numel()] = t_payload
     pad_s = torch.zeros(max_frames, dtype=torch.int64, device=t_payload.device)
     pad_s[: t_sizes.numel()] = t_sizes
-    gp = [torch.empty_like(pad_p) for _ in range(world)] if rank == 0 else None
-    gs = [torch.empty_like(pad_s) for _ in range(world)] if rank == 0 else None
-    dist.gather(pad_p, gp, dst=0)
-    dist.gather(pad_s, gs, dst=0)
+    # all_gather rather than gather: the one collective every backend (RCCL included) implements natively; the
+    # payload is the compressed stream (about 1 % of the raw frames), so the extra copies cost microseconds
+    gp = [torch.empty_like(pad_p) for _ in range(world)]
+    gs = [torch.empty_like(pad_s) for _ in range(world)]
+    dist.all_gather(gp, pad_p)
+    dist.all_gather(gs, pad_s)
     if rank != 0:
         return None, None
     out_p = torch.cat([gp[r][: int(metas[r][0])] for r in range(world)])
