@@ -747,22 +747,25 @@ struct RansBlock {
 // One lane per block of <= 131072 entries, processed last to first; bytes are
 // written backwards into the block's scratch (ransmt.h:116-134).  x / freq uses
 // the exact 32-bit reciprocal (rans_byte.h:171-240).
-// One coder entry, loop-free: the renormalisation emits at most two bytes (x < 2^31 and
-// x_max = freq << 19 >= 2^19), so both the count and the bytes follow from two compares.
-// `r` is the reciprocal of the entry's frequency (fetched ahead of the dependent chain).
+// One coder entry, loop-free.  The renormalisation emits at most two bytes (x < 2^31 and
+// x_max = freq << 19 >= 2^19): both are stored every time, as one 16-bit store just below the write
+// pointer, and the pointer moves by the number that count; what is left below it is overwritten by the
+// next entry (the block's scratch has room for two spare bytes).  The state update is ryg's
+// x + bias + (x / freq) * (4096 - freq) (rans_byte.h:199-240) with the exact 32-bit reciprocal, which also
+// covers freq = 1 (bias + 4095, quotient x - 1).  A raw byte (freq 0) is the same code with a limit no
+// state reaches and a zero multiplier.  `r` = reciprocal of the entry's frequency (fetched ahead of the chain).
 __device__ __forceinline__ void rans_put(u32& x, u8*& p, u32 v, const RansRcp r) {
   const u32 fr = v & 0xFFFF, cf = v >> 16;
-  const bool coded = fr != 0;
-  const u32 f1 = coded ? fr : 1u;
-  const u32 x_max = f1 << 19;  // ((L >> 12) << 8) * freq
-  const int n = coded ? (int)(x >= x_max) + (int)((x >> 8) >= x_max) : 0;
-  if (n >= 1) p[-1] = (u8)x;
-  if (n == 2) p[-2] = (u8)(x >> 8);
-  if (!coded) p[-1] = (u8)cf;  // raw byte (ransmt.h:128)
-  p -= coded ? n : 1;
+  const bool raw = fr == 0;
+  const u32 x_max = raw ? 0xFFFFFFFFu : fr << 19;  // ((L >> 12) << 8) * freq
+  const u32 n = (u32)(x >= x_max) + (u32)((x >> 8) >= x_max);
+  const u16 out = raw ? (u16)(cf << 8) : __builtin_bswap16((u16)x);  // the first byte out sits at the higher address
+  __builtin_memcpy(p - 2, &out, 2);
+  p -= n + (raw ? 1u : 0u);
   const u32 xs = x >> (8 * n);
-  const u32 q = f1 == 1 ? xs : (__umulhi(xs, r.rcp) >> r.shift);
-  x = coded ? (q << kProbBits) + (xs - q * f1) + cf : x;
+  const u32 q = __umulhi(xs, r.rcp) >> r.shift;
+  const u32 cmpl = raw ? 0u : (u32)kProbScale - fr, bias = raw ? 0u : cf + r.pad;
+  x = xs + bias + q * cmpl;
 }
 __global__ __launch_bounds__(64) void k_rans(const u32* __restrict__ entries, const RansBlock* __restrict__ blocks, int nblocks, const RansRcp* __restrict__ rcp_g,
                                              u8* __restrict__ scratch, u32* __restrict__ blksize) {
@@ -779,7 +782,7 @@ __global__ __launch_bounds__(64) void k_rans(const u32* __restrict__ entries, co
   int i = (int)blk.len;
   for (int r = i & 15; r > 0; r--) {  // ragged top
     const u32 v = e[--i];
-    rans_put(x, p, v, lrcp[(v & 0xFFFF) ? (v & 0xFFFF) : 1]);
+    rans_put(x, p, v, lrcp[v & 0xFFFF]);  // entry 0 of the table is that of freq 1
   }
   while (i > 0) {  // 16 entries per trip: neither the entry loads nor the reciprocal lookups depend on the coder state
     i -= 16;
@@ -789,7 +792,7 @@ __global__ __launch_bounds__(64) void k_rans(const u32* __restrict__ entries, co
     const u32 v[16] = {v4[0].x, v4[0].y, v4[0].z, v4[0].w, v4[1].x, v4[1].y, v4[1].z, v4[1].w, v4[2].x, v4[2].y, v4[2].z, v4[2].w, v4[3].x, v4[3].y, v4[3].z, v4[3].w};
     RansRcp r[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) r[k] = lrcp[(v[k] & 0xFFFF) ? (v[k] & 0xFFFF) : 1];
+    for (int k = 0; k < 16; k++) r[k] = lrcp[v[k] & 0xFFFF];
 #pragma unroll
     for (int k = 15; k >= 0; k--) rans_put(x, p, v[k], r[k]);
   }

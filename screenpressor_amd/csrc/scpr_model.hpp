@@ -573,11 +573,11 @@ enum : uint32_t { kRansL = 1u << 23 };
 struct RansRcp {
   uint32_t rcp;    // ceil(2^(31+shift) / freq) low 32 bits
   uint16_t shift;  // ceil(log2(freq)) - 1 (0 for freq <= 2)
-  uint16_t pad;
+  uint16_t pad;    // 4095 for freq 1 (its quotient comes out as x - 1), else 0: added to the entry's start
 };
 SCPR_HD RansRcp rans_rcp(uint32_t freq) {
   RansRcp r;
-  r.pad = 0;
+  r.pad = freq < 2 ? 4095 : 0;
   if (freq < 2) {
     r.rcp = ~0u;
     r.shift = 0;
