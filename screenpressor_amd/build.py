@@ -12,8 +12,9 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 LIB = os.path.join(PKG, "libscpr_amd.so")
 HIP_SRC = os.path.join(PKG, "csrc", "scpr_amd.hip")
+HOST_SRC = [os.path.join(PKG, "csrc", "scpr_driver.cpp"), os.path.join(PKG, "csrc", "scpr_avi.cpp")]  # host-only policy / container code
 HIP_DEPS = [os.path.join(PKG, "csrc", f) for f in sorted(os.listdir(os.path.join(PKG, "csrc")))] + [
-    os.path.join(ROOT, "include", "scpr_amd.h"), os.path.abspath(__file__)]
+    os.path.join(ROOT, "include", f) for f in sorted(os.listdir(os.path.join(ROOT, "include")))] + [os.path.abspath(__file__)]
 
 
 def _stale(out: str, deps: list[str]) -> bool:
@@ -25,7 +26,7 @@ def build_hip(force: bool = False) -> str:
     if force or _stale(LIB, HIP_DEPS):
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-strict-aliasing", "-fPIC", "-shared", "-Wno-unused-result",
-               "-o", LIB, HIP_SRC]
+               "-o", LIB, HIP_SRC] + HOST_SRC
         subprocess.check_call(cmd)
     return LIB
 

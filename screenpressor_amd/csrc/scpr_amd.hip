@@ -411,6 +411,8 @@ static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int n
   if (Mtot)
     hipLaunchKernelGGL(k_misc_chain, dim3(MC_COUNT, ngens), dim3(64), 0, st, c->misc.as<u32>(), c->miscpos.as<u32>(), c->miscranges.as<MiscRange>(), ngens, load_first ? 1 : 0,
                        c->misc_persist.as<FixedPersist>(), c->entries.as<u32>());
+  else if (!(load_first && ngens == 1))  // a new generation without any P-frame symbol: its P-frame models are the renewed ones, not the kept ones
+    HIPCHK(hipMemsetAsync(c->misc_persist.p, 0, MC_COUNT * sizeof(FixedPersist), st));
   stage_end(c, ST_FIXED);
   HIPCHK(hipStreamSynchronize(st));  // rg / mr are host memory
   stage_begin(c, ST_COLOUR);
