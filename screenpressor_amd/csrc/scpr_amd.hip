@@ -103,6 +103,7 @@ struct scpr_codec {
   bool live_valid = false;   // a generation is live (a key frame or flat frame has been coded)
   bool live_has_state = false;  // ... and it has coded symbols (a flat frame renews the models without coding any)
   u32 live_stamp = 0, next_stamp = 1;
+  int live_buf = 0;  // which half of fixed_persist / misc_persist / colour_persist holds the live generation
   size_t arena_used_bound = 0;  // upper bound of dense tables held by the live generation
   // decoder side of the same
   DevBuf decgops, decfixed, dec_fixed_persist, dec_colour_persist;
@@ -206,18 +207,20 @@ static int ensure_codec(scpr_codec* c, int version) {  // CreateCodec + CScreenC
     HIPCHK(c->miscranges.reserve(ns * sizeof(MiscRange)));
     HIPCHK(c->mvs.reserve(nblk * 4));
     HIPCHK(hipMemsetAsync(c->mvs.p, 0, nblk * 4, c->stream));  // calloc'd in the reference (screencap.cpp:96-97), never reset
-    HIPCHK(c->fixed_persist.reserve(12 * sizeof(FixedPersist)));
-    HIPCHK(c->misc_persist.reserve(MC_COUNT * sizeof(FixedPersist)));
-    HIPCHK(hipMemsetAsync(c->fixed_persist.p, 0, 12 * sizeof(FixedPersist), c->stream));
-    HIPCHK(hipMemsetAsync(c->misc_persist.p, 0, MC_COUNT * sizeof(FixedPersist), c->stream));
-    HIPCHK(c->colour_persist.reserve((size_t)NCOLCTX * sizeof(ColState)));
-    HIPCHK(hipMemsetAsync(c->colour_persist.p, 0, (size_t)NCOLCTX * sizeof(ColState), c->stream));
+    // two copies of everything the chains keep between calls (see k_fixed_chain: a call with several generations reads one, writes the other)
+    HIPCHK(c->fixed_persist.reserve(2 * 12 * sizeof(FixedPersist)));
+    HIPCHK(c->misc_persist.reserve(2 * MC_COUNT * sizeof(FixedPersist)));
+    HIPCHK(hipMemsetAsync(c->fixed_persist.p, 0, 2 * 12 * sizeof(FixedPersist), c->stream));
+    HIPCHK(hipMemsetAsync(c->misc_persist.p, 0, 2 * MC_COUNT * sizeof(FixedPersist), c->stream));
+    HIPCHK(c->colour_persist.reserve(2 * (size_t)NCOLCTX * sizeof(ColState)));
+    HIPCHK(hipMemsetAsync(c->colour_persist.p, 0, 2 * (size_t)NCOLCTX * sizeof(ColState), c->stream));
   }
   c->live_valid = false;
   c->dec_live = false;
   c->live_has_state = false;
   c->live_stamp = 0;
   c->next_stamp = 1;
+  c->live_buf = 0;
   c->arena_used_bound = 0;
   HIPCHK(c->arena_top.reserve(16));
   HIPCHK(c->err.reserve(64));
@@ -406,21 +409,23 @@ static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int n
   HIPCHK(hipMemcpyAsync(c->ranges.p, rg.data(), ngens * sizeof(GenRange), hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(c->miscranges.p, mr.data(), ngens * sizeof(MiscRange), hipMemcpyHostToDevice, st));
   stage_begin(c, ST_FIXED);
+  const int buf_in = c->live_buf, buf_out = ngens > 1 ? 1 - c->live_buf : c->live_buf;
   hipLaunchKernelGGL(k_fixed_chain, dim3(ngens), dim3(768), 0, st, c->runs.as<u32>(), c->runpos.as<u32>(), c->ranges.as<GenRange>(), ngens, load_first ? 1 : 0,
-                     c->fixed_persist.as<FixedPersist>(), c->entries.as<u32>());
+                     c->fixed_persist.as<FixedPersist>() + buf_in * 12, c->fixed_persist.as<FixedPersist>() + buf_out * 12, c->entries.as<u32>());
   if (Mtot)
     hipLaunchKernelGGL(k_misc_chain, dim3(MC_COUNT, ngens), dim3(64), 0, st, c->misc.as<u32>(), c->miscpos.as<u32>(), c->miscranges.as<MiscRange>(), ngens, load_first ? 1 : 0,
-                       c->misc_persist.as<FixedPersist>(), c->entries.as<u32>());
+                       c->misc_persist.as<FixedPersist>() + buf_in * MC_COUNT, c->misc_persist.as<FixedPersist>() + buf_out * MC_COUNT, c->entries.as<u32>());
   else if (!(load_first && ngens == 1))  // a new generation without any P-frame symbol: its P-frame models are the renewed ones, not the kept ones
-    HIPCHK(hipMemsetAsync(c->misc_persist.p, 0, MC_COUNT * sizeof(FixedPersist), st));
+    HIPCHK(hipMemsetAsync(c->misc_persist.as<FixedPersist>() + buf_out * MC_COUNT, 0, MC_COUNT * sizeof(FixedPersist), st));
   stage_end(c, ST_FIXED);
   HIPCHK(hipStreamSynchronize(st));  // rg / mr are host memory
   stage_begin(c, ST_COLOUR);
   {
     Arena ar{c->arena.as<DenseTab>(), c->arena_top.as<u32>(), (u32)arena_cap, c->err.as<u32>()};
     const u32 stamp_out = (load_first && ngens == 1) ? c->live_stamp : c->next_stamp++;
-    ChainPersist cp{c->colour_persist.as<ColState>(), c->live_stamp, stamp_out, load_first ? 1 : 0, ngens};
+    ChainPersist cp{c->colour_persist.as<ColState>() + (size_t)buf_in * NCOLCTX, c->colour_persist.as<ColState>() + (size_t)buf_out * NCOLCTX, c->live_stamp, stamp_out, load_first ? 1 : 0, ngens};
     c->live_stamp = stamp_out;
+    c->live_buf = buf_out;
     const u32 cap = (u32)std::min<size_t>(nchains, Ctot + 1);
     HIPCHK(c->chainlists.reserve((size_t)cap * 8 + 64));
     HIPCHK(c->chaincounts.reserve(16));
@@ -872,7 +877,7 @@ int scpr_debug_colour_chain(int device, const uint8_t* syms, int n, int f0, uint
   HIPCHK(hipMemcpy(dn.p, cnt, 4, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(dt.p, zero, 8, hipMemcpyHostToDevice));
   Arena ar{da.as<DenseTab>(), dt.as<u32>(), (u32)acap, dt.as<u32>() + 1};
-  ChainPersist cp{nullptr, 0, 0, 0, 0};  // nothing loaded, nothing kept
+  ChainPersist cp{nullptr, nullptr, 0, 0, 0, 0};  // nothing loaded, nothing kept
   hipLaunchKernelGGL(k_colour_chain_w, dim3(1), dim3(64), 0, 0, dk.as<u32>(), dv.as<u32>(), dc.as<u32>(), dl.as<u32>(), dn.as<u32>(), f0, ar, cp, de.as<u32>());
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpy(out, de.p, (size_t)n * 4, hipMemcpyDeviceToHost));

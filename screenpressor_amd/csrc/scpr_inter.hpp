@@ -31,6 +31,8 @@ __device__ __forceinline__ Rect binfo_rect(u32 v, int bx, int by) {
   r.y2 = by * 16 + (int)((v >> 16) & 15) + 1;
   return r;
 }
+// "no vector" in the per-frame dictionary: not a packed vector (components are within +-256; (-1,-1) packs to 0xFFFFFFFF)
+constexpr u32 MV_NONE = 0x7FFF7FFFu;
 __device__ __forceinline__ u32 mv_pack(int dx, int dy) { return ((u32)(dx & 0xFFFF)) | ((u32)(dy & 0xFFFF) << 16); }
 __device__ __forceinline__ int mv_x(u32 v) { return (int)(int16_t)(v & 0xFFFF); }
 __device__ __forceinline__ int mv_y(u32 v) { return (int)(int16_t)(v >> 16); }
@@ -232,7 +234,7 @@ __global__ __launch_bounds__(256) void k_mvdict(Geom g, const u32* __restrict__ 
   const int pi = blockIdx.x, tid = threadIdx.x;
   const int nbx = (g.W + 15) >> 4, nby = (g.H + 15) >> 4, nblocks = nbx * nby;
   for (int i = tid; i < 1024; i += 256) {
-    hkey[i] = 0xFFFFFFFFu;
+    hkey[i] = MV_NONE;
     hcnt[i] = 0;
   }
   __syncthreads();
@@ -243,8 +245,8 @@ __global__ __launch_bounds__(256) void k_mvdict(Geom g, const u32* __restrict__ 
       const u32 key = smv_to_mv(sv);
       u32 h = (key * 2654435761u) >> 22;
       for (int probe = 0; probe < 1024; probe++, h = (h + 1) & 1023) {
-        const u32 old = atomicCAS(&hkey[h], 0xFFFFFFFFu, key);
-        if (old == 0xFFFFFFFFu || old == key) {
+        const u32 old = atomicCAS(&hkey[h], MV_NONE, key);
+        if (old == MV_NONE || old == key) {
           atomicAdd(&hcnt[h], 1u);
           break;
         }
@@ -269,7 +271,7 @@ __global__ __launch_bounds__(256) void k_mvdict(Geom g, const u32* __restrict__ 
       __syncthreads();
     }
     if (tid == 0) {
-      dict[pi * MVDICT + k] = best[0] ? hkey[bidx[0]] : 0xFFFFFFFFu;
+      dict[pi * MVDICT + k] = best[0] ? hkey[bidx[0]] : MV_NONE;
       if (best[0]) hcnt[bidx[0]] = 0;
     }
     __syncthreads();
@@ -318,7 +320,7 @@ __global__ __launch_bounds__(64) void k_mvpretest(const u8* __restrict__ planes,
     bool bad = false;  // this row differs (or the candidate is unusable)
     if (changed) {
       const int x = r.x1 + mv_x(mv), y = r.y1 + mv_y(mv);
-      const bool inwin = mv != 0xFFFFFFFFu && x >= w.fx1 && x < w.fx2 && y >= w.fy1 && y < w.fy2;
+      const bool inwin = mv != MV_NONE && x >= w.fx1 && x < w.fx2 && y >= w.fy1 && y < w.fy2;
       if (!inwin) bad = true;
       else if (row < r.y2 - r.y1) bad = !same_row(cur, prv, g.S, r, x, y, row);
     }
@@ -690,7 +692,7 @@ struct MiscRange {
   u32 begin, end;
 };
 __global__ __launch_bounds__(64) void k_misc_chain(const u32* __restrict__ misc, const u32* __restrict__ miscpos, const MiscRange* __restrict__ ranges, int ngens, int load_first,
-                                                   FixedPersist* __restrict__ persist /* [MC_COUNT] */, u32* __restrict__ entries) {
+                                                   const FixedPersist* persist /* [MC_COUNT] */, FixedPersist* persist_out /* see k_fixed_chain */, u32* __restrict__ entries) {
   __shared__ u32 freq[512], cum[512], cnt[512];
   const int ctx = blockIdx.x, gen = blockIdx.y, lane = threadIdx.x;
   const int nsym = ctx == MC_BT ? 5 : (ctx >= MC_SXY && ctx < MC_SXY + 4) ? 16 : (ctx >= MC_MX) ? 512 : 256;
@@ -765,13 +767,13 @@ __global__ __launch_bounds__(64) void k_misc_chain(const u32* __restrict__ misc,
   }
   if (gen == ngens - 1) {  // the last generation of the call is the live one
     for (int j = lane; j < nsym; j += 64) {
-      persist[ctx].freq[j] = freq[j];
-      persist[ctx].cum[j] = cum[j];
-      persist[ctx].cnt[j] = cnt[j];
+      persist_out[ctx].freq[j] = freq[j];
+      persist_out[ctx].cum[j] = cum[j];
+      persist_out[ctx].cnt[j] = cnt[j];
     }
     if (lane == 0) {
-      persist[ctx].total = total;
-      persist[ctx].valid = 1;
+      persist_out[ctx].total = total;
+      persist_out[ctx].valid = 1;
     }
   }
 }

@@ -602,8 +602,11 @@ struct FixedPersist {  // one fixed-alphabet table as kept between calls (P-fram
   u32 freq[512], cum[512], cnt[512];
   int total, valid, pad0, pad1;
 };
+// persist_in / persist_out: the tables kept between calls.  They are the same array when the call has one
+// generation; with several, the first generation's workgroup reads while the last one's writes, so the
+// host hands out two arrays and swaps them.
 __global__ __launch_bounds__(768) void k_fixed_chain(const u32* __restrict__ runs, const u32* __restrict__ runpos, const GenRange* __restrict__ ranges, int ngens, int load_first,
-                                                     FixedPersist* __restrict__ persist /* [12] */, u32* __restrict__ entries) {
+                                                     const FixedPersist* persist /* [12] */, FixedPersist* persist_out, u32* __restrict__ entries) {
   // One workgroup per generation, one wave per model (cls 0..5 pixel types, 6..11 run lengths): the
   // twelve waves walk the same run list, so it is fetched into this CU's L1 once.  Each wave owns its
   // table; lanes of a wave talk through LDS in program order (wavefront fences only, no barriers).
@@ -694,13 +697,13 @@ __global__ __launch_bounds__(768) void k_fixed_chain(const u32* __restrict__ run
   if (gen == ngens - 1) {  // the last generation of the call is the live one
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     for (int j = lane; j < nsym; j += 64) {
-      persist[cls].freq[j] = freq[j];
-      persist[cls].cum[j] = cum[j];
-      persist[cls].cnt[j] = cnt[j];
+      persist_out[cls].freq[j] = freq[j];
+      persist_out[cls].cum[j] = cum[j];
+      persist_out[cls].cnt[j] = cnt[j];
     }
     if (lane == 0) {
-      persist[cls].total = total;
-      persist[cls].valid = 1;
+      persist_out[cls].total = total;
+      persist_out[cls].valid = 1;
     }
   }
 }

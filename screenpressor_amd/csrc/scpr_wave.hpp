@@ -1282,7 +1282,10 @@ __global__ __launch_bounds__(1024) void k_chain_lists(const u32* __restrict__ cs
 // set (LDS) and dense tables (arena) live in memory.  Entries are produced 64 at a
 // time and scattered to their stream positions.
 struct ChainPersist {
-  ColState* states;   // [NCOLCTX] records of the live generation (pad1 = generation stamp)
+  const ColState* states_in;  // [NCOLCTX] records of the live generation when the call started (pad1 = generation stamp)
+  ColState* states_out;       // where the last generation of this call leaves its records: the same array when the call
+                              // has one generation (a chain reads its record, then writes it), another one otherwise:
+                              // chains of the first and of the last generation of a context run concurrently
   u32 stamp_in;       // stamp of the live generation when the call started
   u32 stamp_out;      // stamp given to the last generation of this call
   int load_first;     // generation 0 of the call continues the live generation
@@ -1303,7 +1306,7 @@ __global__ __launch_bounds__(64) void k_colour_chain_w(const u32* __restrict__ s
     u32 T = kSmallNone;
     wave_fence();
     if (gen == 0 && cp.load_first) {  // continue the model of this context from the previous call
-      const u32* src = (const u32*)&cp.states[ctx];
+      const u32* src = (const u32*)&cp.states_in[ctx];
       const u32 w = lane < 16 ? src[lane] : 0;
       if (rdl(w, 3) == cp.stamp_in) {
         if (lane < 16) rec[lane] = w;
@@ -1339,7 +1342,7 @@ __global__ __launch_bounds__(64) void k_colour_chain_w(const u32* __restrict__ s
       M.store_header(rec, h);
       if (lane == 0) rec[3] = cp.stamp_out;
       wave_fence();
-      if (lane < 16) ((u32*)&cp.states[ctx])[lane] = rec[lane];
+      if (lane < 16) ((u32*)&cp.states_out[ctx])[lane] = rec[lane];
     }
   }
 }

@@ -210,3 +210,84 @@ def test_rgb16_and_loss_per_frame_api():
     assert got == want
     r, out = _codec(w, h, 16).DecompressFrame(got, ft)
     assert r == 1 and np.array_equal(out.reshape(h, pitch)[:, : w * 2], f[:, : w * 2])
+
+
+@pytest.mark.parametrize("seed,w,h", [(s, 96, 64) for s in range(1, 25)] + [(s, 100, 37) for s in range(25, 37)] + [(s, 33, 50) for s in range(37, 43)])
+def test_random_call_patterns_keep_cross_call_state(seed, w, h):
+    """The codec carries state from call to call (previous plane, every model, motion-vector memory,
+    flat-frame state, the loss mask).  Random streams — moving content, repeated frames, flat frames,
+    key-frame requests at random, loss changing on the way — cut into random mixtures of per-frame
+    and batch calls must give the oracle's packets, and decode (cut differently) to the oracle's frames."""
+    import torch
+    rng = np.random.default_rng(100 + seed)
+    n = 48
+    seq = DesktopSequence(w, h, seed=20 + seed, sparkles=30)
+    flat = [np.full((h, w, 4), 0, np.uint8), np.full((h, w, 4), 0, np.uint8)]
+    flat[0][..., :3] = (10, 200, 30)
+    flat[1][..., :3] = (250, 250, 250)
+    for f in flat:
+        f[..., 3] = 255
+    frames, want_key, loss = [], [], []
+    cur_loss = 0
+    for t in range(n):
+        k = rng.random()
+        if k < 0.55 or not frames:
+            frames.append(seq.frame(t))
+        elif k < 0.70:
+            frames.append(frames[-1].copy())          # unchanged
+        elif k < 0.85:
+            frames.append(flat[int(rng.integers(2))].copy())
+        else:
+            frames.append(seq.frame(int(rng.integers(0, t + 1))))  # jump back: big change
+        want_key.append(t == 0 or rng.random() < 0.2)
+        if rng.random() < 0.1:
+            cur_loss = int(rng.integers(0, 3))
+        loss.append(cur_loss)
+    # oracle: one frame at a time
+    ora = O.OracleCodec(w, h, 32)
+    ref = [ora.compress(f, key=k, loss=l) for f, k, l in zip(frames, want_key, loss)]
+    # product: random cuts; a batch has one loss value, so cuts also fall where the loss changes
+    gpu = _codec(w, h)
+    got = []
+    i = 0
+    while i < n:
+        m = int(rng.integers(1, 8))
+        j = i + 1
+        while j < min(n, i + m) and loss[j] == loss[i]:
+            j += 1
+        if j - i == 1 and rng.random() < 0.5:
+            pkt, ft = gpu.CompressFrame(frames[i], 0 if want_key[i] else 1, loss=loss[i])
+            got.append((pkt, ft))
+        else:
+            dev = torch.from_numpy(np.stack(frames[i:j])).cuda().reshape(j - i, -1)
+            pk, sizes, fts = gpu.CompressBatch(dev, [0 if k else 1 for k in want_key[i:j]], loss=loss[i])
+            pk = pk.cpu().numpy()
+            o = 0
+            for s, ft in zip(sizes, fts):
+                got.append((pk[o:o + int(s)].tobytes(), ft))
+                o += int(s)
+        i = j
+    for t, ((gp, gf), (rp, rf)) in enumerate(zip(got, ref)):
+        assert gf == rf and gp == rp, (t, gf, rf, _first_diff(gp, rp), want_key[t], loss[t])
+    # decode: other random cuts, against the oracle's decoder
+    od = O.OracleCodec(w, h, 32)
+    gd = _codec(w, h)
+    i = 0
+    while i < n:
+        j = min(n, i + int(rng.integers(1, 8)))
+        if j - i == 1 and rng.random() < 0.5:
+            r, out = gd.DecompressFrame(ref[i][0], ref[i][1])
+            assert r == 1
+            outs = [out]
+        else:
+            blob = b"".join(p for p, _ in ref[i:j])
+            dev = torch.from_numpy(np.frombuffer(blob, np.uint8).copy()).cuda()
+            r, out = gd.DecompressBatch(dev, [len(p) for p, _ in ref[i:j]], [ft for _, ft in ref[i:j]])
+            assert r == j - i
+            outs = list(out.cpu().numpy().reshape(j - i, -1))
+        for t, o in zip(range(i, j), outs):
+            rr, ro = od.decompress(ref[t][0], ref[t][1])
+            assert rr == 1 and np.array_equal(np.asarray(o).reshape(-1), ro), t
+            if loss[t] == 0 and all(l == 0 for l in loss[:t + 1]):
+                assert np.array_equal(np.asarray(o).reshape(h, w, 4)[..., :3], frames[t][..., :3]), t
+        i = j
