@@ -537,7 +537,14 @@ struct WaveDec : WaveModel {
     u32 hi = x >> kProbBits;
     asm("s_mul_i32 %0, %1, %2" : "=s"(hi) : "s"(hi), "s"(fr));  // the state is wave-uniform: keep it on the scalar unit
     x = hi + (v - cf);
-    while (SCPR_UNLIKELY(x < kRansL)) x = (x << 8) | take_byte();
+    int refills = 0;
+    while (SCPR_UNLIKELY(x < kRansL)) {
+      x = (x << 8) | take_byte();
+      if (SCPR_UNLIKELY(++refills > 4)) {  // a valid state needs at most three bytes (rans_byte.h:137-144); a damaged stream
+        bad = true;                        // (state 0 over a tail of zero bytes) would refill forever
+        x = kRansL;
+      }
+    }
   }
   __device__ __forceinline__ void count() {  // screencap.h:327-331
     if (SCPR_UNLIKELY(++ndec == kBlockEntries)) {

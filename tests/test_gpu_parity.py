@@ -291,3 +291,31 @@ def test_random_call_patterns_keep_cross_call_state(seed, w, h):
             if loss[t] == 0 and all(l == 0 for l in loss[:t + 1]):
                 assert np.array_equal(np.asarray(o).reshape(h, w, 4)[..., :3], frames[t][..., :3]), t
         i = j
+
+
+def test_corrupt_streams_are_survived():
+    """Damaged packets (flipped bytes, truncation) must come back as an error or as some picture — never a
+    fault or a hang — and must not wedge the codec: a clean key frame decodes right afterwards."""
+    rng = np.random.default_rng(77)
+    w, h = 64, 48
+    seq = DesktopSequence(w, h, seed=5, sparkles=20)
+    ora = O.OracleCodec(w, h, 32)
+    key, _ = ora.compress(seq.frame(0), key=True)
+    pfr, _ = ora.compress(seq.frame(1), key=False)
+    gpu = _codec(w, h)
+    for trial in range(40):
+        r, _ = gpu.DecompressFrame(key, 0)
+        assert r == 1
+        which = trial % 4
+        pkt = bytearray(key if which < 2 else pfr)
+        if which % 2 == 0:
+            for _ in range(int(rng.integers(1, 4))):
+                pkt[int(rng.integers(1, len(pkt)))] ^= int(rng.integers(1, 256))
+        else:
+            pkt = pkt[: int(rng.integers(2, len(pkt)))]
+        try:
+            gpu.DecompressFrame(bytes(pkt), 0 if which < 2 else 1)
+        except RuntimeError:
+            pass  # SCPR_E_STREAM / SCPR_E_PARAM surface as exceptions in the Python mirror
+    r, out = gpu.DecompressFrame(key, 0)
+    assert r == 1 and np.array_equal(out.reshape(h, w, 4), seq.frame(0))
