@@ -517,6 +517,9 @@ struct WaveDec : WaveModel {
       nb += 4;
       wpos++;
       nextw = fetch_word(wpos);
+      // Past the end of the packet buffer the reader supplies 0xFF bytes: a damaged stream can run off the end,
+      // and the refill loop of the coder (advance) must still terminate (on zero bytes it would not).
+      if (SCPR_UNLIKELY(wpos > wmax)) nextw = 0xFFFFFFFFu;
     }
   }
   __device__ __forceinline__ u32 take_byte() {
@@ -537,14 +540,7 @@ struct WaveDec : WaveModel {
     u32 hi = x >> kProbBits;
     asm("s_mul_i32 %0, %1, %2" : "=s"(hi) : "s"(hi), "s"(fr));  // the state is wave-uniform: keep it on the scalar unit
     x = hi + (v - cf);
-    int refills = 0;
-    while (SCPR_UNLIKELY(x < kRansL)) {
-      x = (x << 8) | take_byte();
-      if (SCPR_UNLIKELY(++refills > 4)) {  // a valid state needs at most three bytes (rans_byte.h:137-144); a damaged stream
-        bad = true;                        // (state 0 over a tail of zero bytes) would refill forever
-        x = kRansL;
-      }
-    }
+    while (SCPR_UNLIKELY(x < kRansL)) x = (x << 8) | take_byte();  // ends on any input: past the packets the reader supplies 0xFF bytes
   }
   __device__ __forceinline__ void count() {  // screencap.h:327-331
     if (SCPR_UNLIKELY(++ndec == kBlockEntries)) {
