@@ -539,7 +539,7 @@ int64_t scpr_compress_batch(scpr_codec* c, const void* d_frames, int nframes, in
     HIPCHK(hipMemsetAsync(d_nonflat, 0, (size_t)n * 8, st));
     stage_begin(c, ST_PACK);
     if (c->bpp == 4) {
-      dim3 gr((g.H * ((g.W + 3) >> 2) + 255) / 256, n);
+      dim3 gr((g.H * ((g.W + 3) >> 2) + 256 * PACK_ITEMS - 1) / (256 * PACK_ITEMS), n);
       hipLaunchKernelGGL(k_pack32, gr, dim3(256), 0, st, src, c->planes.as<u8>(), g, d_nonflat, d_first);
     } else if (c->bpp == 3) {
       dim3 gr((g.H * (g.S >> 2) + 255) / 256, n);
@@ -779,7 +779,7 @@ int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* 
     stage_begin(c, ST_UNPACK);
     u8* out = (u8*)d_frames_out + (size_t)f0 * pitch * g.H;
     if (c->bpp == 4) {
-      dim3 gr((g.H * ((g.W + 3) >> 2) + 255) / 256, n);
+      dim3 gr((g.H * ((g.W + 3) >> 2) + 256 * PACK_ITEMS - 1) / (256 * PACK_ITEMS), n);
       hipLaunchKernelGGL(k_unpack32, gr, dim3(256), 0, st, c->planes.as<u8>(), out, g, pitch);
     } else {
       dim3 gr((g.H * g.W + 255) / 256, n);

@@ -88,11 +88,39 @@ __device__ __forceinline__ bool pack32_item(const u8* __restrict__ src, u8* __re
   if (room > 8) o[2] = (c >> 16) | (d << 8);
   return diff;
 }
+constexpr int PACK_ITEMS = 8;  // quads per thread: a workgroup per 256 quads is bound by the dispatcher, not by HBM
 __global__ __launch_bounds__(256) void k_pack32(const u8* __restrict__ src, u8* __restrict__ planes, Geom g, u32* flat, u32* first) {
+  __shared__ __attribute__((aligned(16))) u32 stage[4][192];  // per wave: the 768 output bytes of its 64 pixel quads
   const int f = blockIdx.y, G = (g.W + 3) >> 2;
-  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int total = g.H * G;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const u8* fsrc = src + (size_t)f * g.W * g.H * 4;
   bool diff = false;
-  if (idx < g.H * G) diff = pack32_item(src, planes, g, f, idx, G, first);
+  for (int it = 0; it < PACK_ITEMS; it++) {
+    const int idx = (blockIdx.x * PACK_ITEMS + it) * 256 + threadIdx.x;
+    const int wave0 = idx & ~63;
+    if ((g.W & 3) == 0 && wave0 + 64 <= total) {
+      // Rows are whole quads and carry no padding: the plane is one contiguous run of 12-byte quads, so the
+      // wave's output is 768 contiguous bytes: the quads go through LDS and leave as 16-byte stores from 48 lanes.
+      const uint4 v = ((const uint4*)fsrc)[idx];
+      const u32 px0 = *(const u32*)fsrc & 0xFFFFFFu;
+      const u32 a = v.x & 0xFFFFFFu, b = v.y & 0xFFFFFFu, c = v.z & 0xFFFFFFu, d = v.w & 0xFFFFFFu;
+      diff |= a != px0 || b != px0 || c != px0 || d != px0;
+      if (idx == 0) first[f] = px0;
+      u32* st = stage[wv];
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the previous trip's reads are done (same wave: LDS is in order)
+      st[3 * lane] = a | (b << 24);
+      st[3 * lane + 1] = (b >> 8) | (c << 16);
+      st[3 * lane + 2] = (c >> 16) | (d << 8);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // other lanes' words are read below
+      if (lane < 48) {
+        const uint4 o = ((const uint4*)st)[lane];
+        ((uint4*)(planes + (size_t)f * g.plane_stride + (size_t)wave0 * 12))[lane] = o;
+      }
+    } else if (idx < total) {
+      diff |= pack32_item(src, planes, g, f, idx, G, first);
+    }
+  }
   // flat detection: one relaxed L2 read and at most one atomic per wave
   if (__ballot(diff) && lane_id() == 0 && __hip_atomic_load(&flat[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) atomicOr(&flat[f], 1u);
 }
@@ -156,19 +184,26 @@ __global__ __launch_bounds__(256) void k_loss(u8* planes, Geom g, const int* slo
 
 // plane -> RGB32 with alpha 255 (screencap.cpp:1711-1725), 4 pixels per lane
 __global__ __launch_bounds__(256) void k_unpack32(const u8* __restrict__ planes, u8* __restrict__ dst, Geom g, int pitch) {
-  const int f = blockIdx.y, G = (g.W + 3) >> 2;
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= g.H * G) return;
-  const int y = idx / G, gx = idx - y * G;
-  const u32* s = (const u32*)(planes + (size_t)f * g.plane_stride + (size_t)y * g.S) + gx * 3;
-  const int room = g.S - gx * 12;
-  u32 w0 = s[0], w1 = room > 4 ? s[1] : 0, w2 = room > 8 ? s[2] : 0;
-  u32* o = (u32*)(dst + (size_t)f * pitch * g.H + (size_t)y * pitch) + gx * 4;
-  const int nv = min(4, g.W - gx * 4);
-  o[0] = (w0 & 0xFFFFFFu) | 0xFF000000u;
-  if (nv > 1) o[1] = ((w0 >> 24) | ((w1 & 0xFFFFu) << 8)) | 0xFF000000u;
-  if (nv > 2) o[2] = ((w1 >> 16) | ((w2 & 0xFFu) << 16)) | 0xFF000000u;
-  if (nv > 3) o[3] = (w2 >> 8) | 0xFF000000u;
+  const int f = blockIdx.y, G = (g.W + 3) >> 2, total = g.H * G;
+  for (int it = 0; it < PACK_ITEMS; it++) {  // several quads per thread (see k_pack32)
+    const int idx = (blockIdx.x * PACK_ITEMS + it) * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int y = idx / G, gx = idx - y * G;
+    const u32* s = (const u32*)(planes + (size_t)f * g.plane_stride + (size_t)y * g.S) + gx * 3;
+    const int room = g.S - gx * 12;
+    u32 w0 = s[0], w1 = room > 4 ? s[1] : 0, w2 = room > 8 ? s[2] : 0;
+    u32* o = (u32*)(dst + (size_t)f * pitch * g.H + (size_t)y * pitch) + gx * 4;
+    const int nv = min(4, g.W - gx * 4);
+    if (nv == 4 && ((pitch | (int)(size_t)dst) & 15) == 0) {  // rows and base 16-byte aligned: one store
+      *(uint4*)o = make_uint4((w0 & 0xFFFFFFu) | 0xFF000000u, ((w0 >> 24) | ((w1 & 0xFFFFu) << 8)) | 0xFF000000u, ((w1 >> 16) | ((w2 & 0xFFu) << 16)) | 0xFF000000u,
+                              (w2 >> 8) | 0xFF000000u);
+    } else {
+      o[0] = (w0 & 0xFFFFFFu) | 0xFF000000u;
+      if (nv > 1) o[1] = ((w0 >> 24) | ((w1 & 0xFFFFu) << 8)) | 0xFF000000u;
+      if (nv > 2) o[2] = ((w1 >> 16) | ((w2 & 0xFFu) << 16)) | 0xFF000000u;
+      if (nv > 3) o[3] = (w2 >> 8) | 0xFF000000u;
+    }
+  }
 }
 // plane -> RGB24 rows with the caller's pitch / RGB16 (screencap.cpp:1726-1737)
 __global__ __launch_bounds__(256) void k_unpack_rows(const u8* __restrict__ planes, u8* __restrict__ dst, Geom g, int pitch, int bpp, int rs, int gs, int bs) {
