@@ -132,7 +132,8 @@ def main():
         traffic = None
         kernel_of = {"decode": "k_decode_gop_w", "rans": "k_rans", "colour_chain": "k_colour_chain_w", "pack": "k_pack32"}
         try:
-            rec = json.load(open(os.path.join(ROOT, "profiles", "r1d_pmc_hbm_traffic.json")))
+            import glob
+            rec = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")))[-1]))  # the latest recorded pass
             if args.workload == "keys" and N == 300 and (W, H) == (1920, 1080):
                 for kq in rec["kernels"]:
                     if kernel_of.get(dom, "?") in kq["kernel"]:
