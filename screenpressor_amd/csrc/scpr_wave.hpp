@@ -919,7 +919,7 @@ __device__ __forceinline__ void decode_intra_frame(WaveDec& D, const Geom& g, u8
     if (t == 0) {  // DecodeRGB, screencap.cpp:662-679: contexts are the two previous bytes >> 2 (MAKECX1, screencap.h:35-36)
       u32 a = (lastpix >> 18) & 63, b = (lastpix >> 10) & 63;
       px = 0;
-#pragma unroll 1
+#pragma unroll
       for (int plane = 0; plane < 3; plane++) {
         const u32 c = (u32)D.colour(plane * 4096 + (int)(a | (b << 6)));
         px |= c << (8 * plane);
