@@ -13,10 +13,10 @@
 //   (rocPRIM)         stable radix sort of colour symbols by (generation, plane, context)
 //   k_fixed_chain     one wave per fixed-alphabet context: epoch-parallel lookups,
 //                     LDS-resident table, wave prefix-scan rebuilds                  (FixedSizeRansCtx, ans_contexts.h:1054-1132)
-//   k_colour_chain    one lane per colour context: the 7-kind state machine         (Context, ans_contexts.cpp:34-50)
+//   k_colour_chain_w  one wave per colour context: the 7-kind state machine (scpr_wave.hpp) (Context, ans_contexts.cpp:34-50)
 //   k_rans            one lane per 131072-entry block: byte-wise rANS, reverse order (ransmt.h:116-134, rans_byte.h:59-102)
 //   k_offsets/k_gather  packet assembly
-// Decoder: k_decode_intra (one wave per key frame, serial symbol chain) + k_unpack*.
+// Decoder: k_decode_gop_w (scpr_wave.hpp: one wave per GOP, serial symbol chain) + k_unpack*.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -750,33 +750,7 @@ struct Arena {
   u32 cap;
   u32* err;
 };
-__device__ __forceinline__ DenseTab* arena_alloc(const Arena& a, ColState& st) {
-  u32 idx = atomicAdd(a.top, 1u);
-  if (idx >= a.cap) {
-    atomicOr(a.err, 1u);
-    idx = 0;
-  }
-  st.dense = idx;
-  return a.tabs + idx;
-}
-
-// one lane per (generation, plane, context): walks its symbols in stream order
-__global__ __launch_bounds__(64) void k_colour_chain(const u32* __restrict__ skeys, const u32* __restrict__ svals, const u32* __restrict__ cstart, int nchains,
-                                                     int f0, Arena arena, u32* __restrict__ entries) {
-  const int q = blockIdx.x * 64 + threadIdx.x;
-  if (q >= nchains) return;
-  const u32 start = cstart[q], len = cstart[q + 1] - start;
-  if (!len) return;
-  ColState st;
-  col_reset(st);
-  auto alloc = [&](ColState& s) { return arena_alloc(arena, s); };
-  auto tab = [&](ColState& s) { return arena.tabs + s.dense; };
-  for (u32 i = 0; i < len; i++) {
-    const u32 k = skeys[start + i];
-    Ivl e = col_encode(st, (u8)(k & 255), f0, alloc, tab);
-    entries[svals[start + i]] = (u32)e.freq | ((u32)e.cum << 16);
-  }
-}
+// (the chains themselves are in scpr_wave.hpp: one wave per chain, WaveModel)
 
 // ------------------------------------------------------------------ rANS ---
 struct RansBlock {

@@ -1,20 +1,23 @@
-// Wave-cooperative key-frame decoder (gfx950, one 64-lane wave per frame).
+// Wave-cooperative decoder (gfx950, one 64-lane wave per GOP) and the wave-per-chain colour
+// model of the encoder.
 //
-// The decode of one frame is a single dependent chain (every symbol's model
-// depends on the bytes decoded before it; DecompressI, screencap.cpp:414-498),
-// so the wave does not split the symbols; it splits the WORK PER SYMBOL:
-//   * the rANS state and all control flow are wave-uniform (scalar unit);
-//   * fixed-alphabet tables (run lengths, pixel types) live in LDS, four
-//     entries per lane; a symbol is found with one 16-byte LDS read per lane,
-//     a ballot and a readlane; rebuilds are a wave prefix-scan
-//     (FixedSizeRansCtx, ans_contexts.h:1054-1132);
-//   * colour contexts are 64-byte records cached in LDS (direct mapped,
-//     write-back to HBM); small tables use one lane per symbol and a 16-lane
-//     scan (SmallContext, :155-290); dense tables use four symbols per lane
-//     (Cx6/Cx7, :377-998);
-//   * the input bytes are fetched with wave-uniform (scalar) loads, one word ahead of use;
-//   * runs are written by all lanes at once; the gradient predictor is a wave
-//     prefix sum of (top - topleft) deltas.
+// The decode of a GOP is a single dependent chain (every symbol's model depends on the bytes
+// decoded before it; DecompressI, screencap.cpp:414-498; DecompressP, :1275-1432), so the wave
+// does not split the symbols; it splits the WORK PER SYMBOL:
+//   * the rANS state, the byte reader and all control flow are wave-uniform (scalar unit);
+//   * run-length tables (FixedSizeRansCtx<256> x 6, ans_contexts.h:1054-1132) sit in LDS one
+//     symbol per lane: a symbol below 64 is one compare + population count, and the table word,
+//     the "below 64?" word and the running total arrive behind ONE wait; counts are bumped with
+//     ds_add, rebuilds are wave prefix scans;
+//   * the six pixel-type tables live in one vector register pair and are searched by one compare;
+//   * colour contexts are 80-byte records cached in LDS (direct mapped, write-back to HBM);
+//     a small table (SmallContext, :155-290) is one packed word per lane with incrementally
+//     maintained prefix sums: lookup = one wait, one ballot, one readlane; dense tables
+//     (Cx6/Cx7, :377-998) are four symbols per lane in HBM;
+//   * runs are written by all lanes into an LDS ring of pixels; the gradient predictor is a wave
+//     prefix sum of (top - topleft) deltas; finished rows leave as 12-byte-per-lane stores.
+// What a lone wave pays per dependent instruction, and the rules that follow, are in DESIGN.md §3
+// (tools/lonewave_bench.hip).
 #pragma once
 #include "scpr_kernels.hpp"
 
