@@ -46,8 +46,8 @@ FrameCodec::FrameCodec(const Params& p, int version) {  // Init, screencap.cpp:6
   version_ = version;
   f0_ = version == 3 ? 64 : 32;  // screencap.cpp:1613-1614
   workers_ = p.workers < 1 ? 1 : (int)p.workers;
-  far_x = std::min<uint32_t>(p.high_range_x, 256);  // :79
-  far_y = std::min<uint32_t>(p.high_range_y, 256);
+  far_x = version < 3 ? p.high_range_x : std::min<uint32_t>(p.high_range_x, 256);  // :76-80: version 2 takes the caller's range as it is
+  far_y = version < 3 ? p.high_range_y : std::min<uint32_t>(p.high_range_y, 256);
   near_x = p.low_range_x;
   near_y = p.low_range_y;
   nbx = (W + 15) / 16;
@@ -60,10 +60,193 @@ FrameCodec::FrameCodec(const Params& p, int version) {  // Init, screencap.cpp:6
   band_start_.assign((size_t)imax(nby, workers_), 0);
   band_size_.assign((size_t)imax(nby, workers_), 0);
   m_ = new Models;
+  if (version_ == 2) {
+    v2_ = new V2Tables;
+    v2_->init(far_x, far_y);
+  }
   set_loss((int)p.loss);
 }
 
-FrameCodec::~FrameCodec() { delete m_; }
+FrameCodec::~FrameCodec() {
+  delete m_;
+  delete v2_;
+}
+
+void FrameCodec::reset_models() {  // RenewI, screencap.cpp:178-198
+  if (version_ == 2) v2_->reset();
+  else m_->reset();
+}
+
+// ------------------------------ version 2: coder and tables ------------------
+void RangeCoderV2::enc_begin(uint8_t* dst) {  // UseRC::encodeBegin (screencap.h:111-117) + EncodeBegin (sub.h:26-28)
+  out = dst;
+  low = 0;
+  ffnum = cache = 0;
+  range = 0xFFFFFFFFu;
+}
+void RangeCoderV2::shift_low() {  // sub.cpp:30-41
+  if ((low >> 24) != 0xFF) {
+    *out++ = (uint8_t)(cache + (uint32_t)(low >> 32));
+    const int c = 0xFF + (int)(low >> 32);
+    while (ffnum) {
+      *out++ = (uint8_t)c;
+      ffnum--;
+    }
+    cache = (uint32_t)low >> 24;
+  } else
+    ffnum++;
+  low = (int64_t)(uint32_t)((uint32_t)low << 8);
+}
+uint8_t* RangeCoderV2::enc_end() {  // sub.cpp:13-19
+  low += 1;
+  for (int i = 0; i < 5; i++) shift_low();
+  return out;
+}
+void RangeCoderV2::encode(uint32_t cum, uint32_t freq, uint32_t tot) {  // sub.cpp:21-27
+  range /= tot;
+  low += (uint32_t)(cum * range);
+  range *= freq;
+  while (range < (1u << 24)) {
+    shift_low();
+    range <<= 8;
+  }
+}
+void RangeCoderV2::dec_begin(const uint8_t* src, int len) {  // sub.h:30-42
+  code = 0;
+  range = 0xFFFFFFFFu;
+  in = src;
+  in_end = src + len;
+  overrun = len < 5;
+  for (int i = 0; i < 5 && in < in_end; i++) code = (code << 8) | *in++;
+}
+void RangeCoderV2::decode(uint32_t cum, uint32_t freq, uint32_t tot) {  // sub.cpp:48-60 (range was divided by tot in get_freq)
+  (void)tot;
+  code -= cum * range;
+  range *= freq;
+  while (range < (1u << 24)) {
+    if (in >= in_end) {
+      overrun = true;
+      return;
+    }
+    code = (code << 8) | *in++;
+    range <<= 8;
+  }
+}
+static inline void v2_bump(uint32_t* cnt, uint32_t maxc, int c, uint32_t step) {  // the tail of EncodeVal / DecodeVal, sub.cpp:73-82
+  cnt[c] += step;
+  cnt[maxc] += step;
+  if (cnt[maxc] > (1u << 16)) {  // BOT_C
+    uint32_t t = 0;
+    for (uint32_t i = 0; i < maxc; i++) {
+      cnt[i] = (cnt[i] >> 1) + 1;
+      t += cnt[i];
+    }
+    cnt[maxc] = t;
+  }
+}
+void RangeCoderV2::enc_val(int c, uint32_t* cnt, uint32_t maxc, uint32_t step) {  // sub.cpp:63-83
+  uint32_t cum = 0;
+  for (int i = 0; i < c; i++) cum += cnt[i];
+  encode(cum, cnt[c], cnt[maxc]);
+  v2_bump(cnt, maxc, c, step);
+}
+int RangeCoderV2::dec_val(uint32_t* cnt, uint32_t maxc, uint32_t step) {  // sub.cpp:86-110
+  const uint32_t value = get_freq(cnt[maxc]);
+  uint32_t cum = 0, c = 0;
+  for (; c < maxc; c++) {
+    if (value >= cum + cnt[c]) cum += cnt[c];
+    else break;
+  }
+  if (c >= maxc) {  // only a damaged stream: the reference reads cnt[maxc] here; stop instead
+    overrun = true;
+    c = maxc - 1;
+    cum -= cnt[c];
+  }
+  decode(cum, cnt[c], cnt[maxc]);
+  v2_bump(cnt, maxc, (int)c, step);
+  return (int)c;
+}
+static inline void v2_bump_uni(uint32_t* cnt, int c, uint32_t x, uint32_t step) {  // sub.cpp:126-139
+  cnt[c] += step;
+  cnt[256 + x] += step;
+  cnt[272] += step;
+  if (cnt[272] > (1u << 16)) {
+    uint32_t t = 0;
+    for (int i = 0; i < 256; i++) {
+      cnt[i] = (cnt[i] >> 1) + 1;
+      t += cnt[i];
+    }
+    cnt[272] = t;
+    for (int i = 0; i < 16; i++) {
+      cnt[256 + i] = 0;
+      for (int j = 0; j < 16; j++) cnt[256 + i] += cnt[i * 16 + j];
+    }
+  }
+}
+void RangeCoderV2::enc_uni(int c, uint32_t* cnt, uint32_t step) {  // sub.cpp:113-141
+  uint32_t cum = 0, x = 0;
+  for (; x < (uint32_t)c / 16; x++) cum += cnt[256 + x];
+  for (uint32_t i = x * 16; i < (uint32_t)c; i++) cum += cnt[i];
+  encode(cum, cnt[c], cnt[272]);
+  v2_bump_uni(cnt, c, x, step);
+}
+int RangeCoderV2::dec_uni(uint32_t* cnt, uint32_t step) {  // sub.cpp:144-177
+  const uint32_t value = get_freq(cnt[272]);
+  uint32_t cum = 0, x = 0;
+  for (; x < 16; x++) {
+    if (value >= cum + cnt[256 + x]) cum += cnt[256 + x];
+    else break;
+  }
+  uint32_t c = x * 16;
+  for (; c < 256; c++) {
+    if (value >= cum + cnt[c]) cum += cnt[c];
+    else break;
+  }
+  if (c >= 256) {  // damaged stream
+    overrun = true;
+    c = 255;
+    x = 15;
+    cum -= cnt[c];
+  }
+  decode(cum, cnt[c], cnt[272]);
+  v2_bump_uni(cnt, (int)c, x, step);
+  return (int)c;
+}
+void V2Tables::init(uint32_t msr_x, uint32_t msr_y) {
+  // order of the FixedModel members of Models: run_len[6], blk_run, blk_type, rect[4], motion[2], pix_type[6], blk_index
+  for (int i = 0; i < 6; i++) maxc[i] = 256, step[i] = 400;       // ntab, SC_NSTEP (screencap.h:34, :136-149)
+  maxc[6] = 256, step[6] = 20;                                    // ntab2, SC_BTNSTEP (:41, :202-211)
+  maxc[7] = 5, step[7] = 10;                                      // bttab, SC_BTSTEP (:39, :213-222)
+  for (int i = 8; i < 12; i++) maxc[i] = 16, step[i] = 100;       // sxytab, SC_SXYSTEP (:42, :224-233)
+  maxc[12] = msr_x * 2, maxc[13] = msr_y * 2;                     // mvtab sized by the motion range (:235-260)
+  step[12] = step[13] = 100;                                      // SC_MSTEP (:43)
+  for (int i = 14; i < 20; i++) maxc[i] = 6, step[i] = 1000;      // ptypetab, SC_UNSTEP (:44, :160-169)
+  maxc[20] = 256, step[20] = 1;                                   // xxtab, SC_XXSTEP (:45, :191-200)
+  for (int i = 0; i < 21; i++) fixed[i].assign(maxc[i] + 1, 0);
+  colour.assign((size_t)3 * 4096 * 273, 0);
+  reset();
+}
+void V2Tables::reset() {
+  for (int i = 0; i < 21; i++) {  // renewN / FixedTab::renew / renewM: every count 1, total = alphabet size
+    for (uint32_t j = 0; j < maxc[i]; j++) fixed[i][j] = 1;
+    fixed[i][maxc[i]] = maxc[i];
+  }
+  for (size_t t = 0; t < (size_t)3 * 4096; t++) {  // renewC, screencap.h:182-189
+    uint32_t* c = &colour[t * 273];
+    for (int n = 0; n < 256; n++) c[n] = 1;
+    for (int n = 0; n < 16; n++) c[256 + n] = 16;
+    c[272] = 256;
+  }
+}
+
+void FrameCodec::put_sym(FixedModel& m, int sym, int tag) {
+  if (version_ == 2) {
+    const int k = v2_index(m);
+    rc_.enc_val(sym, v2_->fixed[k].data(), v2_->maxc[k], v2_->step[k]);
+  } else {
+    put(m.encode(sym), tag);
+  }
+}
 
 void FrameCodec::set_loss(int loss) {  // SetupLossMask, screencap.cpp:127-139
   int mask = 0;
@@ -100,7 +283,11 @@ bool FrameCodec::is_flat(const uint8_t* src) const {  // IsFlat, :1436-1444
 }
 
 // ------------------------------ encoder: symbols ---------------------------
-void FrameCodec::put_colour(int plane, uint8_t c) {  // UseANS::encodeC, screencap.h:311-317
+void FrameCodec::put_colour(int plane, uint8_t c) {  // UseANS::encodeC, screencap.h:311-317; UseRC::encodeC, :172-175
+  if (version_ == 2) {
+    rc_.enc_uni(c, v2_->col(plane, cx_ + cx1_), 400);  // SC_STEP
+    return;
+  }
   Ivl e;
   if (!m_->colour[plane][cx_ + cx1_].encode(c, e, f0_)) {
     e.freq = 0;
@@ -123,7 +310,7 @@ void FrameCodec::put_rgb(const uint8_t* px) {  // EncodeRGB, :631-643
 }
 
 void FrameCodec::put_pixel(int t, int last_t, const uint8_t* px) {  // WritePixel, :609-627
-  put(m_->pix_type[last_t].encode(t), 12294 + last_t);
+  put_sym(m_->pix_type[last_t], t, 12294 + last_t);
   if (t) return;
   put_colour(0, px[0]);
   SPO_NEXT_CX(px[0]);
@@ -250,7 +437,8 @@ int FrameCodec::encode_intra(uint8_t* src, uint8_t* dst) {  // CompressI, :319-4
   }
   out_.clear();
   tags_.clear();
-  m_->reset();
+  if (version_ == 2) rc_.enc_begin(dst);
+  reset_models();
   put_rgb(src);
 
   int t = 0, last_t = 0, n = 1, lasti = 0;
@@ -259,13 +447,13 @@ int FrameCodec::encode_intra(uint8_t* src, uint8_t* dst) {  // CompressI, :319-4
     if (eq3(src + i, src + lasti) && n < 255)
       n++;
     else {
-      put(m_->run_len[0].encode(n), 12288);
+      put_sym(m_->run_len[0], n, 12288);
       put_rgb(src + i);
       n = 1;
     }
     lasti = i;
   }
-  put(m_->run_len[0].encode(n), 12288);
+  put_sym(m_->run_len[0], n, 12288);
   int x = 0, y = 1;
   const uint8_t* rec = last_records.data();
   for (int band = 0; band < workers_; band++) {
@@ -278,7 +466,7 @@ int FrameCodec::encode_intra(uint8_t* src, uint8_t* dst) {  // CompressI, :319-4
       last_t = t;
       if (!t) j += 3;
       n = rec[j + 1];
-      put(m_->run_len[t].encode(n), 12288 + t);
+      put_sym(m_->run_len[t], n, 12288 + t);
       j += 2;
       x += n;
       while (x >= W) {
@@ -288,7 +476,8 @@ int FrameCodec::encode_intra(uint8_t* src, uint8_t* dst) {  // CompressI, :319-4
       lasti = y * stride_ + x * 3;
     }
   }
-  uint8_t* end = flush_entries(dst);
+  uint8_t* end = version_ == 2 ? rc_.enc_end() : flush_entries(dst);
+  if (version_ == 2) last_entries.clear();
   memcpy(prev_.data(), src, (size_t)H * stride_);
   return (int)(end - dst);
 }
@@ -512,27 +701,28 @@ int FrameCodec::encode_inter(uint8_t* src, uint8_t* dst0) {  // CompressP, :1091
   *dst++ = 1;
   out_.clear();
   tags_.clear();
+  if (version_ == 2) rc_.enc_begin(dst);
   int bx1, bx2, by1, by2;
   decide_blocks(src, bx1, bx2, by1, by2);
 
   int xx1 = by1 * nbx + bx1, xx2 = by2 * nbx + bx2;
-  put(m_->blk_index.encode(xx1 & 255), 12300);
-  put(m_->blk_index.encode((xx1 >> 8) & 255), 12300);
-  put(m_->blk_index.encode(xx2 & 255), 12300);
-  put(m_->blk_index.encode((xx2 >> 8) & 255), 12300);
+  put_sym(m_->blk_index, xx1 & 255, 12300);
+  put_sym(m_->blk_index, (xx1 >> 8) & 255, 12300);
+  put_sym(m_->blk_index, xx2 & 255, 12300);
+  put_sym(m_->blk_index, (xx2 >> 8) & 255, 12300);
 
   int oldt = -1, n = -1;
   for (int b = xx1; b <= xx2; b++) {  // block-type RLE, :1155-1169
     if (blk_types[b] == oldt && n < 255)
       n++;
     else {
-      if (n > 0) put(m_->blk_run.encode(n), 12301);
-      put(m_->blk_type.encode(blk_types[b]), 12302);
+      if (n > 0) put_sym(m_->blk_run, n, 12301);
+      put_sym(m_->blk_type, blk_types[b], 12302);
       oldt = blk_types[b];
       n = 1;
     }
   }
-  put(m_->blk_run.encode(n), 12301);
+  put_sym(m_->blk_run, n, 12301);
 
   cx_ = cx1_ = 0;
   int lastmx = 0, lastmy = 0;
@@ -544,20 +734,23 @@ int FrameCodec::encode_inter(uint8_t* src, uint8_t* dst0) {  // CompressP, :1091
       if (!bt) continue;
       int x1 = rect_xy[0][bi], x2 = rect_xy[2][bi], y1 = rect_xy[1][bi], y2 = rect_xy[3][bi];
       if ((bt - 1) & 1) {
-        put(m_->rect[0].encode(x1 - bx * 16), 12303);
-        put(m_->rect[1].encode(y1 - by * 16), 12304);
-        put(m_->rect[2].encode(x2 - 1 - bx * 16), 12305);
-        put(m_->rect[3].encode(y2 - 1 - by * 16), 12306);
+        put_sym(m_->rect[0], x1 - bx * 16, 12303);
+        put_sym(m_->rect[1], y1 - by * 16, 12304);
+        put_sym(m_->rect[2], x2 - 1 - bx * 16, 12305);
+        put_sym(m_->rect[3], y2 - 1 - by * 16, 12306);
       }
       if ((bt - 1) & 2) {  // motion vector, :1199-1214
-        if (bi > 0 && mv[0][bi] == lastmx && mv[1][bi] == lastmy) {
+        if (version_ == 2) {  // no "same vector" flag before version 3 (canEncodeBool, screencap.h:262)
+          put_sym(m_->motion[0], mv[0][bi] + (int)far_x, 12307);
+          put_sym(m_->motion[1], mv[1][bi] + (int)far_y, 12308);
+        } else if (bi > 0 && mv[0][bi] == lastmx && mv[1][bi] == lastmy) {
           Ivl e = {kProbScale / 2, kProbScale / 2};
           put(e, 12309);
         } else {
           Ivl e = {kProbScale / 2, 0};
           put(e, 12309);
-          put(m_->motion[0].encode(mv[0][bi] + (int)far_x), 12307);
-          put(m_->motion[1].encode(mv[1][bi] + (int)far_y), 12308);
+          put_sym(m_->motion[0], mv[0][bi] + (int)far_x, 12307);
+          put_sym(m_->motion[1], mv[1][bi] + (int)far_y, 12308);
           lastmx = mv[0][bi];
           lastmy = mv[1][bi];
         }
@@ -569,7 +762,7 @@ int FrameCodec::encode_inter(uint8_t* src, uint8_t* dst0) {  // CompressP, :1091
           int i = y * stride_ + x * 3;
           put_pixel(t, last_t, src + i);
           last_t = t;
-          put(m_->run_len[t].encode(rn), 12288 + t);
+          put_sym(m_->run_len[t], rn, 12288 + t);
           if (rn > 1) {
             int q = x - x1 + rn - 1;
             x = q % (x2 - x1) + x1;
@@ -586,7 +779,8 @@ int FrameCodec::encode_inter(uint8_t* src, uint8_t* dst0) {  // CompressP, :1091
       }
     }
   }
-  uint8_t* end = flush_entries(dst);
+  uint8_t* end = version_ == 2 ? rc_.enc_end() : flush_entries(dst);
+  if (version_ == 2) last_entries.clear();
   memcpy(prev_.data(), src, (size_t)H * stride_);
   return (int)(end - dst0);
 }
@@ -596,7 +790,7 @@ int FrameCodec::compress(uint8_t* src, uint8_t* dst, int /*dst_len*/, int& ftype
     ftype = 0;
     if (!(last_flat_ && !memcmp(src, last_flat_rgb_, 3))) {
       memcpy(prev_.data(), src, (size_t)H * stride_);
-      m_->reset();
+      reset_models();
       memcpy(last_flat_rgb_, src, 3);
     }
     dst[0] = (uint8_t)(1 + (version_ - 1) * 16);
@@ -618,7 +812,11 @@ int FrameCodec::compress(uint8_t* src, uint8_t* dst, int /*dst_len*/, int& ftype
 }
 
 // ------------------------------ decoder -----------------------------------
-void FrameCodec::dec_begin(const uint8_t* p) {  // decodeBegin, screencap.h:295-301
+void FrameCodec::dec_begin(const uint8_t* p) {  // decodeBegin, screencap.h:295-301; UseRC::decodeBegin, :123-125
+  if (version_ == 2) {
+    rc_.dec_begin(p, dec_len_);
+    return;
+  }
   in_ = p;
   n_dec_ = 0;
   rx_ = (uint32_t)in_[0] | ((uint32_t)in_[1] << 8) | ((uint32_t)in_[2] << 16) | ((uint32_t)in_[3] << 24);
@@ -635,14 +833,19 @@ static inline void rans_advance(uint32_t& x, const uint8_t*& p, uint32_t start, 
   x = freq * (x >> kProbBits) + (x & (kProbScale - 1)) - start;
   while (x < kRansL) x = (x << 8) | *p++;
 }
-int FrameCodec::get_fixed(FixedModel& m) {  // decodeF, screencap.h:346-359
+int FrameCodec::get_fixed(FixedModel& m) {  // decodeF, screencap.h:346-359; the DecodeVal family of version 2
+  if (version_ == 2) {
+    const int k = v2_index(m);
+    return rc_.dec_val(v2_->fixed[k].data(), v2_->maxc[k], v2_->step[k]);
+  }
   Ivl e;
   int c = m.decode((int)(rx_ & (kProbScale - 1)), e);
   rans_advance(rx_, in_, e.cum, e.freq);
   dec_count();
   return c;
 }
-int FrameCodec::get_colour(int plane) {  // decodeC, screencap.h:318-333
+int FrameCodec::get_colour(int plane) {  // decodeC, screencap.h:318-333; UseRC::decodeC, :176-180
+  if (version_ == 2) return rc_.dec_uni(v2_->col(plane, cx_ + cx1_), 400);
   ColourCtx& cx = m_->colour[plane][cx_ + cx1_];
   Ivl e;
   uint8_t c;
@@ -663,7 +866,8 @@ void FrameCodec::get_rgb(int& r, int& g, int& b) {  // DecodeRGB, :662-679
   b = get_colour(2);
   SPO_NEXT_CX(b);
 }
-bool FrameCodec::get_bool() {  // decodeBool, screencap.h:411-421
+bool FrameCodec::get_bool() {  // decodeBool, screencap.h:411-421 (version 2: never the same vector, :263-264)
+  if (version_ == 2) return false;
   bool flag = (rx_ & (kProbScale - 1)) >= kProbScale / 2;
   rans_advance(rx_, in_, flag ? kProbScale / 2 : 0, kProbScale / 2);
   dec_count();
@@ -673,7 +877,7 @@ bool FrameCodec::get_bool() {  // decodeBool, screencap.h:411-421
 int FrameCodec::decode_intra(const uint8_t* src, uint8_t* dst) {  // DecompressI, :414-498
   int r = 0, g = 0, b = 0;
   dec_begin(src);
-  m_->reset();
+  reset_models();
   cx_ = cx1_ = 0;
   int t = 0, last_t = 0, i = 0, n = 1, k = 0, lasti = 0;
   while (k < W + 1) {
@@ -840,7 +1044,8 @@ int FrameCodec::decode_inter(const uint8_t* src, uint8_t* dst) {  // DecompressP
   return 1;
 }
 
-int FrameCodec::decompress(const uint8_t* src, int /*src_len*/, uint8_t* dst, int ftype) {  // :1522-1557
+int FrameCodec::decompress(const uint8_t* src, int src_len, uint8_t* dst, int ftype) {  // :1522-1557
+  dec_len_ = src_len;  // version 2 hands the packet length to its coder as it is (one more than what follows the header byte)
   if (W & 3) {
     int pad = stride_ - W * 3;
     for (int y = 0; y < H; y++) memset(dst + (size_t)y * stride_ + W * 3, 0, pad);
@@ -856,7 +1061,7 @@ int FrameCodec::decompress(const uint8_t* src, int /*src_len*/, uint8_t* dst, in
     for (int y = 1; y < H; y++) memcpy(dst + (size_t)y * stride_, dst, (size_t)W * 3);
     if (!(last_flat_ && !memcmp(last_flat_rgb_, src, 3))) {
       memcpy(prev_.data(), dst, (size_t)H * stride_);
-      m_->reset();
+      reset_models();
     }
     last_flat_ = true;
     memcpy(last_flat_rgb_, src, 3);
@@ -901,7 +1106,7 @@ void ScreenCodec::deinit() {  // :1619-1629
 int ScreenCodec::compress_frame(uint8_t* src, uint8_t* dst, int dst_len, int* ftype, int loss) {  // :1632-1692
   if (crashed_) return 0;
   if (p_.bits_per_pixel != 16 && p_.bits_per_pixel != 24 && p_.bits_per_pixel != 32) return -48;
-  if (!fc_) create(p_.version == 3 ? 3 : 4);
+  if (!fc_) create(p_.version == 3 ? 3 : p_.version == 2 ? 2 : 4);
   if (loss != last_loss_) {
     fc_->set_loss(loss);
     last_loss_ = loss;
@@ -939,7 +1144,7 @@ int ScreenCodec::decompress_frame(const uint8_t* src, int src_len, uint8_t* dst,
   if (!fc_) {
     if (ftype > 0) return 0;
     int version = (src[0] >> 4) + 1;
-    if (version < 3 || version > 4) return -version;  // v2 (range coder) is not restated here
+    if (version < 2 || version > 4) return -version;  // BadVersionException, :1589-1590
     if (p_.bits_per_pixel != 16 && p_.bits_per_pixel != 24 && p_.bits_per_pixel != 32) return -48;
     create(version);
   }

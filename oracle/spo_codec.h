@@ -1,8 +1,9 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY (see spo_model.h for the parity note).
 //
 // CPU restatement of the ScreenPressor frame codec: ScreenCodec /
-// CScreenCapt<UseANS> (screencap.h, screencap.cpp), RansMTCoder (ransmt.h) and
-// the byte-wise rANS primitives (rans_byte.h).  Citations are relative to
+// CScreenCapt<UseANS> (screencap.h, screencap.cpp), RansMTCoder (ransmt.h), the
+// byte-wise rANS primitives (rans_byte.h), and for version 2 streams UseRC
+// (screencap.h:105-265) over RangeCoderSub (sub.h, sub.cpp).  Citations are relative to
 // /root/reference.
 #pragma once
 #include <stdint.h>
@@ -18,7 +19,40 @@ struct Params {  // CodecParameters, screencap.h:49-55, plus the worker count
   uint32_t high_range_x, high_range_y, low_range_x, low_range_y;
   uint32_t loss;
   uint32_t workers;  // size of the reference's CSquad pool; bitstream-visible for I-frames
-  uint32_t version;  // 4 (default) or 3; encoder side only
+  uint32_t version;  // 4 (default), 3 or 2; encoder side only (the reference itself only ever encodes 4)
+};
+
+// ---- version 2: range coder + plain adaptive count tables (UseRC, screencap.h:105-265) ----
+// RangeCoderSub, sub.h:20-57 / sub.cpp:13-60.  All arithmetic is the reference's: 32-bit
+// unsigned `code`/`range`, 64-bit `low`, carry propagation through Cache/FFNum.
+struct RangeCoderV2 {
+  uint32_t code = 0, range = 0, ffnum = 0, cache = 0;
+  int64_t low = 0;
+  uint8_t* out = nullptr;
+  const uint8_t* in = nullptr;
+  const uint8_t* in_end = nullptr;
+  bool overrun = false;  // the reference throws std::length_error (sub.cpp:52-53)
+  void enc_begin(uint8_t* dst);
+  uint8_t* enc_end();
+  void shift_low();
+  void encode(uint32_t cum, uint32_t freq, uint32_t tot);
+  void dec_begin(const uint8_t* src, int len);
+  uint32_t get_freq(uint32_t tot) { return code / (range /= tot); }
+  void decode(uint32_t cum, uint32_t freq, uint32_t tot);
+  // EncodeVal / DecodeVal / EncodeValUni / DecodeValUni, sub.cpp:63-177 (cnt[maxc] is the total)
+  void enc_val(int c, uint32_t* cnt, uint32_t maxc, uint32_t step);
+  int dec_val(uint32_t* cnt, uint32_t maxc, uint32_t step);
+  void enc_uni(int c, uint32_t* cnt, uint32_t step);
+  int dec_uni(uint32_t* cnt, uint32_t step);
+};
+// the tables of UseRC (screencap.h:133-260): index = position of the matching FixedModel in Models
+struct V2Tables {
+  std::vector<uint32_t> fixed[21];
+  uint32_t maxc[21], step[21];
+  std::vector<uint32_t> colour;  // [3][4096][256 + 16 + 1]
+  void init(uint32_t msr_x, uint32_t msr_y);
+  void reset();  // RenewI with the renew* of UseRC
+  uint32_t* col(int plane, uint32_t ctx) { return &colour[((size_t)plane * 4096 + ctx) * 273]; }
 };
 
 enum { kRansL = 1u << 23, kBlockEntries = 128 * 1024 };  // rans_byte.h:47, ransmt.h:38
@@ -91,6 +125,11 @@ class FrameCodec {  // CScreenCapt<UseANS>
     out_.push_back(e);
     tags_.push_back((uint16_t)tag);
   }
+  void put_sym(FixedModel& m, int sym, int tag);  // encodeF / the EncodeVal family of version 2
+  void reset_models();
+  RangeCoderV2 rc_;
+  V2Tables* v2_ = nullptr;
+  int v2_index(const FixedModel& m) const { return (int)(&m - m_->run_len); }  // the fixed models are contiguous in Models
   void put_colour(int plane, uint8_t c);
   void put_rgb(const uint8_t* px);           // EncodeRGB
   void put_pixel(int t, int last_t, const uint8_t* px);  // WritePixel
@@ -108,6 +147,7 @@ class FrameCodec {  // CScreenCapt<UseANS>
   const uint8_t* in_ = nullptr;
   uint32_t rx_ = 0;
   int n_dec_ = 0;
+  int dec_len_ = 0;
   void dec_begin(const uint8_t* p);
   void dec_count();
   int get_fixed(FixedModel& m);

@@ -16,6 +16,7 @@
 #include "../../include/scpr_amd.h"
 #include "scpr_kernels.hpp"
 #include "scpr_wave.hpp"
+#include "scpr_v2.hpp"
 #include "scpr_inter.hpp"
 
 using namespace scpr;
@@ -157,10 +158,11 @@ static void setup_loss(scpr_codec* c, int loss) {  // SetupLossMask, screencap.c
 
 static int ensure_codec(scpr_codec* c, int version) {  // CreateCodec + CScreenCapt::Init, screencap.cpp:1587-1617, :69-124
   if (c->have_codec) return SCPR_OK;
-  if (version < 3 || version > 4) return SCPR_E_BAD_VERSION;
+  if (version < 2 || version > 4) return SCPR_E_BAD_VERSION;  // BadVersionException (:1589-1590); version 2 is decode-only here
   const scpr_params& p = c->prm;
   if (p.bits_per_pixel != 16 && p.bits_per_pixel != 24 && p.bits_per_pixel != 32) return SCPR_E_BAD_VERSION;
   if (p.width < 3 || p.height < 2 || p.width > 8000 || p.workers < 1 || p.height < 2 * p.workers) return SCPR_E_PARAM;
+  if (version == 2 && (p.high_range_x > 256 || p.high_range_y > 256 || !p.high_range_x || !p.high_range_y)) return SCPR_E_PARAM;  // its motion tables hold 2 * range symbols (LDS: 512)
   c->version = version;
   c->f0 = version == 3 ? 64 : 32;
   Geom& g = c->g;
@@ -522,6 +524,7 @@ int64_t scpr_compress_batch(scpr_codec* c, const void* d_frames, int nframes, in
   if (!c || !c->inited || !d_frames || !ftypes || !d_out || !sizes || nframes < 0) return SCPR_E_PARAM;
   if (c->crashed) return 0;  // screencap.cpp:1634
   if (hipSetDevice(c->device) != hipSuccess) return SCPR_E_DEVICE;
+  if (c->have_codec && c->version == 2) return SCPR_E_BAD_VERSION;  // a codec that has decoded version 2 cannot encode (no version 2 encoder here)
   int rc = ensure_codec(c, c->have_codec ? c->version : 4);  // the encoder always writes v4 (screencap.cpp:1646-1648)
   if (rc != SCPR_OK) return rc;
   if (loss != c->last_loss) setup_loss(c, loss);
@@ -736,20 +739,23 @@ int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* 
     if (ng) {
       HIPCHK(c->decframes.reserve(fr.size() * sizeof(DecFrame)));
       HIPCHK(c->decgops.reserve(ng * sizeof(DecGop)));
-      HIPCHK(c->decstates.reserve(ng * NCOLCTX * sizeof(DecRec)));
-      HIPCHK(c->decfixed.reserve(ng * sizeof(FixedBlob)));
-      HIPCHK(c->dec_fixed_persist.reserve(sizeof(FixedBlob)));
-      HIPCHK(c->dec_colour_persist.reserve((size_t)NCOLCTX * sizeof(DecRec)));
-      HIPCHK(hipMemsetAsync(c->decstates.p, 0, ng * NCOLCTX * sizeof(DecRec), st));  // kind 0 everywhere (RenewI)
+      const bool v2 = c->version == 2;  // range-coder streams: count tables instead of context records (scpr_v2.hpp)
+      const size_t state_bytes = v2 ? (size_t)NCOLCTX * V2_COLTAB * 4 : (size_t)NCOLCTX * sizeof(DecRec);
+      const size_t blob_bytes = v2 ? sizeof(V2Fixed) : sizeof(FixedBlob);
+      HIPCHK(c->decstates.reserve(ng * state_bytes));
+      HIPCHK(c->decfixed.reserve(ng * blob_bytes));
+      HIPCHK(c->dec_fixed_persist.reserve(blob_bytes));
+      HIPCHK(c->dec_colour_persist.reserve(state_bytes));
+      if (!v2) HIPCHK(hipMemsetAsync(c->decstates.p, 0, ng * state_bytes, st));  // kind 0 everywhere (RenewI)
       const bool cont = gops[0].load != 0;
       if (cont) {  // the first GOP continues the state kept from the previous call
-        HIPCHK(hipMemcpyAsync(c->decstates.p, c->dec_colour_persist.p, (size_t)NCOLCTX * sizeof(DecRec), hipMemcpyDeviceToDevice, st));
-        HIPCHK(hipMemcpyAsync(c->decfixed.p, c->dec_fixed_persist.p, sizeof(FixedBlob), hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync(c->decstates.p, c->dec_colour_persist.p, state_bytes, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync(c->decfixed.p, c->dec_fixed_persist.p, blob_bytes, hipMemcpyDeviceToDevice, st));
       } else {
         c->arena_used_bound = 0;
         HIPCHK(hipMemsetAsync(c->arena_top.p, 0, 4, st));
       }
-      const size_t arena_cap = c->arena_used_bound + ng * 12288 + 64;
+      const size_t arena_cap = c->arena_used_bound + (v2 ? 0 : ng * 12288) + 64;
       HIPCHK(c->arena.reserve_keep(arena_cap * sizeof(DenseTab), c->arena_used_bound * sizeof(DenseTab), st));
       c->arena_used_bound = arena_cap;
       HIPCHK(hipMemcpyAsync(c->decframes.p, fr.data(), fr.size() * sizeof(DecFrame), hipMemcpyHostToDevice, st));
@@ -757,21 +763,29 @@ int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* 
       Arena ar{c->arena.as<DenseTab>(), c->arena_top.as<u32>(), (u32)arena_cap, c->err.as<u32>()};
       // LDS ring of 32-bit pixels: the predictors look back one row + 1 pixel, a finished row is flushed at most
       // one run after it ends, and a run writes up to 255 pixels ahead: a power of two >= W + 512 pixels.
-      // (Keeping static + dynamic LDS under 64 KiB lets two GOPs share a CU.)
+      // (Keeping static + dynamic LDS under 80 KiB lets two GOPs share a CU.)
       int ring = 4096;
       while (ring < 4 * (g.W + 512)) ring <<= 1;
       const int nblocks = ((g.W + 15) / 16) * ((g.H + 15) / 16);
       bool has_p = false;
       for (const DecFrame& d : fr) has_p |= d.kind == 2;
       const int dyn = ring + (has_p ? ((nblocks + 15) & ~15) : 0);  // + one byte per block for P-frames
-      auto kern = has_p ? k_decode_gop_w<true> : k_decode_gop_w<false>;  // key-frame-only GOPs: smaller kernel (instruction cache)
-      HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
-      hipLaunchKernelGGL(kern, dim3((unsigned)ng), dim3(64), dyn, st, (const u8*)d_packets, (const u8*)d_packets + offs[nframes] + 8, c->decframes.as<DecFrame>(),
-                         c->decgops.as<DecGop>(), c->planes.as<u8>(), g, c->decstates.as<DecRec>(), ar, c->f0, c->err.as<u32>(), ring, c->decfixed.as<FixedBlob>(),
-                         (int)std::min<u32>(c->prm.high_range_x, 256), (int)std::min<u32>(c->prm.high_range_y, 256));
+      const u8* pk = (const u8*)d_packets;
+      if (v2) {
+        auto kern = has_p ? k_decode_gop_v2<true> : k_decode_gop_v2<false>;
+        HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
+        hipLaunchKernelGGL(kern, dim3((unsigned)ng), dim3(64), dyn, st, pk, pk + offs[nframes] + 8, c->decframes.as<DecFrame>(), c->decgops.as<DecGop>(), c->planes.as<u8>(), g,
+                           c->decstates.as<u32>(), c->err.as<u32>(), ring, c->decfixed.as<V2Fixed>(), (int)c->prm.high_range_x, (int)c->prm.high_range_y);  // the caller's range, unclamped (:76-77)
+      } else {
+        auto kern = has_p ? k_decode_gop_w<true> : k_decode_gop_w<false>;  // key-frame-only GOPs: smaller kernel (instruction cache)
+        HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
+        hipLaunchKernelGGL(kern, dim3((unsigned)ng), dim3(64), dyn, st, pk, pk + offs[nframes] + 8, c->decframes.as<DecFrame>(), c->decgops.as<DecGop>(), c->planes.as<u8>(), g,
+                           c->decstates.as<DecRec>(), ar, c->f0, c->err.as<u32>(), ring, c->decfixed.as<FixedBlob>(), (int)std::min<u32>(c->prm.high_range_x, 256),
+                           (int)std::min<u32>(c->prm.high_range_y, 256));
+      }
       // keep the state of the last GOP and the last plane for the next call
-      HIPCHK(hipMemcpyAsync(c->dec_colour_persist.p, c->decstates.as<DecRec>() + (ng - 1) * NCOLCTX, (size_t)NCOLCTX * sizeof(DecRec), hipMemcpyDeviceToDevice, st));
-      HIPCHK(hipMemcpyAsync(c->dec_fixed_persist.p, c->decfixed.as<FixedBlob>() + (ng - 1), sizeof(FixedBlob), hipMemcpyDeviceToDevice, st));
+      HIPCHK(hipMemcpyAsync(c->dec_colour_persist.p, (const u8*)c->decstates.p + (ng - 1) * state_bytes, state_bytes, hipMemcpyDeviceToDevice, st));
+      HIPCHK(hipMemcpyAsync(c->dec_fixed_persist.p, (const u8*)c->decfixed.p + (ng - 1) * blob_bytes, blob_bytes, hipMemcpyDeviceToDevice, st));
       c->dec_live = true;
     }
     HIPCHK(hipMemcpyAsync(c->planes.as<u8>() + (size_t)c->slots * g.plane_stride, c->planes.as<u8>() + (size_t)(n - 1) * g.plane_stride, g.plane_stride, hipMemcpyDeviceToDevice, st));

@@ -882,7 +882,8 @@ __device__ __forceinline__ u32 ld3_l2(const u8* p) {
 // pixels indexed by raster position (it always holds the last two rows: the predictors read
 // "previous", "top" and "top-left" from it); every finished row is packed to RGB24 and flushed
 // to HBM four pixels per lane.  The plane in HBM is never read back.
-__device__ __forceinline__ void decode_intra_frame(WaveDec& D, const Geom& g, u8* __restrict__ dst, u32* ring, int ring_pixels) {
+template <class DEC>
+__device__ __forceinline__ void decode_intra_frame(DEC& D, const Geom& g, u8* __restrict__ dst, u32* ring, int ring_pixels) {
   const int lane = D.lane;
   const u32 pm = (u32)ring_pixels - 1u;
   const int W = g.W, H = g.H, S = g.S, NP = g.NP;
@@ -915,9 +916,9 @@ __device__ __forceinline__ void decode_intra_frame(WaveDec& D, const Geom& g, u8
   int p = 0, t = 0;  // next pixel (raster index), type of the previous run
   while (SCPR_LIKELY(p < NP && !D.bad)) {
     const bool hdr = p <= W;
-    D.stamp<4>();
+    D.template stamp<4>();
     if (SCPR_LIKELY(!hdr)) t = D.fixed_p(t);
-    D.stamp<0>();
+    D.template stamp<0>();
     u32 px = lastpix;
     if (t == 0) {  // DecodeRGB, screencap.cpp:662-679: contexts are the two previous bytes >> 2 (MAKECX1, screencap.h:35-36)
       u32 a = (lastpix >> 18) & 63, b = (lastpix >> 10) & 63;
@@ -929,10 +930,10 @@ __device__ __forceinline__ void decode_intra_frame(WaveDec& D, const Geom& g, u8
         b = a;
         a = c >> 2;
       }
-      D.stamp<1>();
+      D.template stamp<1>();
     }
     const int n = D.fixed_n(t);
-    D.stamp<2>();
+    D.template stamp<2>();
     if (SCPR_UNLIKELY((u32)(n - 1) >= (u32)((hdr ? W + 1 : NP) - p))) {  // empty, or longer than what is left (of the header row)
       D.bad = true;
       break;
@@ -988,7 +989,7 @@ __device__ __forceinline__ void decode_intra_frame(WaveDec& D, const Geom& g, u8
       wave_fence();
       lastpix = rdl(v, m - 1);
     }
-    D.stamp<3>();
+    D.template stamp<3>();
     p += n;
     if (SCPR_UNLIKELY(p >= rowbase + W)) {
       int done = flushed + 1;
@@ -1002,7 +1003,8 @@ __device__ __forceinline__ void decode_intra_frame(WaveDec& D, const Geom& g, u8
 // P-frame (DecompressP, screencap.cpp:1275-1432).  The new plane starts as a copy of the previous
 // one; motion blocks are copied from the previous plane, pixel-coded rects are rebuilt in an LDS
 // tile (with the row above and the column to the left as predictor context) and written back.
-__device__ __forceinline__ void decode_inter_frame(WaveDec& D, const Geom& g, u8* __restrict__ cur, const u8* __restrict__ prv, const u8* head, u8* bts, int far_x, int far_y) {
+template <class DEC>
+__device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __restrict__ cur, const u8* __restrict__ prv, const u8* head, u8* bts, int far_x, int far_y) {
   const int lane = D.lane;
   const int W = g.W, H = g.H, S = g.S;
   const int nbx = (W + 15) >> 4, nby = (H + 15) >> 4, nblocks = nbx * nby;

@@ -319,3 +319,41 @@ def test_corrupt_streams_are_survived():
             pass  # SCPR_E_STREAM / SCPR_E_PARAM surface as exceptions in the Python mirror
     r, out = gpu.DecompressFrame(key, 0)
     assert r == 1 and np.array_equal(out.reshape(h, w, 4), seq.frame(0))
+
+
+@pytest.mark.parametrize("w,h,seed", [(64, 48, 1), (100, 37, 2), (320, 240, 3), (33, 50, 4)])
+def test_version2_streams_decode(w, h, seed):
+    """Version 2 (range coder, UseRC) is decode-only, as in the reference (its compress side always
+    writes version 4).  Streams come from the oracle's version 2 encoder: key frames, P-frames with
+    motion, unchanged and flat frames; decoded frame by frame and in random batches."""
+    import torch
+    rng = np.random.default_rng(seed)
+    seq = DesktopSequence(w, h, seed=30 + seed, sparkles=25)
+    flat = np.full((h, w, 4), 255, np.uint8)
+    flat[..., :3] = (7, 99, 201)
+    frames, keys = [], []
+    for t in range(14):
+        k = rng.random()
+        frames.append(seq.frame(t) if k < 0.7 or not frames else (frames[-1].copy() if k < 0.85 else flat.copy()))
+        keys.append(t == 0 or rng.random() < 0.2)
+    enc = O.OracleCodec(w, h, 32, version=2)
+    pk = [enc.compress(f, key=k) for f, k in zip(frames, keys)]
+    assert pk[0][0][0] == 0x12  # version 2 key frame header (2 + (2 - 1) * 16)
+    gpu = _codec(w, h)
+    for (p, ft), f in zip(pk, frames):  # one call per frame
+        r, out = gpu.DecompressFrame(p, ft)
+        assert r == 1 and np.array_equal(out.reshape(h, w, 4)[..., :3], f[..., :3])
+    gb = _codec(w, h)
+    i = 0
+    while i < len(pk):  # batches
+        j = min(len(pk), i + int(rng.integers(1, 6)))
+        blob = b"".join(p for p, _ in pk[i:j])
+        dev = torch.from_numpy(np.frombuffer(blob, np.uint8).copy()).cuda()
+        r, out = gb.DecompressBatch(dev, [len(p) for p, _ in pk[i:j]], [ft for _, ft in pk[i:j]])
+        assert r == j - i
+        out = out.cpu().numpy().reshape(j - i, h, w, 4)
+        for t in range(i, j):
+            assert np.array_equal(out[t - i][..., :3], frames[t][..., :3]), t
+        i = j
+    with pytest.raises(Exception):  # a codec that has decoded version 2 has no encoder for it
+        gb.CompressFrame(frames[0], 0)

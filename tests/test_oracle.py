@@ -260,3 +260,20 @@ def test_fixed_model_known_answers():
     # after enough hits the counts become the frequencies: symbol 0 dominates
     out = O.chain_fixed(256, np.zeros(400, np.uint16))
     assert out[0, 0] == 16 and out[-1, 0] > 3000 and np.all(out[:, 1] == 0)
+
+
+def test_version2_range_coder_round_trip():
+    """UseRC + RangeCoderSub restated (decode side is what the product implements; the encoder exists to make
+    streams): lossless round trip over key, P, unchanged and flat frames, header bytes of version 2."""
+    w, h = 100, 37
+    seq = DesktopSequence(w, h, seed=8, sparkles=20)
+    enc, dec = O.OracleCodec(w, h, 32, version=2), O.OracleCodec(w, h, 32)
+    flat = np.full((h, w, 4), 255, np.uint8)
+    frames = [seq.frame(0), seq.frame(1), seq.frame(1), flat, seq.frame(2), seq.frame(3)]
+    heads = []
+    for t, f in enumerate(frames):
+        p, ft = enc.compress(f, key=(t == 0))
+        heads.append(p[0])
+        r, out = dec.decompress(p, ft)
+        assert r == 1 and np.array_equal(out.reshape(h, w, 4)[..., :3], f[..., :3]), t
+    assert heads == [0x12, 0x01, 0x00, 0x11, 0x01, 0x01]
