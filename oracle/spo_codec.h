@@ -37,7 +37,14 @@ struct RangeCoderV2 {
   void shift_low();
   void encode(uint32_t cum, uint32_t freq, uint32_t tot);
   void dec_begin(const uint8_t* src, int len);
-  uint32_t get_freq(uint32_t tot) { return code / (range /= tot); }
+  uint32_t get_freq(uint32_t tot) {  // sub.cpp:43-46; a damaged stream can drive the range to zero (the reference would divide by it)
+    range /= tot;
+    if (!range) {
+      overrun = true;
+      return 0;
+    }
+    return code / range;
+  }
   void decode(uint32_t cum, uint32_t freq, uint32_t tot);
   // EncodeVal / DecodeVal / EncodeValUni / DecodeValUni, sub.cpp:63-177 (cnt[maxc] is the total)
   void enc_val(int c, uint32_t* cnt, uint32_t maxc, uint32_t step);

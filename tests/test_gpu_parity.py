@@ -357,3 +357,29 @@ def test_version2_streams_decode(w, h, seed):
         i = j
     with pytest.raises(Exception):  # a codec that has decoded version 2 has no encoder for it
         gb.CompressFrame(frames[0], 0)
+
+
+def test_corrupt_version2_streams_are_survived():
+    rng = np.random.default_rng(78)
+    w, h = 64, 48
+    seq = DesktopSequence(w, h, seed=6, sparkles=20)
+    enc = O.OracleCodec(w, h, 32, version=2)
+    key, _ = enc.compress(seq.frame(0), key=True)
+    pfr, _ = enc.compress(seq.frame(1), key=False)
+    gpu = _codec(w, h)
+    for trial in range(24):
+        r, _ = gpu.DecompressFrame(key, 0)
+        assert r == 1
+        which = trial % 4
+        pkt = bytearray(key if which < 2 else pfr)
+        if which % 2 == 0:
+            for _ in range(int(rng.integers(1, 4))):
+                pkt[int(rng.integers(1, len(pkt)))] ^= int(rng.integers(1, 256))
+        else:
+            pkt = pkt[: int(rng.integers(2, len(pkt)))]
+        try:
+            gpu.DecompressFrame(bytes(pkt), 0 if which < 2 else 1)
+        except RuntimeError:
+            pass
+    r, out = gpu.DecompressFrame(key, 0)
+    assert r == 1 and np.array_equal(out.reshape(h, w, 4)[..., :3], seq.frame(0)[..., :3])

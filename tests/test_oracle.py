@@ -216,8 +216,8 @@ def test_decoder_refusals():
     dec = O.OracleCodec(w, h, 32)
     r, _ = dec.decompress(b"\x01abc", 1)
     assert r == 0  # P-frame before any key frame (screencap.cpp:1699)
-    r, _ = dec.decompress(bytes([0x12, 0, 0, 0, 0]), 0)
-    assert r < 0   # v2 stream: range-coder back end not restated
+    r, _ = dec.decompress(bytes([0x02, 0, 0, 0, 0]), 0)
+    assert r < 0   # version 1 stream: BadVersionException (screencap.cpp:1589-1590)
 
 
 def _model_sequences():
