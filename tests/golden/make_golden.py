@@ -34,6 +34,9 @@ CASES = [
     ("desktop_1080p_keys", 1920, 1080, 32, 3, (0, 1, 2), 1, 0.0, 1, 0, False),  # BASELINE configs[1] content
     ("desktop_1080p_ip", 1920, 1080, 32, 4, (0,), 1, 0.0, 1, 0, False),        # BASELINE configs[2] content
 ]
+# streams of the legacy version 2 format (range coder): the product only decodes these
+V2_CASES = [("desktop_100x37_v2_ip", 100, 37, 32, 7, (0, 4), 7, 0.0, 1, 0, True), ("desktop_320x240_v2_ip", 320, 240, 32, 5, (0,), 8, 0.0, 1, 0, True)]
+CASES_ALL = CASES + V2_CASES
 
 
 def frames_of(case):
@@ -45,9 +48,10 @@ def frames_of(case):
 
 def main():
     manifest = {}
-    for case in CASES:
+    for case in CASES_ALL:
         name, w, h, bpp, n, keys, seed, noise, workers, loss, keep = case
-        enc = O.OracleCodec(w, h, bpp, loss=loss, workers=workers)
+        version = 2 if case in V2_CASES else 4
+        enc = O.OracleCodec(w, h, bpp, loss=loss, workers=workers, version=version)
         packets, types = [], []
         for t, f in frames_of(case):
             data, ft = enc.compress(f, key=(t in keys))
@@ -55,7 +59,7 @@ def main():
             types.append(ft)
         blob = b"".join(packets)
         entry = {"width": w, "height": h, "bpp": bpp, "frames": n, "keys": list(keys), "seed": seed, "noise": noise,
-                 "workers": workers, "loss": loss, "sizes": [len(p) for p in packets], "ftypes": types,
+                 "workers": workers, "loss": loss, "version": version, "sizes": [len(p) for p in packets], "ftypes": types,
                  "sha256": hashlib.sha256(blob).hexdigest(),
                  "frame_sha256": [hashlib.sha256(p).hexdigest() for p in packets]}
         if keep:
