@@ -85,3 +85,38 @@ def test_two_rank_gather_equals_single_stream_of_independent_gops():
         r, out = dec.decompress(blob[off:off + sz], 0 if t % 4 == 0 else 1)
         off += sz
         assert r == 1 and np.array_equal(out.reshape(h, w, 4), seq.frame(t))
+
+
+@pytest.mark.gpu
+def test_rccl_gather_of_gpu_encoded_packets_one_rank():
+    """The RCCL leg of the gather with the only rank a one-GPU box has: process group "nccl", device
+    tensors through gather_packets, payload = packets encoded by the HIP path (run in a child process so
+    the process group does not outlive the test)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import numpy as np, torch, torch.distributed as dist
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+from screenpressor_amd.codec import ScreenCodec
+from screenpressor_amd.sharding import gather_packets
+from screenpressor_amd.synth import DesktopSequence
+import oracle_api as O
+w, h, n = 96, 64, 6
+seq = DesktopSequence(w, h, seed=11)
+frames = torch.from_numpy(seq.frames(n)).cuda().reshape(n, -1)
+pk, sizes, fts = ScreenCodec(0).Init(w, h, 32).CompressBatch(frames, [0 if t %% 3 == 0 else 1 for t in range(n)])
+out_p, out_s = gather_packets(dist, 0, 1, pk, sizes, device=torch.device("cuda", 0))
+t = torch.ones(1, device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX); dist.barrier()
+enc = O.OracleCodec(w, h, 32)
+want = b"".join(enc.compress(seq.frame(t), key=(t %% 3 == 0))[0] for t in range(n))
+assert out_p.cpu().numpy().tobytes() == want and out_s.cpu().tolist() == [int(s) for s in sizes]
+dist.destroy_process_group()
+print("RCCL_OK")
+''' % (root, root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert "RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
