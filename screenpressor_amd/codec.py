@@ -18,7 +18,13 @@ _LIB_PATH = os.environ.get("SCPR_AMD_LIB", os.path.join(_PKG, "libscpr_amd.so"))
 SCPR_OK, SCPR_E_DEVICE, SCPR_E_PARAM, SCPR_E_BAD_VERSION, SCPR_E_CAPACITY, SCPR_E_STREAM = 0, -1, -2, -3, -4, -5
 EXPORTS = ["scpr_create", "scpr_destroy", "scpr_init", "scpr_deinit", "scpr_crash_happened", "scpr_compress_frame",
            "scpr_decompress_frame", "scpr_compress_batch", "scpr_decompress_batch", "scpr_last_timing", "scpr_stage_name",
-           "scpr_debug_entries", "scpr_debug_colour_chain", "scpr_version"]
+           "scpr_debug_entries", "scpr_debug_colour_chain", "scpr_version",
+           # include/scpr_driver.h, include/scpr_avi.h
+           "scpr_driver_open", "scpr_driver_close", "scpr_driver_configure", "scpr_driver_compress_query", "scpr_driver_compress_get_format",
+           "scpr_driver_compress_get_size", "scpr_driver_compress_begin", "scpr_driver_compress_end", "scpr_driver_compress",
+           "scpr_driver_decompress_query", "scpr_driver_decompress_get_format", "scpr_driver_decompress_begin", "scpr_driver_decompress_end",
+           "scpr_driver_decompress", "scpr_infer_frame_type", "scpr_avi_create", "scpr_avi_write", "scpr_avi_finish", "scpr_avi_open",
+           "scpr_avi_get_info", "scpr_avi_frame_size", "scpr_avi_read", "scpr_avi_close"]
 
 
 class ScprParams(C.Structure):
