@@ -687,8 +687,13 @@ int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* 
   std::vector<u64> offs(nframes + 1, 0);
   for (int i = 0; i < nframes; i++) offs[i + 1] = offs[i] + sizes[i];
   std::vector<u32> heads(nframes, 0);
-  for (int i = 0; i < nframes; i++)
-    HIPCHK(hipMemcpyAsync(&heads[i], (const u8*)d_packets + offs[i], std::min<u32>(4, sizes[i]), hipMemcpyDeviceToHost, st));
+  if (nframes) {
+    HIPCHK(c->pktoff.reserve((size_t)(nframes + 1) * 8));
+    HIPCHK(c->outsizes.reserve((size_t)nframes * 4));
+    HIPCHK(hipMemcpyAsync(c->pktoff.p, offs.data(), (size_t)(nframes + 1) * 8, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_heads, dim3((nframes + 255) / 256), dim3(256), 0, st, (const u8*)d_packets, c->pktoff.as<u64>(), nframes, c->outsizes.as<u32>());
+    HIPCHK(hipMemcpyAsync(heads.data(), c->outsizes.p, (size_t)nframes * 4, hipMemcpyDeviceToHost, st));
+  }
   HIPCHK(hipStreamSynchronize(st));
   int done = 0;
   HIPCHK(c->err.reserve(64));

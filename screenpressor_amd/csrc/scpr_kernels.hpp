@@ -880,6 +880,16 @@ __global__ __launch_bounds__(256) void k_gather(const Packet* __restrict__ pk, i
 }
 
 // ---------------------------------------------------------------- decode ---
+// first four bytes of every packet (header byte + flat colour) in one launch: one small D2H copy instead of one per frame
+__global__ __launch_bounds__(256) void k_heads(const u8* __restrict__ packets, const u64* __restrict__ offs, int n, u32* __restrict__ heads) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const u64 a = offs[i], len = offs[i + 1] - a;
+  u32 v = 0;
+  for (u64 k = 0; k < 4 && k < len; k++) v |= (u32)packets[a + k] << (8 * k);
+  heads[i] = v;
+}
+
 // (the decoder proper is in scpr_wave.hpp)
 // flat key frame: every pixel = the 3 bytes after the header (screencap.cpp:1537-1553)
 __global__ __launch_bounds__(256) void k_fill_flat(u8* planes, Geom g, int slot, u32 rgb) {
