@@ -404,7 +404,7 @@ struct WaveModel {
     if (h.kind == 6) {
       step = kStepHash << h.fshift;
       const bool present = (rdl(bits, own) >> kk) & 1u;
-      if (!present) {
+      if (SCPR_UNLIKELY(!present)) {
         if (h.d >= kHashMaxSyms) {  // 41st symbol: becomes kind 7, uncounted (:631, Cx7::create(const Cx6&) :868-915)
           const int wdt = 1 << h.fshift, base = wdt - (wdt >> 1);
           for (int q = 0; q < 4; q++)
@@ -427,7 +427,7 @@ struct WaveModel {
     for (int q = 0; q < 4; q++)
       if (lane == own && q == kk) cn[q] += step;
     h.total += step;
-    if (h.total + step > kProbScale) {
+    if (SCPR_UNLIKELY(h.total + step > kProbScale)) {
       if (h.kind == 7) {  // Cx7::incrCnt rebuild, :963-980
         for (int q = 0; q < 4; q++) {
           fr[q] = cn[q];
@@ -775,7 +775,7 @@ struct WaveDec : WaveModel {
     wave_fence();
     int tot = (int)rfl((u32)tot0) + kStepDense;
     advance(s >> 16, s & 0xFFFF, v);
-    if (tot + kStepDense > kProbScale) tot = fixed_rebuild<PER>(fc, cnt, nsym);
+    if (SCPR_UNLIKELY(tot + kStepDense > kProbScale)) tot = fixed_rebuild<PER>(fc, cnt, nsym);
     if (lane == 0) L.fx.ftot[ti] = tot;
     count();
     return sym;
@@ -1023,7 +1023,7 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
     for (size_t q = (bytes & ~(size_t)15) + lane; q < bytes; q += 64) cur[q] = prv[q];
   }
   const u32 first = *(const volatile u8*)head;
-  if (!(first & 1u)) return;  // nothing changed (:1286-1291)
+  if (SCPR_UNLIKELY(!(first & 1u))) return;  // nothing changed (:1286-1291)
   D.stream_init(head + 1);
   auto get_x = [&]() __attribute__((always_inline)) {
     D.tick();
@@ -1034,7 +1034,7 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
   lo = get_x();
   hi = get_x();
   const int xx2 = (hi << 8) + lo;
-  if (xx2 >= nblocks || xx1 > xx2) {
+  if (SCPR_UNLIKELY(xx2 >= nblocks || xx1 > xx2)) {
     D.bad = true;
     return;
   }
@@ -1045,7 +1045,7 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
     const int c = D.fixed_bt();
     D.tick();
     const int n = D.fixed_x(1);
-    if (n < 1 || b + n > nblocks) {
+    if (SCPR_UNLIKELY(n < 1 || b + n > nblocks)) {
       D.bad = true;
       break;
     }
@@ -1112,7 +1112,7 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
       y2 = y1 + a3 + 1;
       x1 += a0;
       y1 += a1;
-      if (x2 > W || y2 > H || x1 >= x2 || y1 >= y2) {
+      if (SCPR_UNLIKELY(x2 > W || y2 > H || x1 >= x2 || y1 >= y2)) {
         D.bad = true;
         break;
       }
@@ -1129,12 +1129,12 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
       }
       lastmx = mx;
       lastmy = my;
-      if (x1 + mx < 0 || y1 + my < 0 || x2 + mx > W || y2 + my > H) {
+      if (SCPR_UNLIKELY(x1 + mx < 0 || y1 + my < 0 || x2 + mx > W || y2 + my > H)) {
         D.bad = true;
         break;
       }
       if (lane == 0) jobs[njobs] = make_uint2((u32)x1 | ((u32)y1 << 13) | ((u32)(w - 1) << 26), (u32)(h - 1) | ((u32)(mx + 512) << 4) | ((u32)(my + 512) << 14));
-      if (++njobs == 256) flush_jobs();
+      if (SCPR_UNLIKELY(++njobs == 256)) flush_jobs();
       continue;
     }
     if (njobs) flush_jobs();  // a copied block may be this rect's left/top context
@@ -1169,12 +1169,12 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
       }
       D.tick();
       int rem = D.fixed_n(pt);
-      if (rem < 1) {
+      if (SCPR_UNLIKELY(rem < 1)) {
         D.bad = true;
         break;
       }
       while (rem > 0) {
-        if (y >= y2) {
+        if (SCPR_UNLIKELY(y >= y2)) {
           D.bad = true;
           break;
         }
