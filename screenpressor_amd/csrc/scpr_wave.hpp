@@ -235,6 +235,7 @@ struct WaveModel {
       return;
     }
     h.dense = alloc_dense();
+    if (lane == 0) r[2] = h.dense;  // the table index only changes here: the per-symbol header store leaves word 2 alone
     DenseTab* t = arena.tabs + h.dense;
     int fr[4], cn[4];
     if (h.kind == 2) {  // Cx6::create23, ans_contexts.h:491-531
@@ -371,6 +372,7 @@ struct WaveModel {
     atomicOr(&r[4 + (lane >> 3)], bits << ((lane & 7) * 4));
     wave_fence();
     h.dense = alloc_dense();
+    if (lane == 0) r[2] = h.dense;  // the table index only changes here: the per-symbol header store leaves word 2 alone
     const int sum = write_dense(arena.tabs + h.dense, fr, cn);
     h.kind = 6;
     h.fshift = s2;
@@ -842,7 +844,6 @@ struct WaveDec : WaveModel {
       if (lane < 16) r[4 + lane] = w;
     }
     if (lane == 0) *(uint2*)r = make_uint2(pack0(h), pack1(h));
-    if (lane == 0) r[2] = h.dense;
     wave_fence();
     count();
     return c;
