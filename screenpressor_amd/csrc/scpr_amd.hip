@@ -93,7 +93,7 @@ struct scpr_codec {
   // per-slot worst-case buffers
   DevBuf planes, exitmap, entry, runrec, tilecnt, tileoff, hdrrec, hdrcnt, frametot;
   // per-batch buffers
-  DevBuf flags, slotlist, genlist, bases, totals, runs, runpos, keys[2], vals[2], hist, cstart, sorttmp, scantmp, entries, ranges;
+  DevBuf flags, slotlist, genlist, bases, totals, runs, runpos, keys[2], vals[2], cstart, sorttmp, entries, ranges;
   DevBuf rblocks, rscratch, rsize, packets, pktoff, blkdst, outsizes, total64, arena, arena_top, err, rcp;
   DevBuf decframes, decstates, hoststage_in, hoststage_out, chainlists, chaincounts;
   // P-frame buffers
@@ -341,7 +341,6 @@ static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int n
     HIPCHK(c->keys[k].reserve(Ctot * 4 + 64));
     HIPCHK(c->vals[k].reserve(Ctot * 4 + 64));
   }
-  HIPCHK(c->hist.reserve((nchains + 1) * 4));
   HIPCHK(c->cstart.reserve((nchains + 1) * 4));
   HIPCHK(c->entries.reserve(Ttot * 4 + 64));
   // dense-table arena: tables of the live generation stay valid while it continues
@@ -352,14 +351,13 @@ static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int n
   const size_t arena_cap = c->arena_used_bound + Ctot / 16 + 64;
   HIPCHK(c->arena.reserve_keep(arena_cap * sizeof(DenseTab), c->arena_used_bound * sizeof(DenseTab), st));
   c->arena_used_bound = arena_cap;
-  HIPCHK(hipMemsetAsync(c->hist.p, 0, (nchains + 1) * 4, st));
   c->dbg_entries = (int64_t)Ttot;
 
   stage_begin(c, ST_SYMBOLS);
   if (ni)
     hipLaunchKernelGGL(k_symbols, dim3(g.ntiles + 1, ni), dim3(256), 0, st, planes, g, d_slots, c->genlist.as<int>(), c->fidx.as<int>(), c->bases.as<FrameBase>(), c->runrec.as<u32>(),
                        c->tilecnt.as<u32>(), c->tileoff.as<u32>(), c->entry.as<u8>(), c->hdrrec.as<u32>(), c->runs.as<u32>(), c->runpos.as<u32>(), c->keys[0].as<u32>(),
-                       c->vals[0].as<u32>(), c->hist.as<u32>());
+                       c->vals[0].as<u32>());
   if (np) {
     std::vector<PBase> pbv(np);
     for (int k = 0; k < np; k++) {
@@ -369,17 +367,13 @@ static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int n
     HIPCHK(hipMemcpyAsync(c->pbase.p, pbv.data(), np * sizeof(PBase), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_pemit, dim3((nblocks + 63) / 64 + 1, np), dim3(64), 0, st, planes, g, c->pframes.as<PFrame>(), c->pbase.as<PBase>(), c->binfo.as<u32>(), c->btype.as<u8>(),
                        c->bmv.as<u32>(), c->boff.as<BOff>(), c->bflag.as<u32>(), c->pinfo.as<int>(), mp, c->runs.as<u32>(), c->runpos.as<u32>(), c->keys[0].as<u32>(),
-                       c->vals[0].as<u32>(), c->hist.as<u32>(), c->misc.as<u32>(), c->miscpos.as<u32>(), c->entries.as<u32>());
+                       c->vals[0].as<u32>(), c->misc.as<u32>(), c->miscpos.as<u32>(), c->entries.as<u32>());
     HIPCHK(hipStreamSynchronize(st));  // pbv is host memory
   }
   stage_end(c, ST_SYMBOLS);
 
   stage_begin(c, ST_SORT);
   {
-    size_t tmp = 0;
-    HIPCHK(rocprim::exclusive_scan(nullptr, tmp, c->hist.as<u32>(), c->cstart.as<u32>(), 0u, nchains + 1, rocprim::plus<u32>(), st));
-    HIPCHK(c->scantmp.reserve(tmp));
-    HIPCHK(rocprim::exclusive_scan(c->scantmp.p, tmp, c->hist.as<u32>(), c->cstart.as<u32>(), 0u, nchains + 1, rocprim::plus<u32>(), st));
     int genbits = 1;
     while ((1 << genbits) < ngens) genbits++;
     if (Ctot > 0) {
@@ -388,6 +382,7 @@ static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int n
       HIPCHK(c->sorttmp.reserve(stmp));
       HIPCHK(rocprim::radix_sort_pairs(c->sorttmp.p, stmp, c->keys[0].as<u32>(), c->keys[1].as<u32>(), c->vals[0].as<u32>(), c->vals[1].as<u32>(), Ctot, 8, 22 + genbits, st));
     }
+    hipLaunchKernelGGL(k_chain_starts, dim3((unsigned)((Ctot + 256) / 256)), dim3(256), 0, st, c->keys[1].as<u32>(), (u32)Ctot, (u32)nchains, c->cstart.as<u32>());
   }
   stage_end(c, ST_SORT);
 
@@ -506,7 +501,7 @@ void scpr_destroy(scpr_codec* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   DevBuf* all[] = {&c->planes, &c->exitmap, &c->entry, &c->runrec, &c->tilecnt, &c->tileoff, &c->hdrrec, &c->hdrcnt, &c->frametot, &c->flags, &c->slotlist, &c->genlist,
-                   &c->bases, &c->totals, &c->runs, &c->runpos, &c->keys[0], &c->keys[1], &c->vals[0], &c->vals[1], &c->hist, &c->cstart, &c->sorttmp, &c->scantmp,
+                   &c->bases, &c->totals, &c->runs, &c->runpos, &c->keys[0], &c->keys[1], &c->vals[0], &c->vals[1], &c->cstart, &c->sorttmp,
                    &c->entries, &c->ranges, &c->rblocks, &c->rscratch, &c->rsize, &c->packets, &c->pktoff, &c->blkdst, &c->outsizes, &c->total64, &c->arena,
                    &c->arena_top, &c->err, &c->rcp, &c->decframes, &c->decstates, &c->hoststage_in, &c->hoststage_out, &c->chainlists, &c->chaincounts, &c->kinds, &c->pidx, &c->fidx, &c->pframes, &c->pflag, &c->binfo, &c->smv, &c->btype, &c->bmv, &c->bcnt, &c->boff, &c->bflag, &c->pinfo, &c->ptot, &c->pbase, &c->misc, &c->miscpos, &c->miscranges, &c->mvs, &c->fixed_persist, &c->misc_persist, &c->colour_persist, &c->decgops, &c->decfixed, &c->dec_fixed_persist, &c->dec_colour_persist, &c->mvdict, &c->mvpre};
   for (DevBuf* b : all) b->release();

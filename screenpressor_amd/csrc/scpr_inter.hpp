@@ -590,7 +590,7 @@ struct PBase {  // per P-frame (device copy of the relevant FrameBase fields)
 __global__ __launch_bounds__(64) void k_pemit(const u8* __restrict__ planes, Geom g, const PFrame* __restrict__ pf, const PBase* __restrict__ pb, const u32* __restrict__ binfo,
                                               const u8* __restrict__ btype, const u32* __restrict__ bmv, const BOff* __restrict__ boff, const u32* __restrict__ bflag,
                                               const int* __restrict__ pinfo, MvParams mp, u32* __restrict__ runs, u32* __restrict__ runpos, u32* __restrict__ keys,
-                                              u32* __restrict__ vals, u32* __restrict__ hist, u32* __restrict__ misc, u32* __restrict__ miscpos, u32* __restrict__ entries) {
+                                              u32* __restrict__ vals, u32* __restrict__ misc, u32* __restrict__ miscpos, u32* __restrict__ entries) {
   const int pi = blockIdx.y;
   const int nbx = (g.W + 15) >> 4, nby = (g.H + 15) >> 4, nblocks = nbx * nby;
   const PBase fb = pb[pi];
@@ -677,7 +677,7 @@ __global__ __launch_bounds__(64) void k_pemit(const u8* __restrict__ planes, Geo
     runpos[ri] = pos;
     ri++;
     if (type == 0) {
-      emit_colour(fb.gen, ld3(cur + first), pg, pbv, pos + 1, ci, keys, vals, hist);
+      emit_colour(fb.gen, ld3(cur + first), pg, pbv, pos + 1, ci, keys, vals);
       ci += 3;
     }
     pos += 2 + (type == 0 ? 3 : 0);

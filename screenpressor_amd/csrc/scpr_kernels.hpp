@@ -539,7 +539,7 @@ __global__ void k_bases(const int* __restrict__ kinds, const int* __restrict__ p
 
 // colour context ids from the two previous bytes (SC_CXSHIFT = 2, MAKECX1,
 // screencap.h:35-36; WritePixel/EncodeRGB, screencap.cpp:609-643)
-__device__ __forceinline__ void emit_colour(u32 gen, u32 pix, u32 prev_g, u32 prev_b, u32 pos, u32 idx, u32* __restrict__ keys, u32* __restrict__ vals, u32* __restrict__ hist) {
+__device__ __forceinline__ void emit_colour(u32 gen, u32 pix, u32 prev_g, u32 prev_b, u32 pos, u32 idx, u32* __restrict__ keys, u32* __restrict__ vals) {
   const u32 c0 = pix & 255, c1 = (pix >> 8) & 255, c2 = (pix >> 16) & 255;
   const u32 cx0 = (prev_b >> 2) | ((prev_g >> 2) << 6);
   const u32 cx1 = (c0 >> 2) | ((prev_b >> 2) << 6);
@@ -551,9 +551,18 @@ __device__ __forceinline__ void emit_colour(u32 gen, u32 pix, u32 prev_g, u32 pr
   vals[idx] = pos;
   vals[idx + 1] = pos + 1;
   vals[idx + 2] = pos + 2;
-  atomicAdd(&hist[gen * NCOLCTX + k0], 1u);
-  atomicAdd(&hist[gen * NCOLCTX + k1], 1u);
-  atomicAdd(&hist[gen * NCOLCTX + k2], 1u);
+}
+// Chain offsets from the sorted keys: cstart[q] = first sorted position whose chain id (generation * NCOLCTX +
+// plane/context) is >= q, for q = 0 .. nchains (so cstart[nchains] = n).  One thread per sorted position plus a
+// sentinel; a thread fills the (usually empty) gap of chains between its predecessor and itself.  This replaces a
+// histogram of one global atomic per colour symbol, most of them on a handful of hot contexts.
+__global__ __launch_bounds__(256) void k_chain_starts(const u32* __restrict__ skeys, u32 n, u32 nchains, u32* __restrict__ cstart) {
+  const u32 i = blockIdx.x * 256 + threadIdx.x;
+  if (i > n) return;
+  auto chain = [](u32 key) { return (key >> 22) * (u32)NCOLCTX + ((key >> 8) & 0x3FFFu); };
+  const u32 qi = i < n ? chain(skeys[i]) : nchains;
+  const u32 q0 = i > 0 ? chain(skeys[i - 1]) + 1 : 0u;
+  for (u32 q = q0; q <= qi; q++) cstart[q] = i;
 }
 
 // unified run list + colour symbols.  grid = (ntiles + 1, frames); the extra
@@ -561,7 +570,7 @@ __device__ __forceinline__ void emit_colour(u32 gen, u32 pix, u32 prev_g, u32 pr
 __global__ __launch_bounds__(256) void k_symbols(const u8* __restrict__ planes, Geom g, const int* __restrict__ slots, const int* __restrict__ gens, const int* __restrict__ fidx,
                                                  const FrameBase* __restrict__ bases, const u32* __restrict__ runrec, const u32* __restrict__ tilecnt,
                                                  const u32* __restrict__ tileoff, const u8* __restrict__ entry, const u32* __restrict__ hdrrec,
-                                                 u32* __restrict__ runs, u32* __restrict__ runpos, u32* __restrict__ keys, u32* __restrict__ vals, u32* __restrict__ hist) {
+                                                 u32* __restrict__ runs, u32* __restrict__ runpos, u32* __restrict__ keys, u32* __restrict__ vals) {
   __shared__ int wsum[5];
   const int fi = blockIdx.y, slot = slots[fi], tid = threadIdx.x;
   const u32 gen = (u32)gens[fi];
@@ -582,7 +591,7 @@ __global__ __launch_bounds__(256) void k_symbols(const u8* __restrict__ planes, 
         pg = pp[1];
         pb = pp[2];
       }
-      emit_colour(gen, ld3(px), pg, pb, pos, fb.col_base + 3 * j, keys, vals, hist);
+      emit_colour(gen, ld3(px), pg, pb, pos, fb.col_base + 3 * j, keys, vals);
     }
     return;
   }
@@ -617,7 +626,7 @@ __global__ __launch_bounds__(256) void k_symbols(const u8* __restrict__ planes, 
         const int y = p / g.W, x = p - y * g.W;
         const u8* px = plane + (size_t)y * g.S + x * 3;
         const u8* pp = x > 0 ? px - 3 : plane + (size_t)(y - 1) * g.S + (g.W - 1) * 3;
-        emit_colour(gen, ld3(px), pp[1], pp[2], pos + 1, fb.col_base + 3 * (Hr + litidx), keys, vals, hist);
+        emit_colour(gen, ld3(px), pp[1], pp[2], pos + 1, fb.col_base + 3 * (Hr + litidx), keys, vals);
       }
     }
     lit_run += tl;
