@@ -109,6 +109,11 @@ struct scpr_codec {
   // decoder side of the same
   DevBuf decgops, decfixed, dec_fixed_persist, dec_colour_persist;
   bool dec_live = false;
+  // second stream: the fixed-model chains run beside the colour chains (they write disjoint entries)
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  std::vector<GenRange> h_ranges;      // host images of the per-generation ranges (uploaded asynchronously: they must outlive the call)
+  std::vector<MiscRange> h_miscranges;
   // timing
   hipEvent_t ev[ST_COUNT + 1][2];
   bool ev_used[ST_COUNT];
@@ -117,11 +122,11 @@ struct scpr_codec {
   int64_t dbg_entries = 0;
 };
 
-static void stage_begin(scpr_codec* c, int s) {
-  if (!c->ev_used[s]) (void)hipEventRecord(c->ev[s][0], c->stream);
+static void stage_begin(scpr_codec* c, int s, hipStream_t on = nullptr) {
+  if (!c->ev_used[s]) (void)hipEventRecord(c->ev[s][0], on ? on : c->stream);
 }
-static void stage_end(scpr_codec* c, int s) {
-  (void)hipEventRecord(c->ev[s][1], c->stream);
+static void stage_end(scpr_codec* c, int s, hipStream_t on = nullptr) {
+  (void)hipEventRecord(c->ev[s][1], on ? on : c->stream);
   c->ev_used[s] = true;
 }
 static void timing_reset(scpr_codec* c) {
@@ -387,8 +392,10 @@ static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int n
   stage_end(c, ST_SORT);
 
   // per-generation ranges of the run list and of the misc list (frames of a generation are consecutive)
-  std::vector<GenRange> rg(ngens, GenRange{0, 0});
-  std::vector<MiscRange> mr(ngens, MiscRange{0, 0});
+  std::vector<GenRange>& rg = c->h_ranges;
+  std::vector<MiscRange>& mr = c->h_miscranges;
+  rg.assign(ngens, GenRange{0, 0});
+  mr.assign(ngens, MiscRange{0, 0});
   {
     std::vector<bool> seen(ngens, false);
     for (int i = 0; i < n; i++) {
@@ -405,17 +412,24 @@ static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int n
   }
   HIPCHK(hipMemcpyAsync(c->ranges.p, rg.data(), ngens * sizeof(GenRange), hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(c->miscranges.p, mr.data(), ngens * sizeof(MiscRange), hipMemcpyHostToDevice, st));
-  stage_begin(c, ST_FIXED);
+  // The fixed-model chains (run lengths, pixel types, P-frame symbols) and the colour chains read the same lists
+  // and write disjoint coder entries: they run side by side on two streams and join before the coder.
   const int buf_in = c->live_buf, buf_out = ngens > 1 ? 1 - c->live_buf : c->live_buf;
-  hipLaunchKernelGGL(k_fixed_chain, dim3(ngens), dim3(768), 0, st, c->runs.as<u32>(), c->runpos.as<u32>(), c->ranges.as<GenRange>(), ngens, load_first ? 1 : 0,
-                     c->fixed_persist.as<FixedPersist>() + buf_in * 12, c->fixed_persist.as<FixedPersist>() + buf_out * 12, c->entries.as<u32>());
-  if (Mtot)
-    hipLaunchKernelGGL(k_misc_chain, dim3(MC_COUNT, ngens), dim3(64), 0, st, c->misc.as<u32>(), c->miscpos.as<u32>(), c->miscranges.as<MiscRange>(), ngens, load_first ? 1 : 0,
-                       c->misc_persist.as<FixedPersist>() + buf_in * MC_COUNT, c->misc_persist.as<FixedPersist>() + buf_out * MC_COUNT, c->entries.as<u32>());
-  else if (!(load_first && ngens == 1))  // a new generation without any P-frame symbol: its P-frame models are the renewed ones, not the kept ones
-    HIPCHK(hipMemsetAsync(c->misc_persist.as<FixedPersist>() + buf_out * MC_COUNT, 0, MC_COUNT * sizeof(FixedPersist), st));
-  stage_end(c, ST_FIXED);
-  HIPCHK(hipStreamSynchronize(st));  // rg / mr are host memory
+  {
+    hipStream_t s2 = c->stream2;
+    HIPCHK(hipEventRecord(c->ev_fork, st));
+    HIPCHK(hipStreamWaitEvent(s2, c->ev_fork, 0));
+    stage_begin(c, ST_FIXED, s2);
+    hipLaunchKernelGGL(k_fixed_chain, dim3(ngens), dim3(768), 0, s2, c->runs.as<u32>(), c->runpos.as<u32>(), c->ranges.as<GenRange>(), ngens, load_first ? 1 : 0,
+                       c->fixed_persist.as<FixedPersist>() + buf_in * 12, c->fixed_persist.as<FixedPersist>() + buf_out * 12, c->entries.as<u32>());
+    if (Mtot)
+      hipLaunchKernelGGL(k_misc_chain, dim3(MC_COUNT, ngens), dim3(64), 0, s2, c->misc.as<u32>(), c->miscpos.as<u32>(), c->miscranges.as<MiscRange>(), ngens, load_first ? 1 : 0,
+                         c->misc_persist.as<FixedPersist>() + buf_in * MC_COUNT, c->misc_persist.as<FixedPersist>() + buf_out * MC_COUNT, c->entries.as<u32>());
+    else if (!(load_first && ngens == 1))  // a new generation without any P-frame symbol: its P-frame models are the renewed ones, not the kept ones
+      HIPCHK(hipMemsetAsync(c->misc_persist.as<FixedPersist>() + buf_out * MC_COUNT, 0, MC_COUNT * sizeof(FixedPersist), s2));
+    stage_end(c, ST_FIXED, s2);
+    HIPCHK(hipEventRecord(c->ev_join, s2));
+  }
   stage_begin(c, ST_COLOUR);
   {
     Arena ar{c->arena.as<DenseTab>(), c->arena_top.as<u32>(), (u32)arena_cap, c->err.as<u32>()};
@@ -437,6 +451,7 @@ static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int n
     }
   }
   stage_end(c, ST_COLOUR);
+  HIPCHK(hipStreamWaitEvent(st, c->ev_join, 0));  // the coder needs the entries of both
   return SCPR_OK;
 }
 
@@ -455,7 +470,8 @@ scpr_codec* scpr_create(int device) {
   if (hipSetDevice(device) != hipSuccess) return nullptr;
   scpr_codec* c = new scpr_codec;
   c->device = device;
-  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
     delete c;
     return nullptr;
   }
@@ -500,6 +516,7 @@ void scpr_destroy(scpr_codec* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
+  (void)hipStreamSynchronize(c->stream2);
   DevBuf* all[] = {&c->planes, &c->exitmap, &c->entry, &c->runrec, &c->tilecnt, &c->tileoff, &c->hdrrec, &c->hdrcnt, &c->frametot, &c->flags, &c->slotlist, &c->genlist,
                    &c->bases, &c->totals, &c->runs, &c->runpos, &c->keys[0], &c->keys[1], &c->vals[0], &c->vals[1], &c->cstart, &c->sorttmp,
                    &c->entries, &c->ranges, &c->rblocks, &c->rscratch, &c->rsize, &c->packets, &c->pktoff, &c->blkdst, &c->outsizes, &c->total64, &c->arena,
@@ -508,6 +525,9 @@ void scpr_destroy(scpr_codec* c) {
   for (int s = 0; s < ST_COUNT + 1; s++)
     for (int k = 0; k < 2; k++) (void)hipEventDestroy(c->ev[s][k]);
   (void)hipStreamDestroy(c->stream);
+  (void)hipStreamDestroy(c->stream2);
+  (void)hipEventDestroy(c->ev_fork);
+  (void)hipEventDestroy(c->ev_join);
   delete c;
 }
 
