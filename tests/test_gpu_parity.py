@@ -383,3 +383,23 @@ def test_corrupt_version2_streams_are_survived():
             pass
     r, out = gpu.DecompressFrame(key, 0)
     assert r == 1 and np.array_equal(out.reshape(h, w, 4)[..., :3], seq.frame(0)[..., :3])
+
+
+def test_batch_longer_than_the_slot_pool():
+    """One call with more frames than the codec keeps planes for (512): the call is processed in chunks and
+    every piece of cross-frame state has to cross the chunk borders like it crosses call borders."""
+    import torch
+    w, h, n = 64, 48, 1100
+    seq = DesktopSequence(w, h, seed=41, sparkles=10)
+    rng = np.random.default_rng(9)
+    frames = np.stack([seq.frame(t // 3) if t % 3 else seq.frame(t) for t in range(n)])
+    want_key = [t == 0 or rng.random() < 0.02 for t in range(n)]
+    ora = O.OracleCodec(w, h, 32)
+    ref = [ora.compress(f, key=k) for f, k in zip(frames, want_key)]
+    gpu = _codec(w, h)
+    dev = torch.from_numpy(frames).cuda().reshape(n, -1)
+    pk, sizes, fts = gpu.CompressBatch(dev, [0 if k else 1 for k in want_key])
+    assert [int(s) for s in sizes] == [len(p) for p, _ in ref] and list(fts) == [ft for _, ft in ref]
+    assert pk.cpu().numpy().tobytes() == b"".join(p for p, _ in ref)
+    r, out = _codec(w, h).DecompressBatch(pk, sizes, fts)
+    assert r == n and torch.equal(out.reshape(n, -1), dev)
