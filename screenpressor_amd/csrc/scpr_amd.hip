@@ -666,7 +666,7 @@ int64_t scpr_compress_batch(scpr_codec* c, const void* d_frames, int nframes, in
     HIPCHK(hipMemcpyAsync(c->packets.p, pk.data(), (size_t)n * sizeof(Packet), hipMemcpyHostToDevice, st));
     if (nb) {
       stage_begin(c, ST_RANS);
-      hipLaunchKernelGGL(k_rans, dim3((nb + 63) / 64), dim3(64), 0, st, c->entries.as<u32>(), c->rblocks.as<RansBlock>(), nb, c->rcp.as<RansRcp>(), c->rscratch.as<u8>(),
+      hipLaunchKernelGGL(k_rans, dim3((nb + 63) / 64), dim3(256), 0, st, c->entries.as<u32>(), c->rblocks.as<RansBlock>(), nb, c->rcp.as<RansRcp>(), c->rscratch.as<u8>(),
                          c->rsize.as<u32>());
       stage_end(c, ST_RANS);
     }

@@ -768,61 +768,138 @@ struct RansBlock {
 // One lane per block of <= 131072 entries, processed last to first; bytes are
 // written backwards into the block's scratch (ransmt.h:116-134).  x / freq uses
 // the exact 32-bit reciprocal (rans_byte.h:171-240).
-// One coder entry, loop-free.  The renormalisation emits at most two bytes (x < 2^31 and
-// x_max = freq << 19 >= 2^19): both are stored every time, as one 16-bit store just below the write
-// pointer, and the pointer moves by the number that count; what is left below it is overwritten by the
-// next entry (the block's scratch has room for two spare bytes).  The state update is ryg's
-// x + bias + (x / freq) * (4096 - freq) (rans_byte.h:199-240) with the exact 32-bit reciprocal, which also
-// covers freq = 1 (bias + 4095, quotient x - 1).  A raw byte (freq 0) is the same code with a limit no
-// state reaches and a zero multiplier.  `r` = reciprocal of the entry's frequency (fetched ahead of the chain).
-__device__ __forceinline__ void rans_put(u32& x, u8*& p, u32 v, const RansRcp r) {
+// One lane per block of <= 131072 entries, processed last to first; bytes are written backwards into the
+// block's scratch (ransmt.h:116-134).  The chain over the coder state is the whole cost (a lone wave issues a
+// dependent instruction every ~8 cycles), so the workgroup is a three-stage pipeline of waves (two of them feed), one trip
+// (16 entries per lane) apart, handing over through LDS:
+//   feeder  loads the entries, looks up the reciprocals, lays a 16-byte record per entry:
+//           { x_max, reciprocal, (4096 - freq) | shift << 24, bias | raw byte << 16 | raw << 31 }
+//   coder   only advances the state (13 instructions per entry) and passes { state before, bytes out } on
+//   writer  turns that into bytes: the renormalisation emits at most two (x < 2^31, x_max = freq << 19 >= 2^19);
+//           both are stored every time, as one 16-bit store just below the write position, which then moves by
+//           the number that count; what is left below is overwritten by the next entry (the block's scratch
+//           has room for two spare bytes).
+// The state update is ryg's x + bias + (x / freq) * (4096 - freq) (rans_byte.h:199-240) with the exact 32-bit
+// reciprocal, which also covers freq = 1 (bias + 4095, quotient x - 1).  A raw byte (freq 0) is the same code
+// with a limit no state reaches and a zero multiplier; so is the padding of a short block.
+__device__ __forceinline__ uint4 rans_record(u32 v, const RansRcp r) {
   const u32 fr = v & 0xFFFF, cf = v >> 16;
   const bool raw = fr == 0;
-  const u32 x_max = raw ? 0xFFFFFFFFu : fr << 19;  // ((L >> 12) << 8) * freq
-  const u32 n = (u32)(x >= x_max) + (u32)((x >> 8) >= x_max);
-  const u16 out = raw ? (u16)(cf << 8) : __builtin_bswap16((u16)x);  // the first byte out sits at the higher address
-  __builtin_memcpy(p - 2, &out, 2);
-  p -= n + (raw ? 1u : 0u);
-  const u32 xs = x >> (8 * n);
-  const u32 q = __umulhi(xs, r.rcp) >> r.shift;
-  const u32 cmpl = raw ? 0u : (u32)kProbScale - fr, bias = raw ? 0u : cf + r.pad;
-  x = xs + bias + q * cmpl;
+  uint4 o;
+  o.x = raw ? 0xFFFFFFFFu : fr << 19;                                   // x_max = ((L >> 12) << 8) * freq
+  o.y = raw ? 0u : r.rcp;                                               // raw: quotient 0
+  o.z = raw ? 0u : ((u32)kProbScale - fr) | ((u32)r.shift << 24);       // multiplier in the low 24 bits (what a 24-bit multiply reads), shift above
+  o.w = raw ? (0x80000000u | (cf << 16)) : cf + r.pad;                  // bias in the low 16 bits; raw: flag in the sign bit, the byte in bits 16-23
+  return o;
 }
-__global__ __launch_bounds__(64) void k_rans(const u32* __restrict__ entries, const RansBlock* __restrict__ blocks, int nblocks, const RansRcp* __restrict__ rcp_g,
-                                             u8* __restrict__ scratch, u32* __restrict__ blksize) {
-  __shared__ RansRcp lrcp[kProbScale + 1];  // reciprocals in LDS: the lookup is off the HBM path
-  for (int i = threadIdx.x; i <= kProbScale; i += 64) lrcp[i] = rcp_g[i];
+// coder: returns what the writer needs, { state before the step, bytes out (0..2) | raw flag and byte }
+__device__ __forceinline__ uint2 rans_step(u32& x, const uint4 r) {
+  const u32 n = (u32)(x >= r.x) + (u32)((x >> 8) >= r.x);
+  const uint2 pass = make_uint2(x, n | (r.w & 0xFFFF0000u));
+  const u32 xs = x >> (8 * n);
+  const u32 q = __umulhi(xs, r.y) >> (r.z >> 24);
+  x = __umul24(q, r.z) + (xs + (r.w & 0xFFFFu));
+  return pass;
+}
+// writer: straight-line vector code (selects, no exec-masked branches)
+__device__ __forceinline__ void rans_emit(u8* const base, u32& off, const uint2 pass) {
+  const u32 n = pass.y & 3u;
+  const u32 rawmask = (u32)((int)pass.y >> 31);                         // all ones for a raw byte
+  const u32 swapped = __builtin_amdgcn_perm(0u, pass.x, 0x0c0c0001u);   // bytes 0,1 of the state exchanged: the first byte out sits at the higher address
+  const u32 rawval = __builtin_amdgcn_perm(0u, pass.y, 0x0c0c020cu);    // the raw byte in byte 1
+  const u16 o16 = (u16)((rawmask & rawval) | (~rawmask & swapped));
+  __builtin_memcpy(base + (size_t)off - 2, &o16, 2);                    // just below the write position
+  off -= n - rawmask;                                                   // n bytes, or one raw byte
+}
+constexpr int RANS_TRIP = 16;
+__global__ __launch_bounds__(256) void k_rans(const u32* __restrict__ entries, const RansBlock* __restrict__ blocks, int nblocks, const RansRcp* __restrict__ rcp_g,
+                                              u8* __restrict__ scratch, u32* __restrict__ blksize) {
+  __shared__ RansRcp lrcp[kProbScale + 1];          // reciprocals in LDS: the lookup is off the HBM path
+  __shared__ uint4 rec[2][RANS_TRIP][64];           // feeders -> coder, two trips
+  __shared__ uint2 hand[2][RANS_TRIP][64];          // coder -> writer, two trips
+  __shared__ u32 xfinal[64];
+  for (int i = threadIdx.x; i <= kProbScale; i += 256) lrcp[i] = rcp_g[i];
+  const int lane = threadIdx.x & 63, role = threadIdx.x >> 6;  // 0 coder, 1 and 2 feeders (half a trip each), 3 writer
+  const int b = blockIdx.x * 64 + lane;
+  const bool live = b < nblocks;
+  RansBlock blk{0, 0};
+  if (live) blk = blocks[b];
+  int trips = (int)((blk.len + RANS_TRIP - 1) / RANS_TRIP);
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) trips = max(trips, __shfl_xor(trips, d));
   __syncthreads();
-  const int b = blockIdx.x * 64 + threadIdx.x;
-  if (b >= nblocks) return;
-  const RansBlock blk = blocks[b];
-  u8* const end = scratch + (size_t)(b + 1) * RANS_SCRATCH;
-  u8* p = end;
-  u32 x = kRansL;
   const u32* e = entries + blk.begin;
-  int i = (int)blk.len;
-  for (int r = i & 15; r > 0; r--) {  // ragged top
-    const u32 v = e[--i];
-    rans_put(x, p, v, lrcp[v & 0xFFFF]);  // entry 0 of the table is that of freq 1
+  constexpr int HALF = RANS_TRIP / 2;
+  const int k0 = role == 2 ? HALF : 0;  // the feeder's half of a trip
+  // entries of trip t: [len - 16 (t + 1), len - 16 t); indices below 0 do not exist (the short trip of a block comes last)
+  auto fetch = [&](int t, u32 v[HALF]) {
+    const int lo = (int)blk.len - RANS_TRIP * (t + 1) + k0;
+#pragma unroll
+    for (int g4 = 0; g4 < HALF / 4; g4++) {
+      const int i = lo + 4 * g4;
+      if (i >= 0) {
+        uint4 q;
+        __builtin_memcpy(&q, e + i, 16);
+        v[4 * g4] = q.x;
+        v[4 * g4 + 1] = q.y;
+        v[4 * g4 + 2] = q.z;
+        v[4 * g4 + 3] = q.w;
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[4 * g4 + k] = i + k >= 0 ? e[i + k] : 0xFFFFFFFFu;  // 0xFFFFFFFF: no entry (a real one has freq <= 4096)
+      }
+    }
+  };
+  auto lay = [&](int t, const u32 v[HALF]) {
+#pragma unroll
+    for (int k = 0; k < HALF; k++) {
+      uint4 r = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);  // padding: nothing out, state unchanged
+      if (v[k] != 0xFFFFFFFFu) r = rans_record(v[k], lrcp[v[k] & 0xFFFF]);  // entry 0 of the table is that of freq 1
+      rec[t & 1][k0 + k][lane] = r;
+    }
+  };
+  const bool feeder = role == 1 || role == 2;
+  u8* const base = scratch + (size_t)(live ? b : 0) * RANS_SCRATCH;  // the block's scratch; the write position is an offset that runs down from its top
+  u32 off = RANS_SCRATCH;
+  u32 x = kRansL;
+  u32 nxt[HALF];  // feeder: the entries of the trip after the one being laid out (their loads are in flight meanwhile)
+  if (feeder && trips > 0) {
+    u32 cur[HALF];
+    fetch(0, cur);
+    if (trips > 1) fetch(1, nxt);
+    lay(0, cur);
   }
-  while (i > 0) {  // 16 entries per trip: neither the entry loads nor the reciprocal lookups depend on the coder state
-    i -= 16;
-    uint4 v4[4];
+  __syncthreads();
+  for (int t = 0; t <= trips; t++) {  // one extra turn: the writer runs a trip behind the coder
+    if (feeder) {
+      if (t + 1 < trips) {
+        u32 cur[HALF];
 #pragma unroll
-    for (int k = 0; k < 4; k++) __builtin_memcpy(&v4[k], e + i + 4 * k, 16);
-    const u32 v[16] = {v4[0].x, v4[0].y, v4[0].z, v4[0].w, v4[1].x, v4[1].y, v4[1].z, v4[1].w, v4[2].x, v4[2].y, v4[2].z, v4[2].w, v4[3].x, v4[3].y, v4[3].z, v4[3].w};
-    RansRcp r[16];
+        for (int k = 0; k < HALF; k++) cur[k] = nxt[k];
+        if (t + 2 < trips) fetch(t + 2, nxt);
+        lay(t + 1, cur);
+      }
+    } else if (role == 0) {
+      if (t < trips) {
 #pragma unroll
-    for (int k = 0; k < 16; k++) r[k] = lrcp[v[k] & 0xFFFF];
+        for (int k = RANS_TRIP - 1; k >= 0; k--) hand[t & 1][k][lane] = rans_step(x, rec[t & 1][k][lane]);
+        if (t == trips - 1) xfinal[lane] = x;
+      }
+    } else if (t > 0 && live) {
 #pragma unroll
-    for (int k = 15; k >= 0; k--) rans_put(x, p, v[k], r[k]);
+      for (int k = RANS_TRIP - 1; k >= 0; k--) rans_emit(base, off, hand[(t - 1) & 1][k][lane]);
+    }
+    __syncthreads();
   }
-  p -= 4;  // RansEncFlush, rans_byte.h:90-102
-  p[0] = (u8)x;
-  p[1] = (u8)(x >> 8);
-  p[2] = (u8)(x >> 16);
-  p[3] = (u8)(x >> 24);
-  blksize[b] = (u32)(end - p);
+  if (role == 3 && live) {
+    const u32 xf = trips > 0 ? xfinal[lane] : (u32)kRansL;
+    u8* p = base + off - 4;  // RansEncFlush, rans_byte.h:90-102
+    p[0] = (u8)xf;
+    p[1] = (u8)(xf >> 8);
+    p[2] = (u8)(xf >> 16);
+    p[3] = (u8)(xf >> 24);
+    blksize[b] = (u32)RANS_SCRATCH - (off - 4);
+  }
 }
 
 // ---------------------------------------------------------------- gather ---
