@@ -725,7 +725,6 @@ int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* 
     std::vector<DecGop> gops;
     HIPCHK(hipMemsetAsync(c->err.p, 0, 32, st));
     stage_begin(c, ST_DECODE);
-    int ncoded = 0;
     for (int i = 0; i < n; i++) {
       const int fi = f0 + i;
       if (c->crashed && ftypes[fi] > 0) return done;  // (:1697)
@@ -749,7 +748,6 @@ int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* 
         d.kind = 0;
         c->last_flat = false;
         new_gop = true;
-        ncoded++;
       }
       if (new_gop) gops.push_back({(int)fr.size(), 0, 0, 0});
       fr.push_back(d);

@@ -1056,7 +1056,6 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
   wave_fence();
   u32 lastpix = 0;  // cx = cx1 = 0 (:1317)
   int lastmx = 0, lastmy = 0;
-  auto ctx_c0 = [&](u32 lp) __attribute__((always_inline)) { return (int)(((lp >> 18) & 63) | (((lp >> 10) & 63) << 6)); };
   u32* tile = D.L.tile;
   uint2* jobs = D.L.jobs;
   int njobs = 0;
