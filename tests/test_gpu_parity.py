@@ -221,6 +221,7 @@ def test_random_call_patterns_keep_cross_call_state(seed, w, h):
     import torch
     rng = np.random.default_rng(100 + seed)
     n = 48
+    workers = 3 if seed % 5 == 0 else 1  # key frames cut their runs at the worker bands (bitstream-visible)
     seq = DesktopSequence(w, h, seed=20 + seed, sparkles=30)
     flat = [np.full((h, w, 4), 0, np.uint8), np.full((h, w, 4), 0, np.uint8)]
     flat[0][..., :3] = (10, 200, 30)
@@ -244,10 +245,10 @@ def test_random_call_patterns_keep_cross_call_state(seed, w, h):
             cur_loss = int(rng.integers(0, 3))
         loss.append(cur_loss)
     # oracle: one frame at a time
-    ora = O.OracleCodec(w, h, 32)
+    ora = O.OracleCodec(w, h, 32, workers=workers)
     ref = [ora.compress(f, key=k, loss=l) for f, k, l in zip(frames, want_key, loss)]
     # product: random cuts; a batch has one loss value, so cuts also fall where the loss changes
-    gpu = _codec(w, h)
+    gpu = _codec(w, h, workers=workers)
     got = []
     i = 0
     while i < n:
@@ -403,3 +404,62 @@ def test_batch_longer_than_the_slot_pool():
     assert pk.cpu().numpy().tobytes() == b"".join(p for p, _ in ref)
     r, out = _codec(w, h).DecompressBatch(pk, sizes, fts)
     assert r == n and torch.equal(out.reshape(n, -1), dev)
+
+
+@pytest.mark.parametrize("bpp,w,h,seed", [(24, 100, 37, 1), (24, 96, 64, 2), (16, 100, 37, 3), (16, 98, 50, 4), (24, 33, 50, 5), (16, 34, 40, 6)])
+def test_random_streams_rgb24_and_rgb16(bpp, w, h, seed):
+    """The other two input formats (rows padded to 4 bytes) through random key / P / repeated / flat frames and
+    random per-frame / batch cuts: packets equal the oracle's, decoded rows equal the oracle's rows."""
+    import torch
+    rng = np.random.default_rng(500 + seed)
+    seq = DesktopSequence(w, h, seed=60 + seed, sparkles=20)
+    pitch = (w * (bpp // 8) + 3) & ~3
+
+    def conv(t):
+        f24 = seq.frame24(t)  # (h, w, 3)
+        if bpp == 24:
+            return pack24(f24)
+        c = f24.astype(np.uint16) >> 3
+        px = ((c[..., 2] << 10) | (c[..., 1] << 5) | c[..., 0]).astype(np.uint16)
+        out = np.zeros((h, pitch), np.uint8)
+        out[:, : w * 2] = px.view(np.uint8).reshape(h, w * 2)
+        return out
+    n = 24
+    frames, keys = [], []
+    for t in range(n):
+        k = rng.random()
+        if k < 0.65 or not frames:
+            frames.append(np.ascontiguousarray(conv(t)).reshape(h, pitch))
+        elif k < 0.8:
+            frames.append(frames[-1].copy())
+        else:
+            flat = np.zeros((h, pitch), np.uint8)
+            flat[:, : w * (bpp // 8)] = np.tile(np.array([17, 34, 51][: bpp // 8] if bpp == 24 else [0x34, 0x12], np.uint8), w)
+            frames.append(flat)
+        keys.append(t == 0 or rng.random() < 0.2)
+    ora = O.OracleCodec(w, h, bpp)
+    ref = [ora.compress(f, key=k) for f, k in zip(frames, keys)]
+    gpu = _codec(w, h, bpp)
+    got, i = [], 0
+    while i < n:
+        j = min(n, i + int(rng.integers(1, 6)))
+        if j - i == 1:
+            got.append(gpu.CompressFrame(frames[i], 0 if keys[i] else 1))
+        else:
+            dev = torch.from_numpy(np.stack(frames[i:j])).cuda().reshape(j - i, -1)
+            pk, sizes, fts = gpu.CompressBatch(dev, [0 if k else 1 for k in keys[i:j]])
+            pk, o = pk.cpu().numpy(), 0
+            for s, ft in zip(sizes, fts):
+                got.append((pk[o:o + int(s)].tobytes(), ft))
+                o += int(s)
+        i = j
+    for t in range(n):
+        assert got[t] == ref[t], (t, _first_diff(got[t][0], ref[t][0]))
+    od, gd = O.OracleCodec(w, h, bpp), _codec(w, h, bpp)
+    for t in range(n):
+        r1, want = od.decompress(ref[t][0], ref[t][1])
+        r2, out = gd.DecompressFrame(ref[t][0], ref[t][1])
+        assert r1 == 1 and r2 == 1
+        nb = w * (bpp // 8)
+        assert np.array_equal(out.reshape(h, pitch)[:, :nb], want.reshape(h, pitch)[:, :nb]), t
+        assert np.array_equal(out.reshape(h, pitch)[:, :nb], frames[t][:, :nb]) or bpp == 16, t
