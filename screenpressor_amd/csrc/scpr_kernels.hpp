@@ -292,8 +292,8 @@ __global__ __launch_bounds__(256) void k_tiles(const u8* __restrict__ planes, Ge
                                                const u8* __restrict__ entry, u32* __restrict__ runrec, u32* __restrict__ tilecnt) {
   __shared__ u64 fm[4][24];
   __shared__ u8 ty[TILE];
-  __shared__ u16 lv[MARK ? 10 : 2][TILE];
-  __shared__ u16 ln[MARK ? 1 : 2][MARK ? 1 : TILE];
+  __shared__ u16 lv[MARK ? 10 : 1][TILE];
+  __shared__ u32 lp[MARK ? 1 : 2][MARK ? 1 : TILE];  // first pass: successor | last run start << 16, one word per doubling step
   __shared__ u8 mk[MARK ? TILE : 1];
   __shared__ int wsum[5];
   const int slot = slots[blockIdx.y], tile = blockIdx.x, tid = threadIdx.x;
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256) void k_tiles(const u8* __restrict__ planes, Ge
       j = (p + 1 + n >= g.NP) ? EXITED : r + 1 + n;
     }
     lv[0][r] = (u16)j;
-    if (!MARK) ln[0][r] = (u16)r;
+    if (!MARK) lp[0][r] = (u32)j | ((u32)r << 16);
   }
   __syncthreads();
   if (!MARK) {
@@ -329,22 +329,20 @@ __global__ __launch_bounds__(256) void k_tiles(const u8* __restrict__ planes, Ge
     for (int it = 0; it < 10; it++) {
       for (int k = 0; k < 4; k++) {
         const int r = k * 256 + tid;
-        int j = lv[cur][r], nj = j, nl = ln[cur][r];
-        if (j < TILE) {
-          nj = lv[cur][j];
-          nl = ln[cur][j];
-        }
-        lv[cur ^ 1][r] = (u16)nj;
-        ln[cur ^ 1][r] = (u16)nl;
+        u32 v = lp[cur][r];
+        const u32 j = v & 0xFFFFu;
+        if (j < TILE) v = lp[cur][j];  // jump: the successor's successor, and the start of the run it sits in
+        lp[cur ^ 1][r] = v;
       }
       __syncthreads();
       cur ^= 1;
     }
     if (tid < HALO) {
-      int j = lv[cur][tid];
+      const u32 v = lp[cur][tid];
+      const int j = (int)(v & 0xFFFFu);
       u8* row = exitmap + ((size_t)slot * g.ntiles + tile) * 512;
       row[2 * tid] = (u8)(j == EXITED ? 255 : j - TILE);  // 255: the path ended inside this tile (frame end)
-      row[2 * tid + 1] = ty[ln[cur][tid]];
+      row[2 * tid + 1] = ty[v >> 16];
     }
   } else {
     for (int lvl = 0; lvl < 9; lvl++) {
