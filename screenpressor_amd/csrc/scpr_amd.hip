@@ -682,6 +682,7 @@ int64_t scpr_compress_batch(scpr_codec* c, const void* d_frames, int nframes, in
     HIPCHK(hipMemcpyAsync(&chunk_total, c->total64.p, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(&err, c->err.p, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipGetLastError());  // a kernel that could not be launched (the launches themselves are not checked one by one)
     timing_collect(c);
     if (err & 2) return SCPR_E_CAPACITY;
     if (err & 1) {
@@ -821,6 +822,7 @@ int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* 
     u32 errv[8] = {0};
     HIPCHK(hipMemcpyAsync(errv, c->err.p, 32, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));  // also covers fr / gops (host memory)
+    HIPCHK(hipGetLastError());         // a kernel that could not be launched
     timing_collect(c);
     const u32 err = errv[0];
     if (err & 4) return SCPR_E_STREAM;
