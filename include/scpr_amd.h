@@ -41,7 +41,7 @@ enum {
     SCPR_OK = 0,
     SCPR_E_DEVICE = -1,      /* no usable gfx950 device / HIP error */
     SCPR_E_PARAM = -2,       /* bad argument */
-    SCPR_E_BAD_VERSION = -3, /* BadVersionException (screencap.h:86-90): stream version not 3/4 or bpp not 16/24/32 */
+    SCPR_E_BAD_VERSION = -3, /* BadVersionException (screencap.h:86-90): stream version not 2/3/4 (version 2 is decode-only) or bpp not 16/24/32 */
     SCPR_E_CAPACITY = -4,    /* destination too small */
     SCPR_E_STREAM = -5       /* corrupt stream detected by the decoder */
 };
