@@ -438,17 +438,15 @@ static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int n
     c->live_stamp = stamp_out;
     c->live_buf = buf_out;
     const u32 cap = (u32)std::min<size_t>(nchains, Ctot + 1);
-    HIPCHK(c->chainlists.reserve((size_t)cap * 8 + 64));
+    HIPCHK(c->chainlists.reserve((size_t)cap * 4 * CHAIN_CLASSES + 64));
     HIPCHK(c->chaincounts.reserve(16));
-    HIPCHK(hipMemsetAsync(c->chaincounts.p, 0, 8, st));
-    hipLaunchKernelGGL(k_chain_lists, dim3((unsigned)((nchains + 1023) / 1024)), dim3(1024), 0, st, c->cstart.as<u32>(), (int)nchains, 192u, c->chainlists.as<u32>(), cap,
+    HIPCHK(hipMemsetAsync(c->chaincounts.p, 0, 4 * CHAIN_CLASSES, st));
+    hipLaunchKernelGGL(k_chain_lists, dim3((unsigned)((nchains + 1023) / 1024)), dim3(1024), 0, st, c->cstart.as<u32>(), (int)nchains, c->chainlists.as<u32>(), cap,
                        c->chaincounts.as<u32>());
-    for (int which = 0; which < 2; which++) {  // long chains first
-      const unsigned grid = (unsigned)std::min<u32>(cap, which == 0 ? 16384u : 32768u);
-      if (grid)
-        hipLaunchKernelGGL(k_colour_chain_w, dim3(grid), dim3(64), 0, st, c->keys[1].as<u32>(), c->vals[1].as<u32>(), c->cstart.as<u32>(), c->chainlists.as<u32>() + (size_t)which * cap,
-                           c->chaincounts.as<u32>() + which, c->f0, ar, cp, c->entries.as<u32>());
-    }
+    const unsigned grid = (unsigned)std::min<u32>(cap, 24576u);
+    if (grid)
+      hipLaunchKernelGGL(k_colour_chain_w, dim3(grid), dim3(64), 0, st, c->keys[1].as<u32>(), c->vals[1].as<u32>(), c->cstart.as<u32>(), c->chainlists.as<u32>(),
+                         c->chaincounts.as<u32>(), cap, c->f0, ar, cp, c->entries.as<u32>());
   }
   stage_end(c, ST_COLOUR);
   HIPCHK(hipStreamWaitEvent(st, c->ev_join, 0));  // the coder needs the entries of both
@@ -900,7 +898,7 @@ int scpr_debug_colour_chain(int device, const uint8_t* syms, int n, int f0, uint
   HIPCHK(dv.reserve((size_t)n * 4));
   HIPCHK(dc.reserve(8));
   HIPCHK(dl.reserve(4));
-  HIPCHK(dn.reserve(4));
+  HIPCHK(dn.reserve(4 * CHAIN_CLASSES));
   HIPCHK(de.reserve((size_t)n * 4));
   HIPCHK(da.reserve(acap * sizeof(DenseTab)));
   HIPCHK(dt.reserve(8));
@@ -908,11 +906,12 @@ int scpr_debug_colour_chain(int device, const uint8_t* syms, int n, int f0, uint
   HIPCHK(hipMemcpy(dv.p, vals.data(), (size_t)n * 4, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(dc.p, cst, 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(dl.p, lst, 4, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(dn.p, cnt, 4, hipMemcpyHostToDevice));
+  const u32 cnt4[CHAIN_CLASSES] = {cnt[0], 0, 0, 0};
+  HIPCHK(hipMemcpy(dn.p, cnt4, sizeof cnt4, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(dt.p, zero, 8, hipMemcpyHostToDevice));
   Arena ar{da.as<DenseTab>(), dt.as<u32>(), (u32)acap, dt.as<u32>() + 1};
   ChainPersist cp{nullptr, nullptr, 0, 0, 0, 0};  // nothing loaded, nothing kept
-  hipLaunchKernelGGL(k_colour_chain_w, dim3(1), dim3(64), 0, 0, dk.as<u32>(), dv.as<u32>(), dc.as<u32>(), dl.as<u32>(), dn.as<u32>(), f0, ar, cp, de.as<u32>());
+  hipLaunchKernelGGL(k_colour_chain_w, dim3(1), dim3(64), 0, 0, dk.as<u32>(), dv.as<u32>(), dc.as<u32>(), dl.as<u32>(), dn.as<u32>(), 1u, f0, ar, cp, de.as<u32>());
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpy(out, de.p, (size_t)n * 4, hipMemcpyDeviceToHost));
   for (DevBuf* b : {&dk, &dv, &dc, &dl, &dn, &de, &da, &dt}) b->release();

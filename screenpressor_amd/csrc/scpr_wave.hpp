@@ -1264,19 +1264,23 @@ __global__ __launch_bounds__(64) void k_decode_gop_w(const u8* __restrict__ pack
 }
 
 // ------------------------------------------------------------- encoder chains ---
-// Non-empty colour chains, split by length so that the long ones start first.
-__global__ __launch_bounds__(1024) void k_chain_lists(const u32* __restrict__ cstart, int nchains, u32 thresh, u32* __restrict__ lists, u32 cap, u32* __restrict__ counts) {
-  __shared__ u32 cnt[2], base[2];
+// Non-empty colour chains in four length classes (longest first): the chain kernel walks the classes in
+// order with a grid stride, so the long chains - the critical path of the stage - are the first thing the
+// waves pick up, one each, and the short ones fill in behind.
+constexpr int CHAIN_CLASSES = 4;
+__device__ __forceinline__ int chain_class(u32 len) { return len >= 4096 ? 0 : len >= 1024 ? 1 : len >= 192 ? 2 : 3; }
+__global__ __launch_bounds__(1024) void k_chain_lists(const u32* __restrict__ cstart, int nchains, u32* __restrict__ lists, u32 cap, u32* __restrict__ counts) {
+  __shared__ u32 cnt[CHAIN_CLASSES], base[CHAIN_CLASSES];
   const int q = blockIdx.x * 1024 + threadIdx.x;
-  if (threadIdx.x < 2) cnt[threadIdx.x] = 0;
+  if (threadIdx.x < CHAIN_CLASSES) cnt[threadIdx.x] = 0;
   __syncthreads();
   u32 len = 0;
   if (q < nchains) len = cstart[q + 1] - cstart[q];
-  const int which = len >= thresh ? 0 : 1;
+  const int which = chain_class(len);
   u32 local = 0;
   if (len) local = atomicAdd(&cnt[which], 1u);  // LDS: position inside this block's share
   __syncthreads();
-  if (threadIdx.x < 2) base[threadIdx.x] = cnt[threadIdx.x] ? atomicAdd(&counts[threadIdx.x], cnt[threadIdx.x]) : 0u;  // one global atomic per list per block
+  if (threadIdx.x < CHAIN_CLASSES) base[threadIdx.x] = cnt[threadIdx.x] ? atomicAdd(&counts[threadIdx.x], cnt[threadIdx.x]) : 0u;  // one global atomic per class per block
   __syncthreads();
   if (len) {
     const u32 idx = base[which] + local;
@@ -1299,15 +1303,27 @@ struct ChainPersist {
   int load_first;     // generation 0 of the call continues the live generation
   int ngens;
 };
-__global__ __launch_bounds__(64) void k_colour_chain_w(const u32* __restrict__ skeys, const u32* __restrict__ svals, const u32* __restrict__ cstart, const u32* __restrict__ list,
-                                                       const u32* __restrict__ count, int f0, Arena arena, ChainPersist cp, u32* __restrict__ entries) {
+__global__ __launch_bounds__(64) void k_colour_chain_w(const u32* __restrict__ skeys, const u32* __restrict__ svals, const u32* __restrict__ cstart, const u32* __restrict__ lists,
+                                                       const u32* __restrict__ counts, u32 cap, int f0, Arena arena, ChainPersist cp, u32* __restrict__ entries) {
   __shared__ u32 rec[16];
   __shared__ u16 tmp[256];
   WaveModel M(tmp, arena, f0);
   const int lane = M.lane;
-  const u32 n = *count;
+  u32 cn[CHAIN_CLASSES], n = 0;
+#pragma unroll
+  for (int k = 0; k < CHAIN_CLASSES; k++) {
+    cn[k] = min(counts[k], cap);
+    n += cn[k];
+  }
   for (u32 li = blockIdx.x; li < n; li += gridDim.x) {
-    const u32 q = list[li];
+    u32 i = li, seg = 0;  // position li of the classes laid end to end
+#pragma unroll
+    for (int k = 0; k < CHAIN_CLASSES - 1; k++)
+      if (seg == (u32)k && i >= cn[k]) {
+        i -= cn[k];
+        seg = k + 1;
+      }
+    const u32 q = lists[(size_t)seg * cap + i];
     const u32 start = cstart[q], len = cstart[q + 1] - start;
     const int gen = (int)(q / NCOLCTX), ctx = (int)(q - (u32)gen * NCOLCTX);
     ColHdr h = WaveModel::unpack(0, 0, 0);
