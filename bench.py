@@ -39,12 +39,13 @@ def main():
     ap.add_argument("--workload", choices=["keys", "ip"], default="keys",
                     help="keys: every frame a key frame (BASELINE configs[1], the headline); ip: key frame every --gop frames (configs[2])")
     ap.add_argument("--gop", type=int, default=50)
+    ap.add_argument("--bpp", type=int, choices=[32, 24], default=32, help="24: packed 3-byte pixels, rows padded to 4 bytes (BASELINE configs[4])")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     from screenpressor_amd.codec import ScreenCodec
-    from screenpressor_amd.synth import DesktopSequence
+    from screenpressor_amd.synth import DesktopSequence, pack24
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -59,13 +60,16 @@ def main():
 
     # synthetic input, resident in HBM before the timed region (rank r: its own seed/shard)
     seq = DesktopSequence(W, H, seed=1 + rank)
-    frames = torch.empty((N, H * W * 4), dtype=torch.uint8, device=dev)
+    BPP = args.bpp
+    pitch = W * 4 if BPP == 32 else (W * 3 + 3) & ~3
+    frames = torch.empty((N, H * pitch), dtype=torch.uint8, device=dev)
     for t in range(N):
-        frames[t] = torch.from_numpy(seq.frame(t).reshape(-1)).to(dev)
-    codec_e = ScreenCodec(local_rank).Init(W, H, 32)
-    codec_d = ScreenCodec(local_rank).Init(W, H, 32)
+        f = seq.frame(t) if BPP == 32 else pack24(seq.frame24(t))
+        frames[t] = torch.from_numpy(np.ascontiguousarray(f).reshape(-1)).to(dev)
+    codec_e = ScreenCodec(local_rank).Init(W, H, BPP)
+    codec_d = ScreenCodec(local_rank).Init(W, H, BPP)
     packets = torch.empty(max(256 << 20, N * W * H // 2), dtype=torch.uint8, device=dev)
-    decoded = torch.empty(N * H * W * 4, dtype=torch.uint8, device=dev)
+    decoded = torch.empty(N * H * pitch, dtype=torch.uint8, device=dev)
     ftypes = [0] * N if args.workload == "keys" else [0 if t % args.gop == 0 else 1 for t in range(N)]
 
     def barrier():
@@ -78,8 +82,8 @@ def main():
 
     def step(timed):
         nonlocal t_enc_acc, t_dec_acc, comp_bytes
-        codec_e.Deinit(); codec_e.Init(W, H, 32)
-        codec_d.Deinit(); codec_d.Init(W, H, 32)
+        codec_e.Deinit(); codec_e.Init(W, H, BPP)
+        codec_d.Deinit(); codec_d.Init(W, H, BPP)
         t0 = time.perf_counter()
         out, sizes, ft = codec_e.CompressBatch(frames, ftypes, out=packets)
         t1 = time.perf_counter()
@@ -121,7 +125,7 @@ def main():
         # dominant kernel stage by device time (HIP events on the codec's stream, scpr_last_timing)
         per_step = {k: v / args.steps for k, v in stage_acc.items()}
         dom = max(per_step, key=per_step.get)
-        raw = N * W * H * 4
+        raw = N * H * pitch
         # algorithmic bytes per SURVEY.md §8(d): encode I = raw + c, decode I = c + raw, per frame
         alg_bytes = raw + comp_bytes if args.workload == "keys" else 2 * raw + comp_bytes  # P-frames also read the previous frame
         dom_ms = per_step[dom]
@@ -148,8 +152,8 @@ def main():
         if not args.no_cpu:
             import oracle_api as O
             nf = min(args.cpu_frames, N)
-            sample = np.stack([seq.frame(t) for t in range(nf)]).reshape(nf, -1)
-            r = O.time_stream(sample, W, H, 32, key_interval=1 if args.workload == "keys" else args.gop)
+            sample = np.stack([np.ascontiguousarray(seq.frame(t) if BPP == 32 else pack24(seq.frame24(t))).reshape(-1) for t in range(nf)])
+            r = O.time_stream(sample, W, H, BPP, key_interval=1 if args.workload == "keys" else args.gop)
             assert r["bad"] == 0
             cpu = {"value": round(nf * W * H / 1e6 / (r["t_enc"] + r["t_dec"]), 2), "unit": "MPix/s", "cores": 1, "kind": "port",
                    "sample": f"first {nf} frames of the same workload, encode+decode, oracle/libspo.so (single thread)",
@@ -158,8 +162,8 @@ def main():
             "metric": "MPix/s encode+decode, 1080p RGB32; bitstream byte-identical to ref", "value": round(value, 2), "unit": "MPix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": (f"{W}x{H} RGB32 key-frame-only (I-frames), {N} frames per GPU, synthetic desktop seed 1+rank" if args.workload == "keys"
-                                    else f"{W}x{H} RGB32 I+P (key frame every {args.gop}), {N} frames per GPU, synthetic desktop seed 1+rank"),
+            "config": {"workload": (f"{W}x{H} RGB{BPP} key-frame-only (I-frames), {N} frames per GPU, synthetic desktop seed 1+rank" if args.workload == "keys"
+                                    else f"{W}x{H} RGB{BPP} I+P (key frame every {args.gop}), {N} frames per GPU, synthetic desktop seed 1+rank"),
                        "frames_per_gpu": N, "parallelism": f"frame-sharded x{world}", "lossless_roundtrip": lossless,
                        "compressed_bytes_per_gpu": comp_bytes,
                        "enc_MPix_s_rank0": round(N * W * H / 1e6 / (t_enc_acc / args.steps), 2),

@@ -558,10 +558,10 @@ int64_t scpr_compress_batch(scpr_codec* c, const void* d_frames, int nframes, in
       dim3 gr((g.H * ((g.W + 3) >> 2) + 256 * PACK_ITEMS - 1) / (256 * PACK_ITEMS), n);
       hipLaunchKernelGGL(k_pack32, gr, dim3(256), 0, st, src, c->planes.as<u8>(), g, d_nonflat, d_first);
     } else if (c->bpp == 3) {
-      dim3 gr((g.H * (g.S >> 2) + 255) / 256, n);
+      dim3 gr((g.H * (g.S >> 2) + 256 * PACK_ITEMS - 1) / (256 * PACK_ITEMS), n);
       hipLaunchKernelGGL(k_pack24, gr, dim3(256), 0, st, src, c->planes.as<u8>(), g, d_nonflat, d_first);
     } else {
-      dim3 gr((g.H * g.W + 255) / 256, n);
+      dim3 gr((g.H * g.W + 256 * PACK_ITEMS - 1) / (256 * PACK_ITEMS), n);
       hipLaunchKernelGGL(k_pack16, gr, dim3(256), 0, st, src, c->planes.as<u8>(), g, d_nonflat, d_first, c->prm.red_mask, c->prm.green_mask, c->prm.blue_mask, c->rs, c->gs,
                          c->bs);
     }
@@ -812,8 +812,11 @@ int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* 
     if (c->bpp == 4) {
       dim3 gr((g.H * ((g.W + 3) >> 2) + 256 * PACK_ITEMS - 1) / (256 * PACK_ITEMS), n);
       hipLaunchKernelGGL(k_unpack32, gr, dim3(256), 0, st, c->planes.as<u8>(), out, g, pitch);
+    } else if (c->bpp == 3 && pitch == g.S && ((size_t)out & 3) == 0) {
+      dim3 gr((unsigned)(((size_t)g.H * g.S / 4 + 256 * PACK_ITEMS - 1) / (256 * PACK_ITEMS)), n);
+      hipLaunchKernelGGL(k_copy_planes, gr, dim3(256), 0, st, c->planes.as<u8>(), out, g);
     } else {
-      dim3 gr((g.H * g.W + 255) / 256, n);
+      dim3 gr((g.H * g.W + 256 * PACK_ITEMS - 1) / (256 * PACK_ITEMS), n);
       hipLaunchKernelGGL(k_unpack_rows, gr, dim3(256), 0, st, c->planes.as<u8>(), out, g, pitch, c->bpp, c->rs, c->gs, c->bs);
     }
     stage_end(c, ST_UNPACK);

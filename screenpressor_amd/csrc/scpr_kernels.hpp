@@ -127,45 +127,53 @@ __global__ __launch_bounds__(256) void k_pack32(const u8* __restrict__ src, u8* 
 
 // RGB24 rows (pitch = S) -> plane copy with zeroed row padding
 __global__ __launch_bounds__(256) void k_pack24(const u8* __restrict__ src, u8* __restrict__ planes, Geom g, u32* flat, u32* first) {
-  const int f = blockIdx.y, G = g.S >> 2;
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= g.H * G) return;
-  const int y = idx / G, gx = idx - y * G;
-  const u8* row = src + (size_t)f * g.S * g.H + (size_t)y * g.S;
-  u32 v = ((const u32*)row)[gx];
-  const int valid = g.W * 3 - gx * 4;  // bytes of this dword that are pixel data
-  if (valid < 4) v &= (valid <= 0) ? 0u : ((1u << (8 * valid)) - 1u);
-  const u8* p0 = src + (size_t)f * g.S * g.H;
+  const int f = blockIdx.y, G = g.S >> 2, total = g.H * G;
+  const u8* fsrc = src + (size_t)f * g.S * g.H;
+  const u32 px0 = ld3(fsrc), b0 = px0 & 255u, b1 = (px0 >> 8) & 255u, b2 = px0 >> 16;
+  // a flat frame repeats its first pixel: dword gx of a row holds the pattern at phase gx % 3 (4 = 1 mod 3)
+  const u32 e0 = b0 | (b1 << 8) | (b2 << 16) | (b0 << 24), e1 = b1 | (b2 << 8) | (b0 << 16) | (b1 << 24), e2 = b2 | (b0 << 8) | (b1 << 16) | (b2 << 24);
   bool diff = false;
-  for (int k = 0; k < 4 && k < valid; k++) {
-    int byte = gx * 4 + k;
-    diff |= (u8)(v >> (8 * k)) != p0[byte % 3];
+  for (int it = 0; it < PACK_ITEMS; it++) {  // several dwords per thread (see k_pack32)
+    const int idx = (blockIdx.x * PACK_ITEMS + it) * 256 + threadIdx.x;
+    if (idx >= total) break;
+    const int y = idx / G, gx = idx - y * G;
+    u32 v = ((const u32*)(fsrc + (size_t)y * g.S))[gx];
+    const int valid = g.W * 3 - gx * 4;  // bytes of this dword that are pixel data
+    const u32 mask = valid >= 4 ? 0xFFFFFFFFu : (valid <= 0 ? 0u : ((1u << (8 * valid)) - 1u));
+    v &= mask;
+    const int q = gx % 3;
+    diff |= v != ((q == 0 ? e0 : q == 1 ? e1 : e2) & mask);
+    ((u32*)(planes + (size_t)f * g.plane_stride + (size_t)y * g.S))[gx] = v;
   }
-  if (diff && flat[f] == 0) atomicOr(&flat[f], 1u);
-  if (idx == 0) first[f] = ld3(p0);
-  ((u32*)(planes + (size_t)f * g.plane_stride + (size_t)y * g.S))[gx] = v;
+  if (blockIdx.x == 0 && threadIdx.x == 0) first[f] = px0;
+  // flat detection: one relaxed L2 read and at most one atomic per wave
+  if (__ballot(diff) && lane_id() == 0 && __hip_atomic_load(&flat[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) atomicOr(&flat[f], 1u);
 }
 
 // RGB16 -> plane through the caller's channel masks (screencap.cpp:1665-1678)
 __global__ __launch_bounds__(256) void k_pack16(const u8* __restrict__ src, u8* __restrict__ planes, Geom g, u32* flat, u32* first,
                                                 u32 rm, u32 gm, u32 bm, int rs, int gs, int bs) {
-  const int f = blockIdx.y;
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= g.H * g.W) return;
-  const int y = idx / g.W, x = idx - y * g.W;
+  const int f = blockIdx.y, total = g.H * g.W;
   const int pitch = (g.W * 2 + 3) & ~3;
   const u8* fr = src + (size_t)f * pitch * g.H;
   auto conv = [&](u32 w) { return ((w & rm) >> rs) | (((w & gm) >> gs) << 8) | (((w & bm) >> bs) << 16); };
-  u32 w = *(const u16*)(fr + (size_t)y * pitch + x * 2);
-  u32 v = conv(w) & 0xFFFFFFu, v0 = conv(*(const u16*)fr) & 0xFFFFFFu;
-  if (v != v0 && flat[f] == 0) atomicOr(&flat[f], 1u);
-  if (idx == 0) first[f] = v0;
-  u8* o = planes + (size_t)f * g.plane_stride + (size_t)y * g.S + x * 3;
-  o[0] = (u8)v;
-  o[1] = (u8)(v >> 8);
-  o[2] = (u8)(v >> 16);
-  if (x == g.W - 1)
-    for (int k = g.W * 3; k < g.S; k++) (planes + (size_t)f * g.plane_stride + (size_t)y * g.S)[k] = 0;
+  const u32 v0 = conv(*(const u16*)fr) & 0xFFFFFFu;
+  bool diff = false;
+  for (int it = 0; it < PACK_ITEMS; it++) {
+    const int idx = (blockIdx.x * PACK_ITEMS + it) * 256 + threadIdx.x;
+    if (idx >= total) break;
+    const int y = idx / g.W, x = idx - y * g.W;
+    const u32 v = conv(*(const u16*)(fr + (size_t)y * pitch + x * 2)) & 0xFFFFFFu;
+    diff |= v != v0;
+    u8* o = planes + (size_t)f * g.plane_stride + (size_t)y * g.S + x * 3;
+    o[0] = (u8)v;
+    o[1] = (u8)(v >> 8);
+    o[2] = (u8)(v >> 16);
+    if (x == g.W - 1)
+      for (int k = g.W * 3; k < g.S; k++) (planes + (size_t)f * g.plane_stride + (size_t)y * g.S)[k] = 0;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) first[f] = v0;
+  if (__ballot(diff) && lane_id() == 0 && __hip_atomic_load(&flat[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) atomicOr(&flat[f], 1u);
 }
 
 // lossy pre-quantisation on the plane's dwords, then padding back to zero
@@ -207,18 +215,31 @@ __global__ __launch_bounds__(256) void k_unpack32(const u8* __restrict__ planes,
 }
 // plane -> RGB24 rows with the caller's pitch / RGB16 (screencap.cpp:1726-1737)
 __global__ __launch_bounds__(256) void k_unpack_rows(const u8* __restrict__ planes, u8* __restrict__ dst, Geom g, int pitch, int bpp, int rs, int gs, int bs) {
+  const int f = blockIdx.y, total = g.H * g.W;
+  for (int it = 0; it < PACK_ITEMS; it++) {
+    const int idx = (blockIdx.x * PACK_ITEMS + it) * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int y = idx / g.W, x = idx - y * g.W;
+    const u8* s = planes + (size_t)f * g.plane_stride + (size_t)y * g.S + x * 3;
+    u8* o = dst + (size_t)f * pitch * g.H + (size_t)y * pitch;
+    if (bpp == 3) {
+      o[x * 3] = s[0];
+      o[x * 3 + 1] = s[1];
+      o[x * 3 + 2] = s[2];
+    } else {
+      *(u16*)(o + x * 2) = (u16)((s[0] << rs) + (s[1] << gs) + (s[2] << bs));
+    }
+  }
+}
+// RGB24 output whose pitch is the plane's stride: the plane (rows with zeroed padding) is the output
+__global__ __launch_bounds__(256) void k_copy_planes(const u8* __restrict__ planes, u8* __restrict__ dst, Geom g) {
   const int f = blockIdx.y;
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= g.H * g.W) return;
-  const int y = idx / g.W, x = idx - y * g.W;
-  const u8* s = planes + (size_t)f * g.plane_stride + (size_t)y * g.S + x * 3;
-  u8* o = dst + (size_t)f * pitch * g.H + (size_t)y * pitch;
-  if (bpp == 3) {
-    o[x * 3] = s[0];
-    o[x * 3 + 1] = s[1];
-    o[x * 3 + 2] = s[2];
-  } else {
-    *(u16*)(o + x * 2) = (u16)((s[0] << rs) + (s[1] << gs) + (s[2] << bs));
+  const size_t bytes = (size_t)g.H * g.S;  // a multiple of 4
+  const u32* s = (const u32*)(planes + (size_t)f * g.plane_stride);
+  u32* o = (u32*)(dst + (size_t)f * bytes);
+  for (int it = 0; it < PACK_ITEMS; it++) {
+    const size_t i = ((size_t)blockIdx.x * PACK_ITEMS + it) * 256 + threadIdx.x;
+    if (i * 4 < bytes) o[i] = s[i];
   }
 }
 
