@@ -97,7 +97,7 @@ struct scpr_codec {
   DevBuf rblocks, rscratch, rsize, packets, pktoff, blkdst, outsizes, total64, arena, arena_top, err, rcp;
   DevBuf decframes, decstates, hoststage_in, hoststage_out, chainlists, chaincounts;
   // P-frame buffers
-  DevBuf mvdict, mvpre;
+  DevBuf mvdict, mvpre, gmask;
   DevBuf kinds, pidx, fidx, pframes, pflag, binfo, smv, btype, bmv, bcnt, boff, bflag, pinfo, ptot, pbase, misc, miscpos, miscranges;
   // state of the live generation, carried between calls (models are reset only by key frames, screencap.cpp:1118)
   DevBuf mvs, fixed_persist, misc_persist, colour_persist;
@@ -315,15 +315,21 @@ static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int n
     HIPCHK(c->bflag.reserve(pb * 4));
     HIPCHK(hipMemcpyAsync(c->pframes.p, pfr.data(), np * sizeof(PFrame), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemsetAsync(c->pflag.p, 0, (size_t)np * 4, st));
+    const int grp = std::min(64, nbx), ngrp = (nblocks + grp - 1) / grp;
+    HIPCHK(c->gmask.reserve((size_t)np * ngrp * 8));
+    HIPCHK(hipMemsetAsync(c->gmask.p, 0, (size_t)np * ngrp * 8, st));
+    HIPCHK(hipMemsetAsync(c->btype.p, 0, pb, st));       // untouched groups are not visited by k_mvresolve
+    HIPCHK(hipMemsetAsync(c->bmv.p, 0, pb * 4, st));
     stage_begin(c, ST_INTER);
-    hipLaunchKernelGGL(k_pblocks, dim3((nblocks + 3) / 4, np), dim3(64), 0, st, planes, g, c->pframes.as<PFrame>(), c->binfo.as<u32>(), c->pflag.as<u32>());
+    hipLaunchKernelGGL(k_pblocks, dim3((nblocks + 3) / 4, np), dim3(64), 0, st, planes, g, c->pframes.as<PFrame>(), c->binfo.as<u32>(), c->pflag.as<u32>(),
+                       c->gmask.as<unsigned long long>());
     hipLaunchKernelGGL(k_mvsearch, dim3(nblocks, np), dim3(64), 0, st, planes, g, c->pframes.as<PFrame>(), c->binfo.as<u32>(), mp, c->smv.as<u32>());
     HIPCHK(c->mvdict.reserve((size_t)np * MVDICT * 4));
     HIPCHK(c->mvpre.reserve(pb * 4));
     hipLaunchKernelGGL(k_mvdict, dim3(np), dim3(256), 0, st, g, c->binfo.as<u32>(), c->smv.as<u32>(), c->mvdict.as<u32>());
     hipLaunchKernelGGL(k_mvpretest, dim3((nblocks + 3) / 4, np), dim3(64), 0, st, planes, g, c->pframes.as<PFrame>(), c->binfo.as<u32>(), mp, c->mvdict.as<u32>(), c->mvpre.as<u32>());
     hipLaunchKernelGGL(k_mvresolve, dim3(1), dim3(64), 0, st, planes, g, c->pframes.as<PFrame>(), np, c->binfo.as<u32>(), c->smv.as<u32>(), c->mvdict.as<u32>(), c->mvpre.as<u32>(), mp,
-                       c->mvs.as<u32>(), c->btype.as<u8>(), c->bmv.as<u32>(), c->pinfo.as<int>());
+                       c->mvs.as<u32>(), c->btype.as<u8>(), c->bmv.as<u32>(), c->pinfo.as<int>(), c->gmask.as<unsigned long long>());
     hipLaunchKernelGGL(k_pcount, dim3((nblocks + 63) / 64, np), dim3(64), 0, st, planes, g, c->pframes.as<PFrame>(), c->binfo.as<u32>(), c->btype.as<u8>(), c->bcnt.as<u32>());
     hipLaunchKernelGGL(k_pscan, dim3((np + 63) / 64), dim3(64), 0, st, g, np, c->btype.as<u8>(), c->bmv.as<u32>(), c->bcnt.as<u32>(), c->pinfo.as<int>(), c->boff.as<BOff>(),
                        c->bflag.as<u32>(), c->ptot.as<u32>());
@@ -518,7 +524,7 @@ void scpr_destroy(scpr_codec* c) {
   DevBuf* all[] = {&c->planes, &c->exitmap, &c->entry, &c->runrec, &c->tilecnt, &c->tileoff, &c->hdrrec, &c->hdrcnt, &c->frametot, &c->flags, &c->slotlist, &c->genlist,
                    &c->bases, &c->totals, &c->runs, &c->runpos, &c->keys[0], &c->keys[1], &c->vals[0], &c->vals[1], &c->cstart, &c->sorttmp,
                    &c->entries, &c->ranges, &c->rblocks, &c->rscratch, &c->rsize, &c->packets, &c->pktoff, &c->blkdst, &c->outsizes, &c->total64, &c->arena,
-                   &c->arena_top, &c->err, &c->rcp, &c->decframes, &c->decstates, &c->hoststage_in, &c->hoststage_out, &c->chainlists, &c->chaincounts, &c->kinds, &c->pidx, &c->fidx, &c->pframes, &c->pflag, &c->binfo, &c->smv, &c->btype, &c->bmv, &c->bcnt, &c->boff, &c->bflag, &c->pinfo, &c->ptot, &c->pbase, &c->misc, &c->miscpos, &c->miscranges, &c->mvs, &c->fixed_persist, &c->misc_persist, &c->colour_persist, &c->decgops, &c->decfixed, &c->dec_fixed_persist, &c->dec_colour_persist, &c->mvdict, &c->mvpre};
+                   &c->arena_top, &c->err, &c->rcp, &c->decframes, &c->decstates, &c->hoststage_in, &c->hoststage_out, &c->chainlists, &c->chaincounts, &c->kinds, &c->pidx, &c->fidx, &c->pframes, &c->pflag, &c->binfo, &c->smv, &c->btype, &c->bmv, &c->bcnt, &c->boff, &c->bflag, &c->pinfo, &c->ptot, &c->pbase, &c->misc, &c->miscpos, &c->miscranges, &c->mvs, &c->fixed_persist, &c->misc_persist, &c->colour_persist, &c->decgops, &c->decfixed, &c->dec_fixed_persist, &c->dec_colour_persist, &c->mvdict, &c->mvpre, &c->gmask};
   for (DevBuf* b : all) b->release();
   for (int s = 0; s < ST_COUNT + 1; s++)
     for (int k = 0; k < 2; k++) (void)hipEventDestroy(c->ev[s][k]);

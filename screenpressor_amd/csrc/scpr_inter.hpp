@@ -41,7 +41,10 @@ struct PFrame {
   int slot, prev_slot;
 };
 
-__global__ __launch_bounds__(64) void k_pblocks(const u8* __restrict__ planes, Geom g, const PFrame* __restrict__ pf, u32* __restrict__ binfo, u32* __restrict__ pflag) {
+// gmask[pi][group]: which blocks of each group of G = min(64, blocks per row) consecutive blocks changed (the serial
+// resolution pass below only visits groups with a bit set)
+__global__ __launch_bounds__(64) void k_pblocks(const u8* __restrict__ planes, Geom g, const PFrame* __restrict__ pf, u32* __restrict__ binfo, u32* __restrict__ pflag,
+                                                unsigned long long* __restrict__ gmask) {
   const int pi = blockIdx.y, lane = threadIdx.x;
   const int nbx = (g.W + 15) >> 4, nby = (g.H + 15) >> 4, nblocks = nbx * nby;
   const int b = blockIdx.x * 4 + (lane >> 4), row = lane & 15;
@@ -81,6 +84,8 @@ __global__ __launch_bounds__(64) void k_pblocks(const u8* __restrict__ planes, G
       const int type = (fx > 0 || sy1 > 0 || lx < bw - 1 || sy2 < bh - 1) ? 2 : 1;
       v = binfo_pack(fx, sy1, lx, sy2, type);
       if (pflag[pi] == 0) atomicOr(&pflag[pi], 1u);
+      const int G = min(64, nbx), NG = (nblocks + G - 1) / G;
+      atomicOr(&gmask[(size_t)pi * NG + b / G], 1ull << (b % G));
     }
     binfo[(size_t)pi * nblocks + b] = v;
   }
@@ -335,7 +340,7 @@ __global__ __launch_bounds__(64) void k_mvpretest(const u8* __restrict__ planes,
 // pinfo[pi] = {xx1, xx2}: bounding box corners of the changed blocks as block indices (:1145-1150)
 __global__ __launch_bounds__(64) void k_mvresolve(const u8* __restrict__ planes, Geom g, const PFrame* __restrict__ pf, int npf, const u32* __restrict__ binfo,
                                                   const u32* __restrict__ smv, const u32* __restrict__ dict, const u32* __restrict__ pre, MvParams mp, u32* mvs,
-                                                  u8* __restrict__ btype, u32* __restrict__ bmv, int* __restrict__ pinfo) {
+                                                  u8* __restrict__ btype, u32* __restrict__ bmv, int* __restrict__ pinfo, const unsigned long long* __restrict__ gmask) {
   const int lane = threadIdx.x;
   const int nbx = (g.W + 15) >> 4, nby = (g.H + 15) >> 4, nblocks = nbx * nby;
   const int G = min(64, nbx);
@@ -354,7 +359,14 @@ __global__ __launch_bounds__(64) void k_mvresolve(const u8* __restrict__ planes,
     };
     u32 last = 0;  // last vector found by search (0,0), wave-uniform
     int bx1 = nbx, bx2 = -1, by1 = nby, by2 = -1;
-    for (int base = 0; base < nblocks; base += G) {
+    // groups without a changed block are skipped (their types and vectors were zeroed by the host): the loop
+    // is a chain of dependent global reads per group, and most groups of a screen capture are untouched
+    const int NG = (nblocks + G - 1) / G;
+    for (int g0 = 0; g0 < NG; g0 += 64) {
+     u64 active = __ballot(g0 + lane < NG && gmask[(size_t)pi * NG + g0 + lane] != 0ull);
+     while (active) {
+      const int base = (g0 + __builtin_ctzll(active)) * G;
+      active &= active - 1;
       const int b = base + lane;
       const bool vb = lane < G && b < nblocks;
       const u32 info = vb ? binfo[(size_t)pi * nblocks + b] : 0;
@@ -416,6 +428,7 @@ __global__ __launch_bounds__(64) void k_mvresolve(const u8* __restrict__ planes,
         btype[(size_t)pi * nblocks + b] = (u8)type;
         bmv[(size_t)pi * nblocks + b] = my_mv;
       }
+     }
     }
     // bounding box of the changed blocks
 #pragma unroll
