@@ -1325,6 +1325,9 @@ __global__ __launch_bounds__(64) void k_colour_chain_w(const u32* __restrict__ s
       }
     const u32 q = lists[(size_t)seg * cap + i];
     const u32 start = cstart[q], len = cstart[q + 1] - start;
+    // the long chains are the critical path of the stage: their waves win the issue arbitration of their SIMD
+    if (len >= 1024) __builtin_amdgcn_s_setprio(3);
+    else __builtin_amdgcn_s_setprio(0);
     const int gen = (int)(q / NCOLCTX), ctx = (int)(q - (u32)gen * NCOLCTX);
     ColHdr h = WaveModel::unpack(0, 0, 0);
     u32 T = kSmallNone;
