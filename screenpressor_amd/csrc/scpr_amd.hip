@@ -328,8 +328,13 @@ static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int n
     HIPCHK(c->mvpre.reserve(pb * 4));
     hipLaunchKernelGGL(k_mvdict, dim3(np), dim3(256), 0, st, g, c->binfo.as<u32>(), c->smv.as<u32>(), c->mvdict.as<u32>());
     hipLaunchKernelGGL(k_mvpretest, dim3((nblocks + 3) / 4, np), dim3(64), 0, st, planes, g, c->pframes.as<PFrame>(), c->binfo.as<u32>(), mp, c->mvdict.as<u32>(), c->mvpre.as<u32>());
-    hipLaunchKernelGGL(k_mvresolve, dim3(1), dim3(64), 0, st, planes, g, c->pframes.as<PFrame>(), np, c->binfo.as<u32>(), c->smv.as<u32>(), c->mvdict.as<u32>(), c->mvpre.as<u32>(), mp,
-                       c->mvs.as<u32>(), c->btype.as<u8>(), c->bmv.as<u32>(), c->pinfo.as<int>(), c->gmask.as<unsigned long long>());
+    {
+      const size_t lds = (size_t)nblocks * 16;  // the frame's block arrays + the vector memory in LDS when they fit
+      const int use_lds = lds <= 150 * 1024 ? 1 : 0;
+      if (use_lds) HIPCHK(hipFuncSetAttribute((const void*)k_mvresolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(k_mvresolve, dim3(1), dim3(256), use_lds ? lds : 0, st, planes, g, c->pframes.as<PFrame>(), np, c->binfo.as<u32>(), c->smv.as<u32>(), c->mvdict.as<u32>(),
+                         c->mvpre.as<u32>(), mp, c->mvs.as<u32>(), c->btype.as<u8>(), c->bmv.as<u32>(), c->pinfo.as<int>(), c->gmask.as<unsigned long long>(), use_lds);
+    }
     hipLaunchKernelGGL(k_pcount, dim3((nblocks + 63) / 64, np), dim3(64), 0, st, planes, g, c->pframes.as<PFrame>(), c->binfo.as<u32>(), c->btype.as<u8>(), c->bcnt.as<u32>());
     hipLaunchKernelGGL(k_pscan, dim3((np + 63) / 64), dim3(64), 0, st, g, np, c->btype.as<u8>(), c->bmv.as<u32>(), c->bcnt.as<u32>(), c->pinfo.as<int>(), c->boff.as<BOff>(),
                        c->bflag.as<u32>(), c->ptot.as<u32>());

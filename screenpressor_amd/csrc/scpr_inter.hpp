@@ -335,16 +335,41 @@ __global__ __launch_bounds__(64) void k_mvpretest(const u8* __restrict__ planes,
   if (vb && row == 0) pre[(size_t)pi * nblocks + b] = changed ? bits : 0;
 }
 
+__device__ __forceinline__ void wave_fence_inter() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
 // Serial resolution over the P-frames of the chunk, in order (mvs[] carries over).
 // btype: 0 unchanged, 1/2 pixel-coded (whole/partial), 3/4 motion (whole/partial).
 // pinfo[pi] = {xx1, xx2}: bounding box corners of the changed blocks as block indices (:1145-1150)
-__global__ __launch_bounds__(64) void k_mvresolve(const u8* __restrict__ planes, Geom g, const PFrame* __restrict__ pf, int npf, const u32* __restrict__ binfo,
-                                                  const u32* __restrict__ smv, const u32* __restrict__ dict, const u32* __restrict__ pre, MvParams mp, u32* mvs,
-                                                  u8* __restrict__ btype, u32* __restrict__ bmv, int* __restrict__ pinfo, const unsigned long long* __restrict__ gmask) {
-  const int lane = threadIdx.x;
+// The walk is one wave, but its per-group inputs (block info, search result, pre-test bits, the vector
+// memory) are a chain of dependent reads: with `use_lds` the whole workgroup copies a frame's arrays into
+// LDS first (coalesced, 16 bytes per block: 128 KiB at 1080p) and the vector memory lives there for the
+// whole launch; bigger frames fall back to global reads.
+__global__ __launch_bounds__(256) void k_mvresolve(const u8* __restrict__ planes, Geom g, const PFrame* __restrict__ pf, int npf, const u32* __restrict__ binfo,
+                                                   const u32* __restrict__ smv, const u32* __restrict__ dict, const u32* __restrict__ pre, MvParams mp, u32* mvs,
+                                                   u8* __restrict__ btype, u32* __restrict__ bmv, int* __restrict__ pinfo, const unsigned long long* __restrict__ gmask,
+                                                   int use_lds) {
+  extern __shared__ __align__(16) u32 stage[];  // [4][nblocks] when use_lds: vector memory, block info, search result, pre-test bits
+  const int lane = threadIdx.x & 63;
+  const bool walker = threadIdx.x < 64;
   const int nbx = (g.W + 15) >> 4, nby = (g.H + 15) >> 4, nblocks = nbx * nby;
   const int G = min(64, nbx);
+  u32* const l_mv = stage;
+  u32* const l_bi = stage + nblocks;
+  u32* const l_sm = stage + 2 * nblocks;
+  u32* const l_pr = stage + 3 * nblocks;
+  if (use_lds) {
+    for (int i = threadIdx.x; i < nblocks; i += 256) l_mv[i] = mvs[i];
+    __syncthreads();
+  }
   for (int pi = 0; pi < npf; pi++) {
+    if (use_lds) {
+      for (int i = threadIdx.x; i < nblocks; i += 256) {
+        l_bi[i] = binfo[(size_t)pi * nblocks + i];
+        l_sm[i] = smv[(size_t)pi * nblocks + i];
+        l_pr[i] = pre[(size_t)pi * nblocks + i];
+      }
+      __syncthreads();
+    }
+   if (walker) {
     const u8* cur = planes + (size_t)pf[pi].slot * g.plane_stride;
     const u8* prv = planes + (size_t)pf[pi].prev_slot * g.plane_stride;
     u32 dk[MVDICT];
@@ -369,7 +394,7 @@ __global__ __launch_bounds__(64) void k_mvresolve(const u8* __restrict__ planes,
       active &= active - 1;
       const int b = base + lane;
       const bool vb = lane < G && b < nblocks;
-      const u32 info = vb ? binfo[(size_t)pi * nblocks + b] : 0;
+      const u32 info = vb ? (use_lds ? l_bi[b] : binfo[(size_t)pi * nblocks + b]) : 0;
       const bool changed = info & 1u;
       const int by = vb ? b / nbx : 0, bx = vb ? b - by * nbx : 0;
       int type = changed ? (int)((info >> 20) & 7) : 0;
@@ -385,9 +410,10 @@ __global__ __launch_bounds__(64) void k_mvresolve(const u8* __restrict__ planes,
       if (unresolved) {
         const Rect r = binfo_rect(info, bx, by);
         const Windows w = mv_windows(r, g, mp.far_x, mp.far_y, mp.near_x, mp.near_y);
-        const u32 s = changed ? smv[(size_t)pi * nblocks + b] : 0;
-        const u32 pbits = changed ? pre[(size_t)pi * nblocks + b] : 0;
-        const u32 umv = (changed && by > 0) ? __hip_atomic_load(&mvs[b - nbx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        const u32 s = changed ? (use_lds ? l_sm[b] : smv[(size_t)pi * nblocks + b]) : 0;
+        const u32 pbits = changed ? (use_lds ? l_pr[b] : pre[(size_t)pi * nblocks + b]) : 0;
+        wave_fence_inter();  // vectors stored by other lanes of this wave in earlier groups
+        const u32 umv = (changed && by > 0) ? (use_lds ? l_mv[b - nbx] : __hip_atomic_load(&mvs[b - nbx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0;
         const int ui = dict_index(umv);
         auto exact = [&](u32 mv) __attribute__((always_inline)) {  // window test + SameBlocks for a vector outside the dictionary
           const int x = r.x1 + mv_x(mv), y = r.y1 + mv_y(mv);
@@ -423,7 +449,8 @@ __global__ __launch_bounds__(64) void k_mvresolve(const u8* __restrict__ planes,
       if (vb) {
         if (has_mv) {
           type += 2;
-          __hip_atomic_store(&mvs[b], my_mv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (use_lds) l_mv[b] = my_mv;
+          else __hip_atomic_store(&mvs[b], my_mv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         btype[(size_t)pi * nblocks + b] = (u8)type;
         bmv[(size_t)pi * nblocks + b] = my_mv;
@@ -442,7 +469,11 @@ __global__ __launch_bounds__(64) void k_mvresolve(const u8* __restrict__ planes,
       pinfo[pi * 2] = bx2 < 0 ? 0 : by1 * nbx + bx1;
       pinfo[pi * 2 + 1] = bx2 < 0 ? -1 : by2 * nbx + bx2;
     }
+   }
+    if (use_lds) __syncthreads();  // the walk is done with this frame's arrays
   }
+  if (use_lds)
+    for (int i = threadIdx.x; i < nblocks; i += 256) mvs[i] = l_mv[i];
 }
 
 // ---- inter predictors (GetPixelTypeP / PixelTypeFitsP and the edge forms, :525-604) ----
