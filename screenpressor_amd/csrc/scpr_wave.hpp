@@ -86,10 +86,11 @@ struct DecRec {
 };
 constexpr int DECREC_WORDS = 20;
 // What of the fixed models sits in LDS while a wave decodes (the pixel-type tables live in registers).
-constexpr int NTAB_STRIDE = 320;  // words per run-length table: 256 entries, the running total, padding (three reads share one address)
+// words per run-length table: 256 entries (freq | cum << 16), the running total at 256, padding, and the 256 counts from
+// NTAB_CNT on (the lane that holds an entry reaches its count and lane 0 the total with a constant offset from one address)
+constexpr int NTAB_STRIDE = 640, NTAB_CNT = 320;
 struct FixedLds {
   u32 ntab[6][NTAB_STRIDE];
-  u32 ncnt[6][256];
   u32 mfc[2][512];
   u32 mcnt[2][512];
   u32 xfc[2][256];
@@ -568,8 +569,8 @@ struct WaveDec : WaveModel {
     };
     wave_fence();
     for (int t = 0; t < 6; t++) {
-      for (int j = lane; j < NTAB_STRIDE; j += 64) F.ntab[t][j] = j < 256 ? (16u | ((u32)(16 * j) << 16)) : j == 256 ? 8u * 256u : 0u;
-      for (int j = lane; j < 256; j += 64) F.ncnt[t][j] = 8u;
+      for (int j = lane; j < NTAB_CNT; j += 64) F.ntab[t][j] = j < 256 ? (16u | ((u32)(16 * j) << 16)) : j == 256 ? 8u * 256u : 0u;
+      for (int j = lane; j < 256; j += 64) F.ntab[t][NTAB_CNT + j] = 8u;
     }
     {
       const int j = lane & 7, fr = kProbScale / 6, c0 = fr - (fr >> 1);
@@ -589,8 +590,8 @@ struct WaveDec : WaveModel {
     FixedLds& F = L.fx;
     wave_fence();
     for (int t = 0; t < 6; t++) {
-      for (int j = lane; j < NTAB_STRIDE; j += 64) F.ntab[t][j] = j < 256 ? B->nfc[t][j] : j == 256 ? (u32)B->ftot[t] : 0u;
-      for (int j = lane; j < 256; j += 64) F.ncnt[t][j] = B->ncnt[t][j];
+      for (int j = lane; j < NTAB_CNT; j += 64) F.ntab[t][j] = j < 256 ? B->nfc[t][j] : j == 256 ? (u32)B->ftot[t] : 0u;
+      for (int j = lane; j < 256; j += 64) F.ntab[t][NTAB_CNT + j] = B->ncnt[t][j];
     }
     {
       const int t = lane >> 3, j = lane & 7;
@@ -620,7 +621,7 @@ struct WaveDec : WaveModel {
     for (int t = 0; t < 6; t++) {
       for (int j = lane; j < 256; j += 64) {
         B->nfc[t][j] = F.ntab[t][j];
-        B->ncnt[t][j] = F.ncnt[t][j];
+        B->ncnt[t][j] = F.ntab[t][NTAB_CNT + j];
       }
       if (lane == 0) B->ftot[t] = (int)F.ntab[t][256];
     }
@@ -664,20 +665,23 @@ struct WaveDec : WaveModel {
     if (SCPR_LIKELY(rfl(e1) >= lim)) {  // cum of symbol 64 is above v
       sym = __builtin_popcountll(__ballot(e0 < lim)) - 1;
       s = rdl(e0, sym);
+      // the count of the symbol (from the lane that holds it) and the total (lane 0); the other lanes add 0 to padding
+      const u32 dc = lane == sym ? (u32)kStepDense : 0u, dt = lane == 0 ? (u32)kStepDense : 0u;
+      asm volatile("ds_add_u32 %0, %1 offset:%3\n\tds_add_u32 %0, %2 offset:1024" ::"v"(addr), "v"(dc), "v"(dt), "n"(4 * NTAB_CNT) : "memory");
     } else {
       const u32 e2 = tab[128 + lane], e3 = tab[192 + lane];
       sym = 63 + __builtin_popcountll(__ballot(e1 < lim)) + __builtin_popcountll(__ballot(e2 < lim)) + __builtin_popcountll(__ballot(e3 < lim));
       const int q = sym >> 6, l = sym & 63;
       s = q == 1 ? rdl(e1, l) : q == 2 ? rdl(e2, l) : rdl(e3, l);
-    }
-    if (lane == 0) {
-      const u32 a1 = (u32)(size_t)&L.fx.ncnt[t][sym], a2 = (u32)(size_t)&tab[256];
-      asm volatile("ds_add_u32 %0, %2\n\tds_add_u32 %1, %2" ::"v"(a1), "v"(a2), "v"((u32)kStepDense) : "memory");
+      if (lane == 0) {
+        const u32 a1 = (u32)(size_t)&tab[NTAB_CNT + sym], a2 = (u32)(size_t)&tab[256];
+        asm volatile("ds_add_u32 %0, %2\n\tds_add_u32 %1, %2" ::"v"(a1), "v"(a2), "v"((u32)kStepDense) : "memory");
+      }
     }
     advance(s >> 16, s & 0xFFFF, v);
     if (SCPR_UNLIKELY(tot0 + 2 * kStepDense > kProbScale)) {  // rebuild from the counts, ans_contexts.h:1075-1090
       wave_fence();
-      u32* cnt = L.fx.ncnt[t];
+      u32* cnt = tab + NTAB_CNT;
       int base = 0, ns = 0;
 #pragma unroll
       for (int q = 0; q < 4; q++) {
@@ -935,30 +939,33 @@ __device__ __forceinline__ void decode_intra_frame(DEC& D, const Geom& g, u8* __
     }
     const int n = D.fixed_n(t);
     D.template stamp<2>();
-    if (SCPR_UNLIKELY((u32)(n - 1) >= (u32)((hdr ? W + 1 : NP) - p))) {  // empty, or longer than what is left (of the header row)
+    if (SCPR_UNLIKELY((u32)(n - 1) >= (u32)((hdr ? W + 1 : NP) - p) || t == 3)) {  // empty, or longer than what is left (of the header row); type 3 does not exist
       D.bad = true;
       break;
     }
-    if (t <= 1) {  // literal, or copy of the previous pixel: every pixel of the run has the same value
-      for (int q0 = 0; q0 < n; q0 += 64)
-        if (q0 + lane < n) ring[(u32)(p + q0 + lane) & pm] = px;
-      lastpix = px;
-    } else if (SCPR_LIKELY(t == 2 || (t == 5 && pad == 0))) {  // copy of the pixel above (2) or above-left (5)
-      const u32 back = t == 2 ? (u32)W : (u32)W + 1u;
-      u32 v = 0;
-      int m = 0;
-      for (int q0 = 0; q0 < n; q0 += chunk) {
-        wave_fence();  // pixels written by other lanes are read here (a run may be longer than a row)
-        m = min(chunk, n - q0);
-        const u32 pq = (u32)(p + q0 + lane);
-        v = ring[(pq - back) & pm];
-        if (lane < m) ring[pq & pm] = v;
+    if (SCPR_LIKELY(t != 4 && (t != 5 || pad == 0))) {
+      // literal / copy of the previous pixel (0, 1): every pixel of the run has the same value;
+      // copy of the pixel above (2) or above-left (5): read one row back in the ring.
+      // Almost every run fits one pass of the wave; the rest goes round the loop.
+      const u32 back = (u32)W + (u32)(t >> 2);
+      u32 v = px;
+      int m = min(chunk, n);
+      u32 pq = (u32)(p + lane);
+      wave_fence();  // pixels written by other lanes are read here
+      if (t >= 2) v = ring[(pq - back) & pm];
+      if (lane < m) ring[pq & pm] = v;
+      if (SCPR_UNLIKELY(n > chunk)) {
+#pragma nounroll
+        for (int q0 = chunk; q0 < n; q0 += chunk) {
+          wave_fence();  // a run may be longer than a row
+          m = min(chunk, n - q0);
+          pq = (u32)(p + q0 + lane);
+          if (t >= 2) v = ring[(pq - back) & pm];
+          if (lane < m) ring[pq & pm] = v;
+        }
       }
       wave_fence();
       lastpix = rdl(v, m - 1);
-    } else if (SCPR_UNLIKELY(t == 3)) {
-      D.bad = true;
-      break;
     } else {  // above-left with row padding in the way, or the gradient predictor
       u32 v = 0;
       int m = 0;
