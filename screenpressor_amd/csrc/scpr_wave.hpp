@@ -282,7 +282,9 @@ struct WaveModel {
   __device__ __forceinline__ int small_op(u32* r, ColHdr& h, u32& w, int in, u32& ofr, u32& ocf) {
     int d = h.d;
     int tot = h.total;
-    const int sh = shift_for(tot), bonus = (kProbScale - (tot << sh)) >> sh;  // spare code space goes to the top entry
+    // shift_for(tot) without the clamp: a small table's total stays in [2, 4096], so the leading-zero count is
+    // at least 20 (and the whole expression stays on the scalar unit)
+    const int sh = __builtin_clz((u32)(tot - 1)) - 20, bonus = (kProbScale - (tot << sh)) >> sh;  // spare code space goes to the top entry
     const int vv = DEC ? in >> sh : 0;
     const int above = (lane > h.maxpos ? bonus : 0) - lane;
     const int st = (int)sm_sym(w) + (int)sm_p(w) + above;  // where this lane's interval starts
@@ -836,17 +838,21 @@ struct WaveDec : WaveModel {
     if (SCPR_UNLIKELY(h.kind < 4)) {
       c = (int)take_byte();
       note_raw(r, h, c, w);
+      wave_fence();
+      if ((h.kind == 4 || h.kind == 5) && lane < 16) r[4 + lane] = w;  // promoted to a small table
     } else {
       u32 fr, cf;
       const u32 v = x & (kProbScale - 1);
-      if (SCPR_LIKELY(h.kind <= 5)) c = small_op<true>(r, h, w, (int)v, fr, cf);
-      else c = dense_op<true>(r, h, (int)v, fr, cf);
+      if (SCPR_LIKELY(h.kind <= 5)) {
+        c = small_op<true>(r, h, w, (int)v, fr, cf);
+        wave_fence();
+        if (SCPR_LIKELY(h.kind <= 5) && lane < 16) r[4 + lane] = w;  // (a full table has just become a dense one otherwise)
+      } else {
+        c = dense_op<true>(r, h, (int)v, fr, cf);
+      }
       advance(cf, fr, v);
     }
     wave_fence();
-    if (SCPR_LIKELY(h.kind == 4 || h.kind == 5)) {
-      if (lane < 16) r[4 + lane] = w;
-    }
     if (lane == 0) *(uint2*)r = make_uint2(pack0(h), pack1(h));
     wave_fence();
     count();
@@ -919,7 +925,8 @@ __device__ __forceinline__ void decode_intra_frame(DEC& D, const Geom& g, u8* __
   //   header phase (p <= W): literal + run length over the first row and pixel (0,1)  (:421-438)
   //   body: pixel type, literal if type 0, run length                                  (:443-494)
   int p = 0, t = 0;  // next pixel (raster index), type of the previous run
-  while (SCPR_LIKELY(p < NP && !D.bad)) {
+  const u32 slow_types = pad ? 0x38u : 0x18u;  // bit t: not one of the plain fills below (3 does not exist, 4 gradient, 5 when rows are padded)
+  while (SCPR_LIKELY(p < NP)) {
     const bool hdr = p <= W;
     D.template stamp<4>();
     if (SCPR_LIKELY(!hdr)) t = D.fixed_p(t);
@@ -939,11 +946,11 @@ __device__ __forceinline__ void decode_intra_frame(DEC& D, const Geom& g, u8* __
     }
     const int n = D.fixed_n(t);
     D.template stamp<2>();
-    if (SCPR_UNLIKELY((u32)(n - 1) >= (u32)((hdr ? W + 1 : NP) - p) || t == 3)) {  // empty, or longer than what is left (of the header row); type 3 does not exist
+    if (SCPR_UNLIKELY((u32)(n - 1) >= (u32)((hdr ? W + 1 : NP) - p))) {  // empty, or longer than what is left (of the header row)
       D.bad = true;
       break;
     }
-    if (SCPR_LIKELY(t != 4 && (t != 5 || pad == 0))) {
+    if (SCPR_LIKELY(!((slow_types >> t) & 1u))) {
       // literal / copy of the previous pixel (0, 1): every pixel of the run has the same value;
       // copy of the pixel above (2) or above-left (5): read one row back in the ring.
       // Almost every run fits one pass of the wave; the rest goes round the loop.
@@ -966,6 +973,9 @@ __device__ __forceinline__ void decode_intra_frame(DEC& D, const Geom& g, u8* __
       }
       wave_fence();
       lastpix = rdl(v, m - 1);
+    } else if (SCPR_UNLIKELY(t == 3)) {  // no such type: the frame is refused, the loop ends here
+      D.bad = true;
+      p = NP - n;
     } else {  // above-left with row padding in the way, or the gradient predictor
       u32 v = 0;
       int m = 0;
