@@ -946,26 +946,27 @@ __device__ __forceinline__ void decode_intra_frame(DEC& D, const Geom& g, u8* __
     }
     const int n = D.fixed_n(t);
     D.template stamp<2>();
-    if (SCPR_UNLIKELY((u32)(n - 1) >= (u32)((hdr ? W + 1 : NP) - p))) {  // empty, or longer than what is left (of the header row)
-      D.bad = true;
-      break;
-    }
-    if (SCPR_LIKELY(!((slow_types >> t) & 1u))) {
+    // an empty run, or one longer than what is left (of the header row), ends the frame like the type that does not exist
+    const int tt = SCPR_UNLIKELY((u32)(n - 1) >= (u32)((hdr ? W + 1 : NP) - p)) ? 3 : t;
+    const bool slow = (slow_types >> tt) & 1u;
+    {
       // literal / copy of the previous pixel (0, 1): every pixel of the run has the same value;
       // copy of the pixel above (2) or above-left (5): read one row back in the ring.
-      // Almost every run fits one pass of the wave; the rest goes round the loop.
+      // Almost every run fits one pass of the wave; the rest goes round the loop.  (The other types take
+      // this path with an empty run and are handled below: a plain if costs the common case nothing.)
+      const int nf = slow ? 0 : n;
       const u32 back = (u32)W + (u32)(t >> 2);
       u32 v = px;
-      int m = min(chunk, n);
+      int m = min(chunk, nf);
       u32 pq = (u32)(p + lane);
       wave_fence();  // pixels written by other lanes are read here
       if (t >= 2) v = ring[(pq - back) & pm];
       if (lane < m) ring[pq & pm] = v;
-      if (SCPR_UNLIKELY(n > chunk)) {
+      if (SCPR_UNLIKELY(nf > chunk)) {
 #pragma nounroll
-        for (int q0 = chunk; q0 < n; q0 += chunk) {
+        for (int q0 = chunk; q0 < nf; q0 += chunk) {
           wave_fence();  // a run may be longer than a row
-          m = min(chunk, n - q0);
+          m = min(chunk, nf - q0);
           pq = (u32)(p + q0 + lane);
           if (t >= 2) v = ring[(pq - back) & pm];
           if (lane < m) ring[pq & pm] = v;
@@ -973,10 +974,13 @@ __device__ __forceinline__ void decode_intra_frame(DEC& D, const Geom& g, u8* __
       }
       wave_fence();
       lastpix = rdl(v, m - 1);
-    } else if (SCPR_UNLIKELY(t == 3)) {  // no such type: the frame is refused, the loop ends here
+    }
+    if (SCPR_UNLIKELY(slow)) {
+     if (tt == 3) {  // the frame is refused, the loop ends here
       D.bad = true;
       p = NP - n;
-    } else {  // above-left with row padding in the way, or the gradient predictor
+     } else {  // above-left with row padding in the way, or the gradient predictor
+      lastpix = px;
       u32 v = 0;
       int m = 0;
       for (int q0 = 0; q0 < n; q0 += chunk) {
@@ -1006,6 +1010,7 @@ __device__ __forceinline__ void decode_intra_frame(DEC& D, const Geom& g, u8* __
       }
       wave_fence();
       lastpix = rdl(v, m - 1);
+     }
     }
     D.template stamp<3>();
     p += n;
