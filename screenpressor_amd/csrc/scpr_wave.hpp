@@ -662,23 +662,24 @@ struct WaveDec : WaveModel {
     u32 e0, e1, et;
     asm volatile("ds_read_b32 %0, %3\n\tds_read_b32 %1, %3 offset:256\n\tds_read_b32 %2, %3 offset:1024\n\ts_waitcnt lgkmcnt(0)" : "=v"(e0), "=v"(e1), "=v"(et) : "v"(addr) : "memory");
     const int tot0 = (int)rfl(et);
-    int sym;
-    u32 s;
-    if (SCPR_LIKELY(rfl(e1) >= lim)) {  // cum of symbol 64 is above v
-      sym = __builtin_popcountll(__ballot(e0 < lim)) - 1;
-      s = rdl(e0, sym);
-      // the count of the symbol (from the lane that holds it) and the total (lane 0); the other lanes add 0 to padding
-      const u32 dc = lane == sym ? (u32)kStepDense : 0u, dt = lane == 0 ? (u32)kStepDense : 0u;
-      asm volatile("ds_add_u32 %0, %1 offset:%3\n\tds_add_u32 %0, %2 offset:1024" ::"v"(addr), "v"(dc), "v"(dt), "n"(4 * NTAB_CNT) : "memory");
-    } else {
+    // (plain ifs only: an else on this path costs the common case a taken branch)
+    int sym = __builtin_popcountll(__ballot(e0 < lim)) - 1;
+    u32 s = rdl(e0, sym);
+    if (SCPR_UNLIKELY(rfl(e1) < lim)) {  // cum of symbol 64 is not above v: the symbol is further up
       const u32 e2 = tab[128 + lane], e3 = tab[192 + lane];
       sym = 63 + __builtin_popcountll(__ballot(e1 < lim)) + __builtin_popcountll(__ballot(e2 < lim)) + __builtin_popcountll(__ballot(e3 < lim));
       const int q = sym >> 6, l = sym & 63;
       s = q == 1 ? rdl(e1, l) : q == 2 ? rdl(e2, l) : rdl(e3, l);
       if (lane == 0) {
-        const u32 a1 = (u32)(size_t)&tab[NTAB_CNT + sym], a2 = (u32)(size_t)&tab[256];
-        asm volatile("ds_add_u32 %0, %2\n\tds_add_u32 %1, %2" ::"v"(a1), "v"(a2), "v"((u32)kStepDense) : "memory");
+        const u32 a1 = (u32)(size_t)&tab[NTAB_CNT + sym];
+        asm volatile("ds_add_u32 %0, %1" ::"v"(a1), "v"((u32)kStepDense) : "memory");
       }
+    }
+    {
+      // the count of the symbol (from the lane that holds it: none for a symbol above 63, counted above) and the
+      // total (lane 0); the other lanes add 0 to padding
+      const u32 dc = lane == sym ? (u32)kStepDense : 0u, dt = lane == 0 ? (u32)kStepDense : 0u;
+      asm volatile("ds_add_u32 %0, %1 offset:%3\n\tds_add_u32 %0, %2 offset:1024" ::"v"(addr), "v"(dc), "v"(dt), "n"(4 * NTAB_CNT) : "memory");
     }
     advance(s >> 16, s & 0xFFFF, v);
     if (SCPR_UNLIKELY(tot0 + 2 * kStepDense > kProbScale)) {  // rebuild from the counts, ans_contexts.h:1075-1090
