@@ -835,24 +835,29 @@ struct WaveDec : WaveModel {
     ColHdr h;
     u32 w;
     u32* r = record(ctxid, h, w);
-    int c;
-    if (SCPR_UNLIKELY(h.kind < 4)) {
-      c = (int)take_byte();
-      note_raw(r, h, c, w);
+    // Plain ifs, the common case first (an else costs it a taken branch): a raw symbol leaves the coder alone,
+    // which is an advance over the whole range.
+    int c = 0;
+    u32 fr = kProbScale, cf = 0;
+    const u32 v = x & (kProbScale - 1);
+    int kind0 = h.kind;
+    if (SCPR_LIKELY((kind0 | 1) == 5)) {
+      c = small_op<true>(r, h, w, (int)v, fr, cf);
       wave_fence();
-      if ((h.kind == 4 || h.kind == 5) && lane < 16) r[4 + lane] = w;  // promoted to a small table
-    } else {
-      u32 fr, cf;
-      const u32 v = x & (kProbScale - 1);
-      if (SCPR_LIKELY(h.kind <= 5)) {
-        c = small_op<true>(r, h, w, (int)v, fr, cf);
+      if (SCPR_LIKELY(h.kind <= 5) && lane < 16) r[4 + lane] = w;  // (a full table has just become a dense one otherwise)
+    }
+    asm volatile("" : "+s"(kind0));  // keeps the two tests apart (merged, they come back as if/else)
+    if (SCPR_UNLIKELY((kind0 | 1) != 5)) {
+      if (kind0 < 4) {
+        c = (int)take_byte();
+        note_raw(r, h, c, w);
         wave_fence();
-        if (SCPR_LIKELY(h.kind <= 5) && lane < 16) r[4 + lane] = w;  // (a full table has just become a dense one otherwise)
+        if ((h.kind == 4 || h.kind == 5) && lane < 16) r[4 + lane] = w;  // promoted to a small table
       } else {
         c = dense_op<true>(r, h, (int)v, fr, cf);
       }
-      advance(cf, fr, v);
     }
+    advance(cf, fr, v);
     wave_fence();
     if (lane == 0) *(uint2*)r = make_uint2(pack0(h), pack1(h));
     wave_fence();
