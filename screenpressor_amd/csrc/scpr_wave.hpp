@@ -78,7 +78,8 @@ struct FixedBlob {      // every fixed-alphabet model of the decoder (its image 
   int ftot[24];        // totals: 0-5 run lengths, 6-11 pixel types, 12/13 mv, 14/15 index/length, 16-19 rect, 20 block type
 };
 // A colour context as the decoder keeps it (LDS cache line and HBM backing store, 80 bytes):
-//   w[0..2] header (kind | maxpos << 8 | fshift << 16, d | total << 16, dense table index), w[3] cache tag,
+//   w[0] kind | maxpos << 8 | fshift << 16 | d << 20 (rewritten when it changes), w[1] total | fmax << 16 (rewritten after
+//   every symbol), w[2] dense table index (written when the table is allocated), w[3] cache tag,
 //   w[4..11] the 256-bit symbol set (kinds 1-3 and 6), or
 //   w[4 + i] small-table entry i (kinds 4/5), see SmallTab.
 struct DecRec {
@@ -116,6 +117,7 @@ struct __attribute__((aligned(16))) WaveLds {
 // coder value) and the encoder chains (interval from symbol).
 struct ColHdr {
   int kind, maxpos, fshift, d, total;  // total: cached sum of kinds 4-7 (kind 4: kept exact, the reference recomputes it per symbol)
+  int fmax;                             // kinds 4/5: the count of entry maxpos (derived: saves reading it back for every symbol)
   u32 dense;
 };
 // Small table (kinds 4/5): entry i in lane i, sorted by symbol, one packed word per lane:
@@ -133,10 +135,12 @@ __device__ __forceinline__ u32 sm_p(u32 w) { return w >> 20; }
 
 struct WaveModel {
   const int lane;
+  const int l15;  // lane & 15: a small table is kept in every row of 16 lanes alike (so that it can be stored without a lane mask)
   u16* tmp;  // 256 x u16 LDS scratch
   Arena arena;
   int f0;
-  __device__ __forceinline__ WaveModel(u16* tmp_, Arena a, int f0_) : lane(lane_id()), tmp(tmp_), arena(a), f0(f0_) {}
+  __device__ __forceinline__ WaveModel(u16* tmp_, Arena a, int f0_) : lane(lane_id()), l15(lane_id() & 15), tmp(tmp_), arena(a), f0(f0_) {}
+  __device__ __forceinline__ int small_fmax(const ColHdr& h, u32 w) { return (int)sm_fq(rdl(w, h.maxpos)); }
 
   static __device__ __forceinline__ ColHdr unpack(u32 h0, u32 h1, u32 h2) {
     ColHdr h;
@@ -145,6 +149,7 @@ struct WaveModel {
     h.fshift = (h0 >> 16) & 255;
     h.d = h1 & 0xFFFF;
     h.total = h1 >> 16;
+    h.fmax = 0;  // see small_fmax()
     h.dense = h2;
     return h;
   }
@@ -152,15 +157,15 @@ struct WaveModel {
   static __device__ __forceinline__ u32 pack1(const ColHdr& h) { return (u32)h.d | ((u32)h.total << 16); }
   // packed table from per-lane symbols and counts (after a rebuild of the counts, or a load); returns the exact total
   __device__ __forceinline__ int small_pack(u32& w, int sym, int fq, int d) {
-    fq = lane < d ? fq : 0;
+    fq = l15 < d ? fq : 0;
     const int incl = row_incl_scan(fq);
-    w = lane < d ? ((u32)sym | ((u32)fq << 8) | ((u32)(incl - fq) << 20)) : kSmallNone;
+    w = l15 < d ? ((u32)sym | ((u32)fq << 8) | ((u32)(incl - fq) << 20)) : kSmallNone;
     return 256 - d + (int)rdl((u32)incl, 15);
   }
   // ColState image (encoder persistence): entry i <-> record bytes 16+i (symbol) and 32+2i (count)
   __device__ __forceinline__ void load_small(const u32* r, int d, u32& w) {
-    const bool act = lane < d;
-    small_pack(w, act ? ((const u8*)r)[16 + lane] : 0, act ? ((const u16*)r)[16 + lane] : 0, d);
+    const bool act = l15 < d;
+    small_pack(w, act ? ((const u8*)r)[16 + l15] : 0, act ? ((const u16*)r)[16 + l15] : 0, d);
   }
   __device__ __forceinline__ void store_small(u32* r, int d, u32 w) {
     if (lane < d) {
@@ -229,10 +234,11 @@ struct WaveModel {
       for (int q = 0; q < 4; q++)
         if ((bits >> q) & 1u) tmp[base + __builtin_popcount(bits & ((1u << q) - 1u))] = (u16)(lane * 4 + q);
       wave_fence();
-      const int sym = lane < d ? (int)tmp[lane] : 0;
+      const int sym = l15 < d ? (int)tmp[l15] : 0;
       wave_fence();
       h.kind = d <= 4 ? 4 : 5;
       h.total = small_pack(w, sym, sym == c ? 2 * kStepSmall : kStepSmall, d);
+      h.fmax = 2 * kStepSmall;  // maxpos is the repeated symbol
       return;
     }
     h.dense = alloc_dense();
@@ -286,7 +292,7 @@ struct WaveModel {
     // at least 20 (and the whole expression stays on the scalar unit)
     const int sh = __builtin_clz((u32)(tot - 1)) - 20, bonus = (kProbScale - (tot << sh)) >> sh;  // spare code space goes to the top entry
     const int vv = DEC ? in >> sh : 0;
-    const int above = (lane > h.maxpos ? bonus : 0) - lane;
+    const int above = (l15 > h.maxpos ? bonus : 0) - l15;
     const int st = (int)sm_sym(w) + (int)sm_p(w) + above;  // where this lane's interval starts
     const u32 m = DEC ? (u32)__ballot(st <= vv) & 0xFFFFu : (u32)__ballot((int)sm_sym(w) <= in) & ((1u << d) - 1u);
     int p = -1, sp = -1, endp = 0, ap = 0, fpr = 0, pp = 0;
@@ -303,14 +309,17 @@ struct WaveModel {
     if (SCPR_LIKELY(hit)) {
       ofr = (u32)(endp - ap) << sh;
       ocf = (u32)ap << sh;
-      const int fmax = (int)sm_fq(rdl(w, h.maxpos));
-      const u32 add = lane == p ? (u32)kStepSmall << 8 : ((u32)(lane - p - 1) < (u32)(d - p - 1) ? (u32)kStepSmall << 20 : 0u);  // the count of p, the P of p+1 .. d-1
+      const u32 add = l15 == p ? (u32)kStepSmall << 8 : ((u32)(l15 - p - 1) < (u32)(d - p - 1) ? (u32)kStepSmall << 20 : 0u);  // the count of p, the P of p+1 .. d-1
       w += add;
       tot += kStepSmall;
-      if (p != h.maxpos && fpr + kStepSmall > fmax) h.maxpos = p;
+      if (fpr + kStepSmall > h.fmax) {  // p is the top entry already, or becomes it (:181)
+        h.maxpos = p;
+        h.fmax = fpr + kStepSmall;
+      }
       if (SCPR_UNLIKELY(tot + kStepSmall > kProbScale)) {  // rescale, :186-193
         const int fq = (int)sm_fq(w);
         tot = small_pack(w, (int)sm_sym(w), fq - (fq >> 1), d);
+        h.fmax -= h.fmax >> 1;
       }
       h.total = tot;
       return sp;
@@ -322,12 +331,13 @@ struct WaveModel {
     const int cap = h.kind == 4 ? 4 : 16;
     if (d < cap || h.kind == 4) {  // addSymb (:174-184), or Cx5::create(Cx4&, c) (:350-369) when the 4-table is full
       const u32 up = (u32)dpp_row_shr1((int)w);
-      if (lane > pos && lane <= d) w = up + ((u32)kStepSmall << 20);
-      else if (lane == pos) w = (u32)c | ((u32)kStepSmall << 8) | ((u32)(pp + fpr) << 20);
+      if (l15 > pos && l15 <= d) w = up + ((u32)kStepSmall << 20);
+      else if (l15 == pos) w = (u32)c | ((u32)kStepSmall << 8) | ((u32)(pp + fpr) << 20);
       const bool grow = d == cap;  // kind 4 -> 5: maxpos restarts at 0 (value-initialised in the reference)
       d++;
       if (grow) {
         h.maxpos = 0;
+        h.fmax = (int)sm_fq(rdl(w, 0));
         h.kind = 5;
         tot += kStepSmall - 1;  // the exact total of the grown table
       } else {
@@ -335,6 +345,7 @@ struct WaveModel {
         if (tot + 2 * kStepSmall > kProbScale) {
           const int fq = (int)sm_fq(w);
           tot = small_pack(w, (int)sm_sym(w), fq - (fq >> 1), d);
+          h.fmax -= h.fmax >> 1;
         } else {
           tot += h.kind == 4 ? kStepSmall - 1 : kStepSmall;  // kind 5 counts the step only (its total drifts, :174-184)
         }
@@ -344,7 +355,7 @@ struct WaveModel {
       return c;
     }
     // kind 5 full
-    const bool act = lane < d;
+    const bool act = l15 < d;
     const int fqv = act ? (int)sm_fq(w) : 0;
     wave_fence();
     for (int q = 0; q < 4; q++) tmp[lane * 4 + q] = 0;
@@ -381,6 +392,8 @@ struct WaveModel {
     h.fshift = s2;
     h.d = d + 1;
     h.total = ((256 - (d + 1)) << (s2 > 0 ? s2 - 1 : 0)) + sum;
+    wave_fence();
+    w = r[4 + l15];  // the decoder stores w over the entries after every symbol: make that harmless for the new set
     return c;
   }
 
@@ -804,11 +817,12 @@ struct WaveDec : WaveModel {
   // --------------------------------------------------------------- colour ---
   // The record of a context in the LDS cache: header + tag (one broadcast read) and the small
   // table (one word per lane, lanes 16.. mirror lanes 0..15) come back from one wait.
-  __device__ __forceinline__ u32* record(int ctxid, ColHdr& h, u32& w) {
+  __device__ __forceinline__ u32* record(int ctxid, ColHdr& h, u32& w, u32& ra, u32& ea, u32& h0) {
     wave_fence();
     const int slot = (ctxid ^ (ctxid >> 7)) & (CACHE_N - 1);
     u32* r = L.crec[slot];
-    const u32 ra = (u32)(size_t)r, ea = ra + 16u + 4u * (u32)(lane & 15);
+    ra = (u32)(size_t)r;
+    ea = ra + 16u + 4u * (u32)l15;
     u32x4 hw;
     asm volatile("ds_read_b128 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=v"(hw), "=v"(w) : "v"(ra), "v"(ea) : "memory");
     const int tag = (int)rfl(hw.w);
@@ -820,9 +834,18 @@ struct WaveDec : WaveModel {
       wave_fence();
       asm volatile("ds_read_b128 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=v"(hw), "=v"(w) : "v"(ra), "v"(ea) : "memory");
     }
-    h = unpack(rfl(hw.x), rfl(hw.y), rfl(hw.z));
+    h0 = rfl(hw.x);
+    const u32 h1 = rfl(hw.y);
+    h.kind = h0 & 255;
+    h.maxpos = (h0 >> 8) & 255;
+    h.fshift = (h0 >> 16) & 15;
+    h.d = h0 >> 20;
+    h.total = h1 & 0xFFFF;
+    h.fmax = h1 >> 16;
+    h.dense = rfl(hw.z);
     return r;
   }
+  static __device__ __forceinline__ u32 dec_pack0(const ColHdr& h) { return (u32)h.kind | ((u32)h.maxpos << 8) | ((u32)h.fshift << 16) | ((u32)h.d << 20); }
   __device__ __forceinline__ void flush_records() {
     wave_fence();
     for (int slot = 0; slot < CACHE_N; slot++) {
@@ -833,8 +856,8 @@ struct WaveDec : WaveModel {
   // decodeC (screencap.h:318-333)
   __device__ __forceinline__ int colour(int ctxid) {
     ColHdr h;
-    u32 w;
-    u32* r = record(ctxid, h, w);
+    u32 w, ra, ea, h0;
+    u32* r = record(ctxid, h, w, ra, ea, h0);
     // Plain ifs, the common case first (an else costs it a taken branch): a raw symbol leaves the coder alone,
     // which is an advance over the whole range.
     int c = 0;
@@ -844,7 +867,9 @@ struct WaveDec : WaveModel {
     if (SCPR_LIKELY((kind0 | 1) == 5)) {
       c = small_op<true>(r, h, w, (int)v, fr, cf);
       wave_fence();
-      if (SCPR_LIKELY(h.kind <= 5) && lane < 16) r[4 + lane] = w;  // (a full table has just become a dense one otherwise)
+      // the entries go back from every row of 16 lanes alike: no lane mask (a full table has just become a dense
+      // one: then w holds what is there already)
+      asm volatile("ds_write_b32 %0, %1" ::"v"(ea), "v"(w) : "memory");
     }
     asm volatile("" : "+s"(kind0));  // keeps the two tests apart (merged, they come back as if/else)
     if (SCPR_UNLIKELY((kind0 | 1) != 5)) {
@@ -853,13 +878,19 @@ struct WaveDec : WaveModel {
         note_raw(r, h, c, w);
         wave_fence();
         if ((h.kind == 4 || h.kind == 5) && lane < 16) r[4 + lane] = w;  // promoted to a small table
+        wave_fence();
       } else {
         c = dense_op<true>(r, h, (int)v, fr, cf);
       }
     }
     advance(cf, fr, v);
     wave_fence();
-    if (lane == 0) *(uint2*)r = make_uint2(pack0(h), pack1(h));
+    {  // the header: the word that changes with every symbol from all lanes alike (same address, same value), the other one when it changes
+      const u32 h1 = (u32)h.total | ((u32)h.fmax << 16);
+      asm volatile("ds_write_b32 %0, %1 offset:4" ::"v"(ra), "v"(h1) : "memory");
+      const u32 n0 = dec_pack0(h);
+      if (SCPR_UNLIKELY(n0 != h0)) asm volatile("ds_write_b32 %0, %1" ::"v"(ra), "v"(n0) : "memory");
+    }
     wave_fence();
     count();
     return c;
@@ -1367,7 +1398,10 @@ __global__ __launch_bounds__(64) void k_colour_chain_w(const u32* __restrict__ s
         if (lane < 16) rec[lane] = w;
         wave_fence();
         h = WaveModel::unpack(rdl(w, 0), rdl(w, 1), rdl(w, 2));
-        if (h.kind == 4 || h.kind == 5) M.load_small(rec, h.d, T);
+        if (h.kind == 4 || h.kind == 5) {
+          M.load_small(rec, h.d, T);
+          h.fmax = M.small_fmax(h, T);
+        }
       }
     }
     for (u32 base = 0; base < len; base += 64) {
