@@ -57,7 +57,7 @@ __device__ __forceinline__ int wave_sum(int v) {
   return (int)(rdl((u32)v, 15) + rdl((u32)v, 31) + rdl((u32)v, 47) + rdl((u32)v, 63));
 }
 __device__ __forceinline__ int shift_for(int tot) {  // number of doublings until tot > 2048 (ans_contexts.h:196-199), tot >= 2
-  return max(0, __builtin_clz((u32)(tot - 1)) - 20);
+  return __builtin_clz(min((u32)(tot - 1), 0x800u)) - 20;  // (the clamp on the argument, not on the result: stays on the scalar unit)
 }
 
 constexpr int CACHE_N = 256;  // colour records cached in LDS
@@ -141,6 +141,12 @@ struct WaveModel {
   int f0;
   __device__ __forceinline__ WaveModel(u16* tmp_, Arena a, int f0_) : lane(lane_id()), l15(lane_id() & 15), tmp(tmp_), arena(a), f0(f0_) {}
   __device__ __forceinline__ int small_fmax(const ColHdr& h, u32 w) { return (int)sm_fq(rdl(w, h.maxpos)); }
+  // The header fields are wave-uniform wherever they were computed; after the rare paths (which work on the vector
+  // unit) this says so to the compiler: without it the common path keeps the header in vector registers too.
+  static __device__ __forceinline__ void scalar_hdr(ColHdr& h) {
+    h.kind = (int)rfl((u32)h.kind), h.maxpos = (int)rfl((u32)h.maxpos), h.fshift = (int)rfl((u32)h.fshift), h.d = (int)rfl((u32)h.d);
+    h.total = (int)rfl((u32)h.total), h.fmax = (int)rfl((u32)h.fmax);
+  }
 
   static __device__ __forceinline__ ColHdr unpack(u32 h0, u32 h1, u32 h2) {
     ColHdr h;
@@ -295,18 +301,23 @@ struct WaveModel {
     const int above = (l15 > h.maxpos ? bonus : 0) - l15;
     const int st = (int)sm_sym(w) + (int)sm_p(w) + above;  // where this lane's interval starts
     const u32 m = DEC ? (u32)__ballot(st <= vv) & 0xFFFFu : (u32)__ballot((int)sm_sym(w) <= in) & ((1u << d) - 1u);
-    int p = -1, sp = -1, endp = 0, ap = 0, fpr = 0, pp = 0;
-    if (SCPR_LIKELY(m)) {
-      p = 31 - __builtin_clz(m);
-      const u32 wp = rdl(w, p);
-      sp = (int)sm_sym(wp);
-      fpr = (int)sm_fq(wp);
-      pp = (int)sm_p(wp);
-      ap = sp + pp - p + (p > h.maxpos ? bonus : 0);
-      endp = ap + fpr + (p == h.maxpos ? bonus : 0);
+    // (no entry at or below the input: p = -1 and what is read through it is garbage until the rare path below
+    // puts it right; the common path is not asked to branch round that case)
+    const int p = 31 - (m ? __builtin_clz(m) : 32);
+    const u32 wp = rdl(w, p);
+    int sp = (int)sm_sym(wp);
+    int fpr = (int)sm_fq(wp);
+    int pp = (int)sm_p(wp);
+    const int ap = sp + pp - p + (p > h.maxpos ? bonus : 0);
+    int endp = ap + fpr + (p == h.maxpos ? bonus : 0);
+    int over;  // < 0: the input is entry p
+    if (DEC) {
+      over = vv - endp;
+      over = m ? over : 0;
+    } else {
+      over = (m && sp == in) ? -1 : 0;
     }
-    const bool hit = DEC ? vv < endp : sp == in;
-    if (SCPR_LIKELY(hit)) {
+    if (SCPR_LIKELY(over < 0)) {
       ofr = (u32)(endp - ap) << sh;
       ocf = (u32)ap << sh;
       const u32 add = l15 == p ? (u32)kStepSmall << 8 : ((u32)(l15 - p - 1) < (u32)(d - p - 1) ? (u32)kStepSmall << 20 : 0u);  // the count of p, the P of p+1 .. d-1
@@ -322,8 +333,10 @@ struct WaveModel {
         h.fmax -= h.fmax >> 1;
       }
       h.total = tot;
-      return sp;
     }
+    if (DEC) asm volatile("" : "+s"(over));  // keeps the two tests apart: plain ifs, the common case first (merged, they come back as if/else)
+    if (SCPR_LIKELY(over < 0)) return sp;
+    if (!m) sp = -1, endp = 0, fpr = 0, pp = 0;
     const int c = DEC ? sp + 1 + vv - endp : in;
     ofr = 1u << sh;
     ocf = (u32)(DEC ? vv : c - sp - 1 + endp) << sh;
@@ -352,6 +365,7 @@ struct WaveModel {
       }
       h.d = d;
       h.total = tot;
+      if (DEC) scalar_hdr(h);
       return c;
     }
     // kind 5 full
@@ -394,6 +408,7 @@ struct WaveModel {
     h.total = ((256 - (d + 1)) << (s2 > 0 ? s2 - 1 : 0)) + sum;
     wave_fence();
     w = r[4 + l15];  // the decoder stores w over the entries after every symbol: make that harmless for the new set
+    if (DEC) scalar_hdr(h);
     return c;
   }
 
@@ -882,13 +897,13 @@ struct WaveDec : WaveModel {
       } else {
         c = dense_op<true>(r, h, (int)v, fr, cf);
       }
+      scalar_hdr(h);
     }
     advance(cf, fr, v);
     wave_fence();
     {  // the header: the word that changes with every symbol from all lanes alike (same address, same value), the other one when it changes
-      const u32 h1 = (u32)h.total | ((u32)h.fmax << 16);
+      u32 h1 = (u32)h.total | ((u32)h.fmax << 16), n0 = dec_pack0(h);
       asm volatile("ds_write_b32 %0, %1 offset:4" ::"v"(ra), "v"(h1) : "memory");
-      const u32 n0 = dec_pack0(h);
       if (SCPR_UNLIKELY(n0 != h0)) asm volatile("ds_write_b32 %0, %1" ::"v"(ra), "v"(n0) : "memory");
     }
     wave_fence();
