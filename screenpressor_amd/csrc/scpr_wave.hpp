@@ -498,7 +498,8 @@ struct WaveDec : WaveModel {
   const u8* src;
   const u8* src_end;
   const u32* wbase = nullptr;  // 4-byte aligned base of the current packet
-  u32 wpos = 0, wmax = 0, nextw = 0;
+  u32 wpos = 0, wmax = 0;       // next word to take, last word of the packet buffer
+  u32 blk = 0;                  // lane i: word i of the current 64-word block
   u64 buf = 0;
   int nb = 0;
   // coder
@@ -513,11 +514,14 @@ struct WaveDec : WaveModel {
   __device__ __forceinline__ WaveDec(WaveLds& l, const u8* s, const u8* e, DecRec* gs, Arena a, int f0_) : WaveModel(l.tmp, a, f0_), L(l), src(s), src_end(e), gstates(gs) {}
 
   // ---------------------------------------------------------------- input ---
-  // The packet bytes are read with wave-uniform 4-byte loads straight from the packet buffer
-  // (scalar cache), one word ahead of use, into a 64-bit shift buffer.
-  __device__ __forceinline__ u32 fetch_word(u32 i) {
-    const u32 m = i < wmax ? i : wmax;
-    return rfl(wbase[m]);
+  // The packet is read 256 bytes at a time: one load gives every lane one 4-byte word of the block and the
+  // coder takes them out with a lane read: one memory wait per 256 bytes instead of one per word.  (Asking
+  // for the next block ahead of use was tried: the register in flight gets copied at every join of the
+  // control flow, and each copy waits for the load.)  Word indices are clamped to the last word of the
+  // packet buffer (nothing is read past it).
+  __device__ __forceinline__ u32 load_block(u32 b) {
+    const u32 i = b * 64u + (u32)lane;
+    return __builtin_nontemporal_load(&wbase[i < wmax ? i : wmax]);
   }
   __device__ __forceinline__ void stream_init(const u8* s) {  // decodeBegin, screencap.h:295-301
     wave_fence();
@@ -526,10 +530,10 @@ struct WaveDec : WaveModel {
     const u32 skip = (u32)(a & 3);
     wmax = (u32)(((size_t)rfl64((u64)(size_t)src_end) - (a & ~(size_t)3)) >> 2);
     wmax = wmax ? wmax - 1 : 0;
-    buf = (u64)(fetch_word(0) >> (8 * skip));
+    blk = load_block(0);
+    buf = (u64)(rdl(blk, 0) >> (8 * skip));
     nb = 4 - (int)skip;
     wpos = 1;
-    nextw = fetch_word(1);
     ndec = 0;
     x = take_u32();
   }
@@ -549,13 +553,14 @@ struct WaveDec : WaveModel {
 #endif
   __device__ __forceinline__ void need(int k) {
     while (SCPR_UNLIKELY(nb < k)) {
-      buf |= (u64)nextw << (8 * nb);
-      nb += 4;
-      wpos++;
-      nextw = fetch_word(wpos);
+      u32 w = rdl(blk, (int)(wpos & 63u));
       // Past the end of the packet buffer the reader supplies 0xFF bytes: a damaged stream can run off the end,
       // and the refill loop of the coder (advance) must still terminate (on zero bytes it would not).
-      if (SCPR_UNLIKELY(wpos > wmax)) nextw = 0xFFFFFFFFu;
+      if (SCPR_UNLIKELY(wpos > wmax)) w = 0xFFFFFFFFu;
+      buf |= (u64)w << (8 * nb);
+      nb += 4;
+      wpos++;
+      if (SCPR_UNLIKELY((wpos & 63u) == 0)) blk = load_block(wpos >> 6);
     }
   }
   __device__ __forceinline__ u32 take_byte() {
