@@ -983,10 +983,10 @@ __device__ __forceinline__ void decode_intra_frame(DEC& D, const Geom& g, u8* __
   //   body: pixel type, literal if type 0, run length                                  (:443-494)
   int p = 0, t = 0;  // next pixel (raster index), type of the previous run
   const u32 slow_types = pad ? 0x38u : 0x18u;  // bit t: not one of the plain fills below (3 does not exist, 4 gradient, 5 when rows are padded)
+  int lim = W + 1;  // where the runs of the current phase must end: the header phase covers pixels 0..W
   while (SCPR_LIKELY(p < NP)) {
-    const bool hdr = p <= W;
     D.template stamp<4>();
-    if (SCPR_LIKELY(!hdr)) t = D.fixed_p(t);
+    if (SCPR_LIKELY(lim == NP)) t = D.fixed_p(t);
     D.template stamp<0>();
     u32 px = lastpix;
     if (t == 0) {  // DecodeRGB, screencap.cpp:662-679: contexts are the two previous bytes >> 2 (MAKECX1, screencap.h:35-36)
@@ -1004,14 +1004,13 @@ __device__ __forceinline__ void decode_intra_frame(DEC& D, const Geom& g, u8* __
     const int n = D.fixed_n(t);
     D.template stamp<2>();
     // an empty run, or one longer than what is left (of the header row), ends the frame like the type that does not exist
-    const int tt = SCPR_UNLIKELY((u32)(n - 1) >= (u32)((hdr ? W + 1 : NP) - p)) ? 3 : t;
-    const bool slow = (slow_types >> tt) & 1u;
+    const int tt = SCPR_UNLIKELY((u32)(n - 1) >= (u32)(lim - p)) ? 3 : t;
+    const int nf = ((slow_types >> tt) & 1u) ? 0 : n;  // pixels of the run for the common path below
     {
       // literal / copy of the previous pixel (0, 1): every pixel of the run has the same value;
       // copy of the pixel above (2) or above-left (5): read one row back in the ring.
       // Almost every run fits one pass of the wave; the rest goes round the loop.  (The other types take
       // this path with an empty run and are handled below: a plain if costs the common case nothing.)
-      const int nf = slow ? 0 : n;
       const u32 back = (u32)W + (u32)(t >> 2);
       u32 v = px;
       int m = min(chunk, nf);
@@ -1032,7 +1031,7 @@ __device__ __forceinline__ void decode_intra_frame(DEC& D, const Geom& g, u8* __
       wave_fence();
       lastpix = rdl(v, m - 1);
     }
-    if (SCPR_UNLIKELY(slow)) {
+    if (SCPR_UNLIKELY(nf == 0)) {
      if (tt == 3) {  // the frame is refused, the loop ends here
       D.bad = true;
       p = NP - n;
@@ -1071,6 +1070,7 @@ __device__ __forceinline__ void decode_intra_frame(DEC& D, const Geom& g, u8* __
     }
     D.template stamp<3>();
     p += n;
+    lim = p > W ? NP : lim;
     if (SCPR_UNLIKELY(p >= rowbase + W)) {
       int done = flushed + 1;
       while ((done + 1) * W <= p) done++;
