@@ -118,6 +118,7 @@ struct __attribute__((aligned(16))) WaveLds {
 struct ColHdr {
   int kind, maxpos, fshift, d, total;  // total: cached sum of kinds 4-7 (kind 4: kept exact, the reference recomputes it per symbol)
   int fmax;                             // kinds 4/5: the count of entry maxpos (derived: saves reading it back for every symbol)
+  int dirty;                            // decoder: kind, fshift or d changed (the record word that holds them and maxpos is rewritten)
   u32 dense;
 };
 // Small table (kinds 4/5): entry i in lane i, sorted by symbol, one packed word per lane:
@@ -146,6 +147,7 @@ struct WaveModel {
   static __device__ __forceinline__ void scalar_hdr(ColHdr& h) {
     h.kind = (int)rfl((u32)h.kind), h.maxpos = (int)rfl((u32)h.maxpos), h.fshift = (int)rfl((u32)h.fshift), h.d = (int)rfl((u32)h.d);
     h.total = (int)rfl((u32)h.total), h.fmax = (int)rfl((u32)h.fmax);
+    h.dirty = 1;
   }
 
   static __device__ __forceinline__ ColHdr unpack(u32 h0, u32 h1, u32 h2) {
@@ -156,6 +158,7 @@ struct WaveModel {
     h.d = h1 & 0xFFFF;
     h.total = h1 >> 16;
     h.fmax = 0;  // see small_fmax()
+    h.dirty = 0;
     h.dense = h2;
     return h;
   }
@@ -862,6 +865,7 @@ struct WaveDec : WaveModel {
     h.d = h0 >> 20;
     h.total = h1 & 0xFFFF;
     h.fmax = h1 >> 16;
+    h.dirty = 0;
     h.dense = rfl(hw.z);
     return r;
   }
@@ -878,6 +882,7 @@ struct WaveDec : WaveModel {
     ColHdr h;
     u32 w, ra, ea, h0;
     u32* r = record(ctxid, h, w, ra, ea, h0);
+    const int maxpos0 = h.maxpos;
     // Plain ifs, the common case first (an else costs it a taken branch): a raw symbol leaves the coder alone,
     // which is an advance over the whole range.
     int c = 0;
@@ -907,9 +912,12 @@ struct WaveDec : WaveModel {
     advance(cf, fr, v);
     wave_fence();
     {  // the header: the word that changes with every symbol from all lanes alike (same address, same value), the other one when it changes
-      u32 h1 = (u32)h.total | ((u32)h.fmax << 16), n0 = dec_pack0(h);
+      const u32 h1 = (u32)h.total | ((u32)h.fmax << 16);
       asm volatile("ds_write_b32 %0, %1 offset:4" ::"v"(ra), "v"(h1) : "memory");
-      if (SCPR_UNLIKELY(n0 != h0)) asm volatile("ds_write_b32 %0, %1" ::"v"(ra), "v"(n0) : "memory");
+      if (SCPR_UNLIKELY(h.dirty | (h.maxpos ^ maxpos0))) {
+        const u32 n0 = dec_pack0(h);
+        asm volatile("ds_write_b32 %0, %1" ::"v"(ra), "v"(n0) : "memory");
+      }
     }
     wave_fence();
     count();
