@@ -316,9 +316,9 @@ struct WaveModel {
     int over;  // < 0: the input is entry p
     if (DEC) {
       over = vv - endp;
-      over = m ? over : 0;
+      over = p >= 0 ? over : 0;
     } else {
-      over = (m && sp == in) ? -1 : 0;
+      over = (p >= 0 && sp == in) ? -1 : 0;
     }
     if (SCPR_LIKELY(over < 0)) {
       ofr = (u32)(endp - ap) << sh;
@@ -339,7 +339,7 @@ struct WaveModel {
     }
     if (DEC) asm volatile("" : "+s"(over));  // keeps the two tests apart: plain ifs, the common case first (merged, they come back as if/else)
     if (SCPR_LIKELY(over < 0)) return sp;
-    if (!m) sp = -1, endp = 0, fpr = 0, pp = 0;
+    if (p < 0) sp = -1, endp = 0, fpr = 0, pp = 0;
     const int c = DEC ? sp + 1 + vv - endp : in;
     ofr = 1u << sh;
     ocf = (u32)(DEC ? vv : c - sp - 1 + endp) << sh;
