@@ -25,8 +25,11 @@ def build_hip(force: bool = False) -> str:
     """hand-written HIP kernels + C ABI -> screenpressor_amd/libscpr_amd.so (gfx950)"""
     if force or _stale(LIB, HIP_DEPS):
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        # -align-all-nofallthru-blocks=6: branch targets that are not fallen into start on a 64-byte line (no padding is
+        # ever executed).  The decoder is one wave per CU taking ~9 branches per symbol: measured 2 % on its run time, and
+        # it takes most of the layout luck out of comparing small changes.
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-strict-aliasing", "-fPIC", "-shared", "-Wno-unused-result",
-               "-o", LIB, HIP_SRC] + HOST_SRC
+               "-mllvm", "-align-all-nofallthru-blocks=6", "-o", LIB, HIP_SRC] + HOST_SRC
         subprocess.check_call(cmd)
     return LIB
 

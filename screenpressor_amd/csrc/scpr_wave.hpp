@@ -991,7 +991,8 @@ __device__ __forceinline__ void decode_intra_frame(DEC& D, const Geom& g, u8* __
   //   body: pixel type, literal if type 0, run length                                  (:443-494)
   int p = 0, t = 0;  // next pixel (raster index), type of the previous run
   const u32 slow_types = pad ? 0x38u : 0x18u;  // bit t: not one of the plain fills below (3 does not exist, 4 gradient, 5 when rows are padded)
-  int lim = W + 1;  // where the runs of the current phase must end: the header phase covers pixels 0..W
+  int lim = W + 1;     // where the runs of the current phase must end: the header phase covers pixels 0..W
+  int rowend = W + 1;  // the row being decoded ends here (first row: with the header phase, one pixel later)
   while (SCPR_LIKELY(p < NP)) {
     D.template stamp<4>();
     if (SCPR_LIKELY(lim == NP)) t = D.fixed_p(t);
@@ -1078,11 +1079,12 @@ __device__ __forceinline__ void decode_intra_frame(DEC& D, const Geom& g, u8* __
     }
     D.template stamp<3>();
     p += n;
-    lim = p > W ? NP : lim;
-    if (SCPR_UNLIKELY(p >= rowbase + W)) {
+    if (SCPR_UNLIKELY(p >= rowend)) {  // a row is complete (the first time: the header phase is over as well)
+      lim = NP;
       int done = flushed + 1;
       while ((done + 1) * W <= p) done++;
       flush_rows(done);
+      rowend = rowbase + W;
     }
   }
   if (!D.bad) flush_rows(H);
