@@ -886,7 +886,7 @@ struct WaveDec : WaveModel {
     // Plain ifs, the common case first (an else costs it a taken branch): a raw symbol leaves the coder alone,
     // which is an advance over the whole range.
     int c = 0;
-    u32 fr = kProbScale, cf = 0;
+    u32 fr, cf;
     const u32 v = x & (kProbScale - 1);
     int kind0 = h.kind;
     if (SCPR_LIKELY((kind0 | 1) == 5)) {
@@ -899,6 +899,7 @@ struct WaveDec : WaveModel {
     asm volatile("" : "+s"(kind0));  // keeps the two tests apart (merged, they come back as if/else)
     if (SCPR_UNLIKELY((kind0 | 1) != 5)) {
       if (kind0 < 4) {
+        fr = kProbScale, cf = 0;
         c = (int)take_byte();
         note_raw(r, h, c, w);
         wave_fence();
