@@ -61,6 +61,7 @@ __device__ __forceinline__ int shift_for(int tot) {  // number of doublings unti
 }
 
 constexpr int CACHE_N = 256;  // colour records cached in LDS
+constexpr u32 kNoCtx = 0xFFFFFFFFu;  // tag of an empty cache slot
 
 struct FixedBlob {      // every fixed-alphabet model of the decoder (its image in HBM): freq | cum << 16, counts, running totals
   u32 nfc[6][256];     // run lengths, by pixel type (ntab)
@@ -78,7 +79,7 @@ struct FixedBlob {      // every fixed-alphabet model of the decoder (its image 
   int ftot[24];        // totals: 0-5 run lengths, 6-11 pixel types, 12/13 mv, 14/15 index/length, 16-19 rect, 20 block type
 };
 // A colour context as the decoder keeps it (LDS cache line and HBM backing store, 80 bytes):
-//   w[0] kind | maxpos << 8 | fshift << 16 | d << 20 (rewritten when it changes), w[1] total | fmax << 16 (rewritten after
+//   w[0] kind | maxpos << 8 | fshift << 16 | d << 20 | (kind is 4 or 5) << 31 (rewritten when it changes), w[1] total | fmax << 16 (rewritten after
 //   every symbol), w[2] dense table index (written when the table is allocated), w[3] cache tag,
 //   w[4..11] the 256-bit symbol set (kinds 1-3 and 6), or
 //   w[4 + i] small-table entry i (kinds 4/5), see SmallTab.
@@ -310,8 +311,7 @@ struct WaveModel {
     const u32 wp = rdl(w, p);
     int sp = (int)sm_sym(wp);
     int fpr = (int)sm_fq(wp);
-    int pp = (int)sm_p(wp);
-    const int ap = sp + pp - p + (p > h.maxpos ? bonus : 0);
+    const int ap = sp + (int)sm_p(wp) - p + (p > h.maxpos ? bonus : 0);
     int endp = ap + fpr + (p == h.maxpos ? bonus : 0);
     int over;  // < 0: the input is entry p
     if (DEC) {
@@ -339,6 +339,7 @@ struct WaveModel {
     }
     if (DEC) asm volatile("" : "+s"(over));  // keeps the two tests apart: plain ifs, the common case first (merged, they come back as if/else)
     if (SCPR_LIKELY(over < 0)) return sp;
+    int pp = (int)sm_p(wp);
     if (p < 0) sp = -1, endp = 0, fpr = 0, pp = 0;
     const int c = DEC ? sp + 1 + vv - endp : in;
     ofr = 1u << sh;
@@ -840,7 +841,7 @@ struct WaveDec : WaveModel {
   // --------------------------------------------------------------- colour ---
   // The record of a context in the LDS cache: header + tag (one broadcast read) and the small
   // table (one word per lane, lanes 16.. mirror lanes 0..15) come back from one wait.
-  __device__ __forceinline__ u32* record(int ctxid, ColHdr& h, u32& w, u32& ra, u32& ea, u32& h0) {
+  __device__ __forceinline__ u32* record(int ctxid, ColHdr& h, u32& w, u32& ra, u32& ea, u32& h0, u32& hz) {
     wave_fence();
     const int slot = (ctxid ^ (ctxid >> 7)) & (CACHE_N - 1);
     u32* r = L.crec[slot];
@@ -848,11 +849,11 @@ struct WaveDec : WaveModel {
     ea = ra + 16u + 4u * (u32)l15;
     u32x4 hw;
     asm volatile("ds_read_b128 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=v"(hw), "=v"(w) : "v"(ra), "v"(ea) : "memory");
-    const int tag = (int)rfl(hw.w);
-    if (SCPR_UNLIKELY(tag != ctxid + 1)) {
+    const u32 tag = rfl(hw.w);  // the context the slot holds (kNoCtx: none)
+    if (SCPR_UNLIKELY(tag != (u32)ctxid)) {
       if (lane < DECREC_WORDS) {
-        if (tag) gstates[tag - 1].w[lane] = r[lane];
-        r[lane] = lane == 3 ? (u32)(ctxid + 1) : gstates[ctxid].w[lane];
+        if (tag != kNoCtx) gstates[tag].w[lane] = r[lane];
+        r[lane] = lane == 3 ? (u32)ctxid : gstates[ctxid].w[lane];
       }
       wave_fence();
       asm volatile("ds_read_b128 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=v"(hw), "=v"(w) : "v"(ra), "v"(ea) : "memory");
@@ -861,44 +862,49 @@ struct WaveDec : WaveModel {
     const u32 h1 = rfl(hw.y);
     h.kind = h0 & 255;
     h.maxpos = (h0 >> 8) & 255;
-    h.fshift = (h0 >> 16) & 15;
-    h.d = h0 >> 20;
+    h.fshift = 0;  // a small table has none; colour() fills in this and the dense index for the other kinds
+    h.d = (h0 >> 20) & 0x7FF;
     h.total = h1 & 0xFFFF;
     h.fmax = h1 >> 16;
     h.dirty = 0;
-    h.dense = rfl(hw.z);
+    h.dense = 0;
+    hz = hw.z;
     return r;
   }
-  static __device__ __forceinline__ u32 dec_pack0(const ColHdr& h) { return (u32)h.kind | ((u32)h.maxpos << 8) | ((u32)h.fshift << 16) | ((u32)h.d << 20); }
+  static __device__ __forceinline__ u32 dec_pack0(const ColHdr& h) {
+    return (u32)h.kind | ((u32)h.maxpos << 8) | ((u32)h.fshift << 16) | ((u32)h.d << 20) | ((h.kind | 1) == 5 ? 0x80000000u : 0u);
+  }
   __device__ __forceinline__ void flush_records() {
     wave_fence();
     for (int slot = 0; slot < CACHE_N; slot++) {
-      const int tag = (int)rfl(L.crec[slot][3]);
-      if (tag && lane < DECREC_WORDS) gstates[tag - 1].w[lane] = L.crec[slot][lane];
+      const u32 tag = rfl(L.crec[slot][3]);
+      if (tag != kNoCtx && lane < DECREC_WORDS) gstates[tag].w[lane] = L.crec[slot][lane];
     }
   }
   // decodeC (screencap.h:318-333)
   __device__ __forceinline__ int colour(int ctxid) {
     ColHdr h;
-    u32 w, ra, ea, h0;
-    u32* r = record(ctxid, h, w, ra, ea, h0);
+    u32 w, ra, ea, h0, hz;
+    u32* r = record(ctxid, h, w, ra, ea, h0, hz);
     const int maxpos0 = h.maxpos;
     // Plain ifs, the common case first (an else costs it a taken branch): a raw symbol leaves the coder alone,
     // which is an advance over the whole range.
     int c = 0;
     u32 fr, cf;
     const u32 v = x & (kProbScale - 1);
-    int kind0 = h.kind;
-    if (SCPR_LIKELY((kind0 | 1) == 5)) {
+    int small0 = (int)h0;  // sign bit: a small table (kind 4 or 5)
+    if (SCPR_LIKELY(small0 < 0)) {
       c = small_op<true>(r, h, w, (int)v, fr, cf);
       wave_fence();
       // the entries go back from every row of 16 lanes alike: no lane mask (a full table has just become a dense
       // one: then w holds what is there already)
       asm volatile("ds_write_b32 %0, %1" ::"v"(ea), "v"(w) : "memory");
     }
-    asm volatile("" : "+s"(kind0));  // keeps the two tests apart (merged, they come back as if/else)
-    if (SCPR_UNLIKELY((kind0 | 1) != 5)) {
-      if (kind0 < 4) {
+    asm volatile("" : "+s"(small0));  // keeps the two tests apart (merged, they come back as if/else)
+    if (SCPR_UNLIKELY(small0 >= 0)) {
+      h.fshift = (int)((h0 >> 16) & 15u);
+      h.dense = rfl(hz);
+      if (h.kind < 4) {
         fr = kProbScale, cf = 0;
         c = (int)take_byte();
         note_raw(r, h, c, w);
@@ -1329,7 +1335,7 @@ __global__ __launch_bounds__(64) void k_decode_gop_w(const u8* __restrict__ pack
   extern __shared__ __align__(16) u8 pix[];  // ring_bytes = 4 * (power of two >= W + 512) pixels, then (P-frames) one byte per 16x16 block
   const DecGop gop = gops[blockIdx.x];
   const int lane = lane_id();
-  for (int i = lane; i < CACHE_N; i += 64) L.crec[i][3] = 0;  // empty cache
+  for (int i = lane; i < CACHE_N; i += 64) L.crec[i][3] = kNoCtx;  // empty cache
   WaveDec D(L, packets, packets_end, states + (size_t)blockIdx.x * NCOLCTX, arena, f0);
   if (gop.load) D.fixed_load(&fixedstore[blockIdx.x]);
   else D.fixed_init();
