@@ -416,32 +416,12 @@ struct WaveModel {
     return c;
   }
 
-  // kinds 6/7: Cx6/Cx7 decode and encode (ans_contexts.h:640-740, :953-997), 4 symbols per lane.
-  // REG (encoder chains: one wave stays on one context): the table is held in registers between the symbols of
-  // the chain - it is read from the arena once, rebuilt through the arena, and its counts go back when the chain
-  // ends (dense_flush).  Without that every symbol of a dense chain waits for an L2 round trip.
-  struct DenseRegs {
-    uint2 cu, fq, cq;
-    bool have = false;
-  };
-  __device__ __forceinline__ void dense_flush(const ColHdr& h, DenseRegs& R) {
-    if (R.have) ((uint2*)(arena.tabs + h.dense)->cnt)[lane] = R.cq;
-    R.have = false;
-  }
-  template <bool DEC, bool REG = false>
-  __device__ __forceinline__ int dense_op(u32* r, ColHdr& h, int in, u32& ofr, u32& ocf, DenseRegs* R = nullptr) {
+  // kinds 6/7: Cx6/Cx7 decode and encode (ans_contexts.h:640-740, :953-997), 4 symbols per lane
+  template <bool DEC>
+  __device__ __forceinline__ int dense_op(u32* r, ColHdr& h, int in, u32& ofr, u32& ocf) {
     wave_fence();
     DenseTab* t = arena.tabs + h.dense;
-    uint2 cu, fq, cq;
-    if (REG) {
-      if (!R->have) {
-        R->cu = ((const uint2*)t->cum)[lane], R->fq = ((const uint2*)t->freq)[lane], R->cq = ((const uint2*)t->cnt)[lane];
-        R->have = true;
-      }
-      cu = R->cu, fq = R->fq, cq = R->cq;
-    } else {
-      cu = ((const uint2*)t->cum)[lane], fq = ((const uint2*)t->freq)[lane], cq = ((const uint2*)t->cnt)[lane];
-    }
+    const uint2 cu = ((const uint2*)t->cum)[lane], fq = ((const uint2*)t->freq)[lane], cq = ((const uint2*)t->cnt)[lane];
     const u32 v = (u32)in;
     const u32 c0 = cu.x & 0xFFFF, c1 = cu.x >> 16, c2 = cu.y & 0xFFFF, c3 = cu.y >> 16;
     const u64 m = DEC ? __ballot(c0 <= v) : 0;
@@ -466,9 +446,7 @@ struct WaveModel {
           const int wdt = 1 << h.fshift, base = wdt - (wdt >> 1);
           for (int q = 0; q < 4; q++)
             if (!((bits >> q) & 1u)) cn[q] = base;
-          const uint2 nc = make_uint2((u32)cn[0] | ((u32)cn[1] << 16), (u32)cn[2] | ((u32)cn[3] << 16));
-          if (REG) R->cq = nc;
-          else ((uint2*)t->cnt)[lane] = nc;
+          ((uint2*)t->cnt)[lane] = make_uint2((u32)cn[0] | ((u32)cn[1] << 16), (u32)cn[2] | ((u32)cn[3] << 16));
           h.kind = 7;
           return j;
         }
@@ -493,7 +471,6 @@ struct WaveModel {
           cn[q] -= cn[q] >> 1;
         }
         h.total = write_dense(t, fr, cn);
-        if (REG) R->have = false;  // (read back from the arena by the next symbol)
       } else {  // Cx6::rescale, :742-796
         const int wdt = 1 << (h.fshift > 0 ? h.fshift - 1 : 0);
         if (h.fshift > 0) h.fshift--;
@@ -508,10 +485,7 @@ struct WaveModel {
         }
         const int sum = write_dense(t, fr, cn);
         h.total = ((256 - h.d) << (h.fshift > 0 ? h.fshift - 1 : 0)) + sum;
-        if (REG) R->have = false;
       }
-    } else if (REG) {
-      R->cq = make_uint2((u32)cn[0] | ((u32)cn[1] << 16), (u32)cn[2] | ((u32)cn[3] << 16));
     } else if (lane == own) {
       ((uint2*)t->cnt)[lane] = make_uint2((u32)cn[0] | ((u32)cn[1] << 16), (u32)cn[2] | ((u32)cn[3] << 16));
     }
@@ -1453,7 +1427,6 @@ __global__ __launch_bounds__(64) void k_colour_chain_w(const u32* __restrict__ s
     const int gen = (int)(q / NCOLCTX), ctx = (int)(q - (u32)gen * NCOLCTX);
     ColHdr h = WaveModel::unpack(0, 0, 0);
     u32 T = kSmallNone;
-    WaveModel::DenseRegs R;
     wave_fence();
     if (gen == 0 && cp.load_first) {  // continue the model of this context from the previous call
       const u32* src = (const u32*)&cp.states_in[ctx];
@@ -1484,12 +1457,11 @@ __global__ __launch_bounds__(64) void k_colour_chain_w(const u32* __restrict__ s
         else if (h.kind <= 5)
           M.small_op<false>(rec, h, T, c, fr, cf);
         else
-          M.dense_op<false, true>(rec, h, c, fr, cf, &R);
+          M.dense_op<false>(rec, h, c, fr, cf);
         if (lane == j) mine = (fr & 0xFFFFu) | (cf << 16);
       }
       if (lane < m) entries[pos] = mine;
     }
-    M.dense_flush(h, R);
     if (gen == cp.ngens - 1) {  // live generation: keep the state for the next call
       wave_fence();
       if (h.kind == 4 || h.kind == 5) M.store_small(rec, h.d, T);
