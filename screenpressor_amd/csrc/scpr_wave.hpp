@@ -318,7 +318,7 @@ struct WaveModel {
       over = vv - endp;
       over = p >= 0 ? over : 0;
     } else {
-      over = (p >= 0 && sp == in) ? -1 : 0;
+      over = (int)(((u32)(p >> 31) | (u32)(sp ^ in)) == 0u) * -1;  // no entry at or below the symbol, or another symbol: not a hit
     }
     if (SCPR_LIKELY(over < 0)) {
       ofr = (u32)(endp - ap) << sh;
@@ -337,7 +337,9 @@ struct WaveModel {
       }
       h.total = tot;
     }
-    if (DEC) asm volatile("" : "+s"(over));  // keeps the two tests apart: plain ifs, the common case first (merged, they come back as if/else)
+    // keeps the two tests apart: plain ifs, the common case first (merged, they come back as if/else)
+    if (DEC) asm volatile("" : "+s"(over));
+    else over = (int)rfl((u32)over);
     if (SCPR_LIKELY(over < 0)) return sp;
     int pp = (int)sm_p(wp);
     if (p < 0) sp = -1, endp = 0, fpr = 0, pp = 0;
@@ -369,7 +371,7 @@ struct WaveModel {
       }
       h.d = d;
       h.total = tot;
-      if (DEC) scalar_hdr(h);
+      scalar_hdr(h);
       return c;
     }
     // kind 5 full
@@ -412,7 +414,7 @@ struct WaveModel {
     h.total = ((256 - (d + 1)) << (s2 > 0 ? s2 - 1 : 0)) + sum;
     wave_fence();
     w = r[4 + l15];  // the decoder stores w over the entries after every symbol: make that harmless for the new set
-    if (DEC) scalar_hdr(h);
+    scalar_hdr(h);
     return c;
   }
 
@@ -1408,7 +1410,7 @@ __global__ __launch_bounds__(64) void k_colour_chain_w(const u32* __restrict__ s
   u32 cn[CHAIN_CLASSES], n = 0;
 #pragma unroll
   for (int k = 0; k < CHAIN_CLASSES; k++) {
-    cn[k] = min(counts[k], cap);
+    cn[k] = min(rfl(counts[k]), cap);  // (loaded values are wave-uniform: said so, or the loops below are compiled as divergent)
     n += cn[k];
   }
   for (u32 li = blockIdx.x; li < n; li += gridDim.x) {
@@ -1419,8 +1421,8 @@ __global__ __launch_bounds__(64) void k_colour_chain_w(const u32* __restrict__ s
         i -= cn[k];
         seg = k + 1;
       }
-    const u32 q = lists[(size_t)seg * cap + i];
-    const u32 start = cstart[q], len = cstart[q + 1] - start;
+    const u32 q = rfl(lists[(size_t)seg * cap + i]);
+    const u32 start = rfl(cstart[q]), len = rfl(cstart[q + 1]) - start;
     // the long chains are the critical path of the stage: their waves win the issue arbitration of their SIMD
     if (len >= 1024) __builtin_amdgcn_s_setprio(3);
     else __builtin_amdgcn_s_setprio(0);
@@ -1452,12 +1454,15 @@ __global__ __launch_bounds__(64) void k_colour_chain_w(const u32* __restrict__ s
         const int c = (int)(rdl(key, j) & 255u);
         u32 fr = 0, cf = (u32)c;
         wave_fence();
-        if (h.kind < 4)
-          M.note_raw(rec, h, c, T);
-        else if (h.kind <= 5)
-          M.small_op<false>(rec, h, T, c, fr, cf);
-        else
-          M.dense_op<false>(rec, h, c, fr, cf);
+        // plain ifs, the common case first (see the decoder's colour())
+        int small = ((h.kind | 1) == 5) ? -1 : 0;
+        if (SCPR_LIKELY(small < 0)) M.small_op<false>(rec, h, T, c, fr, cf);
+        small = (int)rfl((u32)small);  // (keeps the two tests apart)
+        if (SCPR_UNLIKELY(small >= 0)) {
+          if (h.kind < 4) M.note_raw(rec, h, c, T);
+          else M.dense_op<false>(rec, h, c, fr, cf);
+          WaveModel::scalar_hdr(h);
+        }
         if (lane == j) mine = (fr & 0xFFFFu) | (cf << 16);
       }
       if (lane < m) entries[pos] = mine;
