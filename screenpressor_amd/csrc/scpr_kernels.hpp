@@ -248,8 +248,7 @@ __global__ __launch_bounds__(256) void k_copy_planes(const u8* __restrict__ plan
 // screencap.cpp:502-521) and the set of predictors that fit it
 // (PixelTypeFits, :560-574): bit0 previous pixel (types 0/1), bit1 top (2),
 // bit2 gradient (4), bit3 top-left (5).
-__device__ __forceinline__ void classify_pixel(const u8* plane, const Geom& g, int p, int& type, int& fits) {
-  const int y = p / g.W, x = p - y * g.W;
+__device__ __forceinline__ void classify_pixel(const u8* plane, const Geom& g, int y, int x, int& type, int& fits) {
   const u8* c = plane + (size_t)y * g.S + x * 3;
   const u8* l = x > 0 ? c - 3 : plane + (size_t)(y - 1) * g.S + (g.W - 1) * 3;
   const u32 vc = ld3(c), vl = ld3(l), vt = ld3(c - g.S), vtl = ld3(c - g.S - 3);
@@ -320,12 +319,23 @@ __global__ __launch_bounds__(256) void k_tiles(const u8* __restrict__ planes, Ge
   const int slot = slots[blockIdx.y], tile = blockIdx.x, tid = threadIdx.x;
   const u8* plane = planes + (size_t)slot * g.plane_stride;
   const int tstart = g.p0 + tile * TILE;
+  // row and column of the tile's first pixel, once per workgroup; a pixel's own come from there by stepping over
+  // row ends (one division per pixel was a quarter of this kernel's instructions)
+  const int ty0 = __builtin_amdgcn_readfirstlane(tstart / g.W), tx0 = __builtin_amdgcn_readfirstlane(tstart - ty0 * g.W);
   if (tid < 4 * 24) ((u64*)fm)[tid] = 0;
   __syncthreads();
   for (int k = 0; k < 5; k++) {
     const int r = k * 256 + tid, p = tstart + r;
     int type = 0, fits = 0;
-    if (r < TILE + HALO && p < g.NP) classify_pixel(plane, g, p, type, fits);
+    if (r < TILE + HALO && p < g.NP) {
+      int y = ty0, x = tx0 + r;
+      if (g.W >= 512) {  // at most TILE + HALO + W pixels past the row start: a few row ends
+        while (x >= g.W) x -= g.W, y++;
+      } else {
+        y = p / g.W, x = p - y * g.W;
+      }
+      classify_pixel(plane, g, y, x, type, fits);
+    }
     if (r < TILE) ty[r] = (u8)type;
 #pragma unroll
     for (int b = 0; b < 4; b++) {
