@@ -36,6 +36,8 @@ constexpr u32 V2_BOT = 1u << 16;        // BOT_C, sub.h:17
 constexpr u32 V2_TOP = 1u << 24;        // TOP, sub.h:14
 
 struct WaveDecV2 {
+  static constexpr bool kFastRuns = false;  // decode_intra_frame: no second instance of the run body for this coder
+  int ndec = 0;                             // (unused: the range coder has no blocks)
   const int lane;
   V2Lds& L;
   // input stream (same reader as WaveDec: wave-uniform word loads into a 64-bit shift buffer)
@@ -203,13 +205,16 @@ struct WaveDecV2 {
     return sym;
   }
 
+  template <bool CHK = true>  // (the parameter only exists to match WaveDec, see decode_intra_frame)
   __device__ __forceinline__ int fixed_n(int t) { return dec_lds<4>(L.fx.n[t], 256, 400); }   // SC_NSTEP
+  template <bool CHK = true>  // (the parameter only exists to match WaveDec, see decode_intra_frame)
   __device__ __forceinline__ int fixed_p(int t) { return dec_lds<1>(L.fx.p[t], 6, 1000); }    // SC_UNSTEP
   __device__ __forceinline__ int fixed_x(int k) { return k == 0 ? dec_lds<4>(L.fx.x, 256, 1) : dec_lds<4>(L.fx.bn, 256, 20); }  // SC_XXSTEP / SC_BTNSTEP
   __device__ __forceinline__ int fixed_bt() { return dec_lds<1>(L.fx.bt, 5, 10); }            // SC_BTSTEP
   __device__ __forceinline__ int fixed_sxy(int k) { return dec_lds<1>(L.fx.sxy[k], 16, 100); }  // SC_SXYSTEP
   __device__ __forceinline__ int fixed_mv(int k) { return dec_lds<8>(L.fx.m[k], k ? my2 : mx2, 100); }  // SC_MSTEP
   __device__ __forceinline__ bool get_bool() { return false; }                                // canEncodeBool = false
+  template <bool CHK = true>  // (the parameter only exists to match WaveDec, see decode_intra_frame)
   __device__ __forceinline__ int colour(int ctxid) { return dec_global(gtabs + (size_t)ctxid * V2_COLTAB, 400); }  // SC_STEP
 
   // RenewI with the renew* of UseRC (screencap.h:146-260): every count 1

@@ -19,6 +19,7 @@
 // What a lone wave pays per dependent instruction, and the rules that follow, are in DESIGN.md §3
 // (tools/lonewave_bench.hip).
 #pragma once
+#include <type_traits>
 #include "scpr_kernels.hpp"
 
 namespace scpr {
@@ -589,7 +590,12 @@ struct WaveDec : WaveModel {
     x = hi + (v - cf);
     while (SCPR_UNLIKELY(x < kRansL)) x = (x << 8) | take_byte();  // ends on any input: past the packets the reader supplies 0xFF bytes
   }
+  // CHK = false: the caller has made sure the block does not end within this run and adds the run's symbols to ndec itself
+  // (decode_intra_frame's fast runs): a test-and-branch per symbol is ~20 cycles of a lone wave's time.
+  static constexpr bool kFastRuns = true;
+  template <bool CHK = true>
   __device__ __forceinline__ void count() {  // screencap.h:327-331
+    if (!CHK) return;
     if (SCPR_UNLIKELY(++ndec == kBlockEntries)) {
       x = take_u32();
       ndec = 0;
@@ -693,6 +699,7 @@ struct WaveDec : WaveModel {
   // Symbol j of a table is LDS word j: the first 64 symbols (almost every run) are one per lane and
   // are found with one compare and a population count; word 64 tells whether that is enough, word
   // 256 is the running total.  The three words come back from one wait.
+  template <bool CHK = true>
   __device__ __forceinline__ int fixed_n(int t) {
     wave_fence();
     const u32 v = x & (kProbScale - 1), lim = (v + 1) << 16;  // cum <= v  <=>  (freq | cum << 16) < lim
@@ -739,10 +746,11 @@ struct WaveDec : WaveModel {
       if (lane == 0) tab[256] = (u32)ns;
       wave_fence();
     }
-    count();
+    count<CHK>();
     return sym;
   }
   // Pixel type after a pixel of type t: all six tables are searched by the same compare
+  template <bool CHK = true>
   __device__ __forceinline__ int fixed_p(int t) {
     const u32 v = x & (kProbScale - 1), lim = (v + 1) << 16;
     const u64 m = __ballot(pfc < lim);
@@ -765,7 +773,7 @@ struct WaveDec : WaveModel {
       }
       if (lane == tl) pcnt = (u32)nt;
     }
-    count();
+    count<CHK>();
     return j;
   }
 
@@ -884,6 +892,7 @@ struct WaveDec : WaveModel {
     }
   }
   // decodeC (screencap.h:318-333)
+  template <bool CHK = true>
   __device__ __forceinline__ int colour(int ctxid) {
     ColHdr h;
     u32 w, ra, ea, h0, hz;
@@ -929,7 +938,7 @@ struct WaveDec : WaveModel {
       }
     }
     wave_fence();
-    count();
+    count<CHK>();
     return c;
   }
 };
@@ -1002,9 +1011,15 @@ __device__ __forceinline__ void decode_intra_frame(DEC& D, const Geom& g, u8* __
   const u32 slow_types = pad ? 0x38u : 0x18u;  // bit t: not one of the plain fills below (3 does not exist, 4 gradient, 5 when rows are padded)
   int lim = W + 1;     // where the runs of the current phase must end: the header phase covers pixels 0..W
   int rowend = W + 1;  // the row being decoded ends here (first row: with the header phase, one pixel later)
-  while (SCPR_LIKELY(p < NP)) {
+  int fastend = 0;     // (set with rowend when the header phase is over)
+  // One run: its type (after the header phase), the pixel of a literal, its length, its pixels.  Two instances:
+  // the careful one does everything (header phase, coder block ends), the fast one is entered only where neither
+  // can occur and leaves the per-symbol block-end test out (a test and a branch per symbol is ~20 cycles).
+  auto run = [&](auto fast_tag) __attribute__((always_inline)) {
+    constexpr bool FAST = decltype(fast_tag)::value;
     D.template stamp<4>();
-    if (SCPR_LIKELY(lim == NP)) t = D.fixed_p(t);
+    if constexpr (FAST) t = D.template fixed_p<false>(t);
+    else if (lim == NP) t = D.fixed_p(t);
     D.template stamp<0>();
     u32 px = lastpix;
     if (t == 0) {  // DecodeRGB, screencap.cpp:662-679: contexts are the two previous bytes >> 2 (MAKECX1, screencap.h:35-36)
@@ -1012,14 +1027,22 @@ __device__ __forceinline__ void decode_intra_frame(DEC& D, const Geom& g, u8* __
       px = 0;
 #pragma unroll
       for (int plane = 0; plane < 3; plane++) {
-        const u32 c = (u32)D.colour(plane * 4096 + (int)(a | (b << 6)));
+        u32 c;
+        if constexpr (FAST) c = (u32)D.template colour<false>(plane * 4096 + (int)(a | (b << 6)));
+        else c = (u32)D.colour(plane * 4096 + (int)(a | (b << 6)));
         px |= c << (8 * plane);
         b = a;
         a = c >> 2;
       }
       D.template stamp<1>();
     }
-    const int n = D.fixed_n(t);
+    int n;
+    if constexpr (FAST) {
+      n = D.template fixed_n<false>(t);
+      D.ndec += t == 0 ? 5 : 2;  // the symbols of this run (type, three colour bytes of a literal, length)
+    } else {
+      n = D.fixed_n(t);
+    }
     D.template stamp<2>();
     // an empty run, or one longer than what is left (of the header row), ends the frame like the type that does not exist
     const int tt = SCPR_UNLIKELY((u32)(n - 1) >= (u32)(lim - p)) ? 3 : t;
@@ -1088,12 +1111,26 @@ __device__ __forceinline__ void decode_intra_frame(DEC& D, const Geom& g, u8* __
     }
     D.template stamp<3>();
     p += n;
+  };
+  auto row_end = [&]() __attribute__((always_inline)) {
     if (SCPR_UNLIKELY(p >= rowend)) {  // a row is complete (the first time: the header phase is over as well)
       lim = NP;
       int done = flushed + 1;
       while ((done + 1) * W <= p) done++;
       flush_rows(done);
       rowend = rowbase + W;
+      fastend = min(rowend, NP);  // the fast runs below go on while p < fastend: to the end of the row, never past the frame
+    }
+  };
+  while (SCPR_LIKELY(p < NP)) {
+    run(std::false_type{});
+    row_end();
+    if constexpr (DEC::kFastRuns) {
+      if (SCPR_LIKELY(lim == NP)) {
+        // as long as the row goes on and the coder block does not end within the next run (both differences negative)
+        while (SCPR_LIKELY((int)((u32)(p - fastend) & (u32)(D.ndec - (kBlockEntries - 5))) < 0)) run(std::true_type{});
+        row_end();
+      }
     }
   }
   if (!D.bad) flush_rows(H);
