@@ -1047,32 +1047,34 @@ __device__ __forceinline__ void decode_intra_frame(DEC& D, const Geom& g, u8* __
     // an empty run, or one longer than what is left (of the header row), ends the frame like the type that does not exist
     const int tt = SCPR_UNLIKELY((u32)(n - 1) >= (u32)(lim - p)) ? 3 : t;
     const int nf = ((slow_types >> tt) & 1u) ? 0 : n;  // pixels of the run for the common path below
-    {
-      // literal / copy of the previous pixel (0, 1): every pixel of the run has the same value;
-      // copy of the pixel above (2) or above-left (5): read one row back in the ring.
-      // Almost every run fits one pass of the wave; the rest goes round the loop.  (The other types take
-      // this path with an empty run and are handled below: a plain if costs the common case nothing.)
-      const u32 back = (u32)W + (u32)(t >> 2);
-      u32 v = px;
-      int m = min(chunk, nf);
-      u32 pq = (u32)(p + lane);
-      wave_fence();  // pixels written by other lanes are read here
-      if (t >= 2) v = ring[(pq - back) & pm];
-      if (lane < m) ring[pq & pm] = v;
-      if (SCPR_UNLIKELY(nf > chunk)) {
+    // literal / copy of the previous pixel (0, 1): every pixel of the run has the same value;
+    // copy of the pixel above (2) or above-left (5): read one row back in the ring.
+    // Almost every run fits one pass of the wave.  All 64 lanes store: the lanes past the end of the run scribble
+    // on pixels that are not decoded yet (the ring is W + 512 pixels or more: 64 pixels ahead of the run alias
+    // pixels more than a row and 448 pixels back, older than anything still read), which spares the lane mask.
+    // (The other types take this path with an empty run and are handled below.)
+    const u32 back = (u32)W + (u32)(t >> 2);
+    u32 v = px;
+    int m = min(chunk, nf);
+    u32 pq = (u32)(p + lane);
+    wave_fence();  // pixels written by other lanes are read here
+    if (t >= 2) v = ring[(pq - back) & pm];
+    ring[pq & pm] = v;
+    wave_fence();
+    lastpix = rdl(v, m - 1);
+    if (SCPR_UNLIKELY((u32)(nf - 1) >= (u32)chunk)) {  // a long run, or one of the rare types
+     if (nf > 0) {
 #pragma nounroll
-        for (int q0 = chunk; q0 < nf; q0 += chunk) {
-          wave_fence();  // a run may be longer than a row
-          m = min(chunk, nf - q0);
-          pq = (u32)(p + q0 + lane);
-          if (t >= 2) v = ring[(pq - back) & pm];
-          if (lane < m) ring[pq & pm] = v;
-        }
+      for (int q0 = chunk; q0 < nf; q0 += chunk) {
+        wave_fence();  // a run may be longer than a row
+        m = min(chunk, nf - q0);
+        pq = (u32)(p + q0 + lane);
+        if (t >= 2) v = ring[(pq - back) & pm];
+        ring[pq & pm] = v;
       }
       wave_fence();
       lastpix = rdl(v, m - 1);
-    }
-    if (SCPR_UNLIKELY(nf == 0)) {
+     } else
      if (tt == 3) {  // the frame is refused, the loop ends here
       D.bad = true;
       p = NP - n;
