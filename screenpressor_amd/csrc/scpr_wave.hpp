@@ -1288,30 +1288,35 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
     }
     wave_fence();
     int x = x1, y = y1, pt = 0;
-    while (y < y2 && !D.bad) {
-      D.tick();
+    const int lc = min(lane, 15);
+    // One run of the rect, in two instances like the key-frame loop: the careful one tests for the end of the coder
+    // block after every symbol, the fast one is entered while the block cannot end within a run and counts the
+    // run's symbols in one go.  A refused stream ends the rect (y = y2) instead of leaving the loops from inside.
+    auto prun = [&](auto fast_tag) __attribute__((always_inline)) {
+      constexpr bool FAST = decltype(fast_tag)::value;
       const int last_t = pt;
-      pt = D.fixed_p(last_t);
+      pt = D.template fixed_p<!FAST>(last_t);
       u32 px = lastpix;
       if (pt == 0) {
         u32 a = (lastpix >> 18) & 63, bb = (lastpix >> 10) & 63;
         px = 0;
 #pragma unroll 1
         for (int plane = 0; plane < 3; plane++) {
-          const u32 c = (u32)D.colour(plane * 4096 + (int)(a | (bb << 6)));
+          const u32 c = (u32)D.template colour<!FAST>(plane * 4096 + (int)(a | (bb << 6)));
           px |= c << (8 * plane);
           bb = a;
           a = c >> 2;
         }
       }
-      D.tick();
-      int rem = D.fixed_n(pt);
+      int rem = D.template fixed_n<!FAST>(pt);
+      if (FAST) D.ndec += pt == 0 ? 5 : 2;
       if (SCPR_UNLIKELY(rem < 1)) {
         D.bad = true;
-        break;
+        rem = 0;
+        y = y2;
       }
       while (rem > 0) {
-        if (SCPR_UNLIKELY(y >= y2)) {
+        if (SCPR_UNLIKELY(y >= y2)) {  // the run goes on below the rect
           D.bad = true;
           break;
         }
@@ -1320,28 +1325,33 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
         const bool act = lane < seg;
         const int tx = tx0 + lane;
         wave_fence();
+        // literal (0): px.  Copies inside the tile - of the previous pixel (1: one word for every lane), of the pixel
+        // above (2) or above-left (5) - are one read at an index built from the type (every lane reads: the lanes past
+        // the segment stay inside the tile's rows through lc).  The copy from the previous frame (3) and the gradient
+        // (4) are rare and replace the result.
         u32 v = px;
-        if (pt == 1) {
-          v = tile[ty * 17 + tx0 - 1];
-        } else if (pt == 2) {
-          if (act) v = tile[(ty - 1) * 17 + tx];
-        } else if (pt == 3) {
-          if (act) v = ld3(prv + (size_t)y * S + (x + lane) * 3);
-        } else if (pt == 5) {
-          if (act) v = tile[(ty - 1) * 17 + tx - 1];
-        } else if (pt == 4) {
-          u32 tp = 0, tl = 0;
-          if (act) {
-            tp = tile[(ty - 1) * 17 + tx];
-            tl = tile[(ty - 1) * 17 + tx - 1];
+        if (pt != 0) {
+          const int srow = pt == 1 ? ty : ty - 1, scol = tx0 - (pt == 2 ? 0 : 1);
+          v = tile[srow * 17 + scol + (pt == 1 ? 0 : lc)];
+        }
+        if (SCPR_UNLIKELY((0x18u >> pt) & 1u)) {
+          if (pt == 3) {
+            v = px;
+            if (act) v = ld3(prv + (size_t)y * S + (x + lane) * 3);
+          } else {
+            u32 tp = 0, tl = 0;
+            if (act) {
+              tp = tile[(ty - 1) * 17 + tx];
+              tl = tile[(ty - 1) * 17 + tx - 1];
+            }
+            const u32 base = tile[ty * 17 + tx0 - 1];
+            int d0 = (int)(tp & 255) - (int)(tl & 255), d1 = (int)((tp >> 8) & 255) - (int)((tl >> 8) & 255), d2 = (int)((tp >> 16) & 255) - (int)((tl >> 16) & 255);
+            if (!act) d0 = d1 = d2 = 0;
+            d0 = row_incl_scan(d0);
+            d1 = row_incl_scan(d1);
+            d2 = row_incl_scan(d2);
+            v = (u32)(((int)(base & 255) + d0) & 255) | ((u32)(((int)((base >> 8) & 255) + d1) & 255) << 8) | ((u32)(((int)((base >> 16) & 255) + d2) & 255) << 16);
           }
-          const u32 base = tile[ty * 17 + tx0 - 1];
-          int d0 = (int)(tp & 255) - (int)(tl & 255), d1 = (int)((tp >> 8) & 255) - (int)((tl >> 8) & 255), d2 = (int)((tp >> 16) & 255) - (int)((tl >> 16) & 255);
-          if (!act) d0 = d1 = d2 = 0;
-          d0 = row_incl_scan(d0);
-          d1 = row_incl_scan(d1);
-          d2 = row_incl_scan(d2);
-          v = (u32)(((int)(base & 255) + d0) & 255) | ((u32)(((int)((base >> 8) & 255) + d1) & 255) << 8) | ((u32)(((int)((base >> 16) & 255) + d2) & 255) << 16);
         }
         if (act) tile[ty * 17 + tx] = v;
         wave_fence();
@@ -1353,6 +1363,12 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
           y++;
         }
       }
+      if (SCPR_UNLIKELY(D.bad)) y = y2;
+    };
+    while (y < y2) {
+      D.tick();
+      prun(std::false_type{});
+      while (SCPR_LIKELY((int)((u32)(y - y2) & (u32)(D.ndec - (kBlockEntries - 5))) < 0)) prun(std::true_type{});
     }
     wave_fence();
     for (int i = lane; i < w * h; i += 64) {  // the finished rect goes to the plane
