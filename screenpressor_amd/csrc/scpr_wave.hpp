@@ -1146,16 +1146,17 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
   const int lane = D.lane;
   const int W = g.W, H = g.H, S = g.S;
   const int nbx = (W + 15) >> 4, nby = (H + 15) >> 4, nblocks = nbx * nby;
+  D.template stamp<4>();
   __threadfence();  // the previous plane was written by this wave (or by another kernel): make it readable
   {
     const size_t bytes = (size_t)H * S;
     size_t o = (size_t)lane * 16;
-    for (; o + 7 * 1024 + 16 <= bytes; o += 8192) {  // 8 KiB per trip, eight 16-byte loads in flight per lane
-      uint4 v[8];
+    for (; o + 15 * 1024 + 16 <= bytes; o += 16384) {  // 16 KiB per trip, sixteen 16-byte loads in flight per lane
+      uint4 v[16];
 #pragma unroll
-      for (int k = 0; k < 8; k++) v[k] = *(const uint4*)(prv + o + k * 1024);
+      for (int k = 0; k < 16; k++) v[k] = *(const uint4*)(prv + o + k * 1024);
 #pragma unroll
-      for (int k = 0; k < 8; k++) *(uint4*)(cur + o + k * 1024) = v[k];
+      for (int k = 0; k < 16; k++) *(uint4*)(cur + o + k * 1024) = v[k];
     }
     for (; o + 16 <= bytes; o += 1024) *(uint4*)(cur + o) = *(const uint4*)(prv + o);
     for (size_t q = (bytes & ~(size_t)15) + lane; q < bytes; q += 64) cur[q] = prv[q];
@@ -1191,6 +1192,7 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
     b += n;
   }
   wave_fence();
+  D.template stamp<5>();
   u32 lastpix = 0;  // cx = cx1 = 0 (:1317)
   int lastmx = 0, lastmy = 0;
   u32* tile = D.L.tile;
@@ -1277,16 +1279,21 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
     if (njobs) flush_jobs();  // a copied block may be this rect's left/top context
     // pixel-coded rect (:1370-1421): context border from the plane, then runs inside the tile
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores to the plane have reached L2
-    for (int i = lane; i < 17 * 17; i += 64) {
-      const int ty = i / 17, tx = i - ty * 17;
+    {
+      // the 33 border pixels (row above: lanes 0..16, column to the left: lanes 17..32) in ONE round trip to L2 - a
+      // loop over the 289 tile words with the loads inside waits for L2 five times per rect
+      const int ty = lane < 17 ? 0 : lane - 16, tx = lane < 17 ? lane : 0;
       u32 v = 0;
-      if ((ty == 0 || tx == 0) && ty <= h && tx <= w) {
+      if (lane < 33 && ty <= h && tx <= w) {
         const int xq = x1 - 1 + tx, yq = y1 - 1 + ty;
         if (xq >= 0 && yq >= 0) v = ld3_l2(cur + (size_t)yq * S + xq * 3);
       }
-      tile[i] = v;
+      for (int i = lane; i < 17 * 17; i += 64) tile[i] = 0;
+      wave_fence();
+      if (lane < 33) tile[ty * 17 + tx] = v;
     }
     wave_fence();
+    D.template stamp<6>();
     int x = x1, y = y1, pt = 0;
     const int lc = min(lane, 15);
     // One run of the rect, in two instances like the key-frame loop: the careful one tests for the end of the coder
@@ -1370,6 +1377,7 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
       prun(std::false_type{});
       while (SCPR_LIKELY((int)((u32)(y - y2) & (u32)(D.ndec - (kBlockEntries - 5))) < 0)) prun(std::true_type{});
     }
+    D.template stamp<7>();
     wave_fence();
     for (int i = lane; i < w * h; i += 64) {  // the finished rect goes to the plane
       const int yy = i / w, xq = i - yy * w;

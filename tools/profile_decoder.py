@@ -24,7 +24,8 @@ seq = DesktopSequence(W, H, seed=1)
 frames = torch.from_numpy(seq.frames(n)).cuda().reshape(n, -1)
 c = K.ScreenCodec()
 c.Init(W, H, 32)
-pk, sizes, ft = c.CompressBatch(frames, [0] * n)
+IP = "--ip" in sys.argv  # one GOP: a key frame and n-1 P-frames (sections 5-7 of decode_inter_frame)
+pk, sizes, ft = c.CompressBatch(frames, [0] + [1] * (n - 1) if IP else [0] * n)
 L = K.load_library()
 out = (C.c_ulonglong * 8)()
 L.scpr_debug_profile(out)
@@ -33,9 +34,9 @@ torch.cuda.synchronize()
 assert torch.equal(dec.reshape(-1), frames.reshape(-1))
 L.scpr_debug_profile(out)
 v = np.array(list(out), dtype=np.float64)
-names = ["P", "colour", "N", "fill", "rows/loop", "-", "-", "-"]
+names = ["P", "colour", "N", "fill", "rows/loop", "P-frame: plane copy, header, block types", "P-frame: rect border + write-back, motion copies", "P-frame: runs"]
 tot = v.sum()
 print("ticks per frame: %.0f" % (tot / n))
 for nm, x in zip(names, v):
     if x:
-        print("%-10s %5.1f %%   %.0f ticks/frame" % (nm, 100 * x / tot, x / n))
+        print("%-50s %5.1f %%   %.0f ticks/frame" % (nm, 100 * x / tot, x / n))
