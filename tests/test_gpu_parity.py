@@ -294,6 +294,30 @@ def test_random_call_patterns_keep_cross_call_state(seed, w, h):
         i = j
 
 
+@pytest.mark.parametrize("w,h", [(96, 64), (64, 48), (200, 120), (33, 50), (640, 360)])
+def test_key_frame_decode_stays_inside_its_plane(w, h):
+    """Each frame of a batch is decoded into its own plane, planes back to back.  A key frame followed by a flat
+    frame (whose plane nothing but a fill writes): a decoder that flushes one row too many at the end of the key
+    frame shows up as a wrong first row of the flat one.  (Found by the random-call-pattern test; kept as a direct
+    case: it came from the end-of-frame handling of the run loop.)"""
+    import torch
+    seq = DesktopSequence(w, h, seed=5, sparkles=20)
+    flat = np.zeros((h, w, 4), np.uint8)
+    flat[..., :3] = (10, 200, 30)
+    flat[..., 3] = 255
+    frames = [seq.frame(0), flat, seq.frame(1), flat, flat, seq.frame(2)]
+    ora = O.OracleCodec(w, h, 32)
+    ref = [ora.compress(f, key=True) for f in frames]
+    gd = _codec(w, h)
+    blob = b"".join(p for p, _ in ref)
+    dev = torch.from_numpy(np.frombuffer(blob, np.uint8).copy()).cuda()
+    r, out = gd.DecompressBatch(dev, [len(p) for p, _ in ref], [ft for _, ft in ref])
+    assert r == len(frames)
+    out = out.cpu().numpy().reshape(len(frames), h, w, 4)
+    for t, f in enumerate(frames):
+        assert np.array_equal(out[t][..., :3], f[..., :3]), t
+
+
 def test_corrupt_streams_are_survived():
     """Damaged packets (flipped bytes, truncation) must come back as an error or as some picture — never a
     fault or a hang — and must not wedge the codec: a clean key frame decodes right afterwards."""
