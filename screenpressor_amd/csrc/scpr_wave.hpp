@@ -288,6 +288,37 @@ struct WaveModel {
     }
   }
 
+  // The decoder's common case of small_op() below with every test behind one branch: the coder value falls on an entry
+  // of the table, and the table is not due for a rescale.  Returns a negative number and has applied the symbol (w,
+  // h.total, h.fmax, h.maxpos updated; c, ofr, ocf set) - or a non-negative one with nothing touched: small_op() then
+  // does the symbol from scratch.  (A branch costs a lone wave ~12 cycles even when it is not taken: three sign bits
+  // and-ed together are cheaper than three tests.)
+  __device__ __forceinline__ int small_hit(ColHdr& h, u32& w, int in, int& c, u32& ofr, u32& ocf) {
+    const int d = h.d, tot = h.total;
+    const int sh = __builtin_clz((u32)(tot - 1)) - 20, bonus = (kProbScale - (tot << sh)) >> sh;
+    const int vv = in >> sh;
+    const int st = (int)sm_sym(w) + (int)sm_p(w) + (l15 > h.maxpos ? bonus : 0) - l15;
+    const u32 m = (u32)__ballot(st <= vv) & 0xFFFFu;
+    const int p = 31 - (m ? __builtin_clz(m) : 32);  // -1: below the first entry
+    const u32 wp = rdl(w, p);
+    const int sp = (int)sm_sym(wp), fpr = (int)sm_fq(wp);
+    const int ap = sp + (int)sm_p(wp) - p + (p > h.maxpos ? bonus : 0);
+    const int endp = ap + fpr + (p == h.maxpos ? bonus : 0);
+    // each negative when fine: the value is inside entry p, no rescale after this symbol, there is an entry p
+    const int t = (vv - endp) & (tot + 2 * kStepSmall - kProbScale - 1) & ~p;
+    if (SCPR_LIKELY(t < 0)) {
+      ofr = (u32)(endp - ap) << sh;
+      ocf = (u32)ap << sh;
+      w += l15 == p ? (u32)kStepSmall << 8 : ((u32)(l15 - p - 1) < (u32)(d - p - 1) ? (u32)kStepSmall << 20 : 0u);
+      h.total = tot + kStepSmall;
+      if (fpr + kStepSmall > h.fmax) {
+        h.maxpos = p;
+        h.fmax = fpr + kStepSmall;
+      }
+      c = sp;
+    }
+    return t;
+  }
   // kinds 4/5: SmallContext::decode / ::encode (ans_contexts.h:195-283), on the packed table w.
   // DEC: `in` is the coder value (state & 4095), the symbol is returned; else `in` is the symbol.
   // Both directions come down to the lane p of the last entry at or below the input (by interval
@@ -905,7 +936,9 @@ struct WaveDec : WaveModel {
     const u32 v = x & (kProbScale - 1);
     int small0 = (int)h0;  // sign bit: a small table (kind 4 or 5)
     if (SCPR_LIKELY(small0 < 0)) {
-      c = small_op<true>(r, h, w, (int)v, fr, cf);
+      int t = small_hit(h, w, (int)v, c, fr, cf);
+      asm volatile("" : "+s"(t));  // (keeps the test inside small_hit and this one apart)
+      if (SCPR_UNLIKELY(t >= 0)) c = small_op<true>(r, h, w, (int)v, fr, cf);
       wave_fence();
       // the entries go back from every row of 16 lanes alike: no lane mask (a full table has just become a dense
       // one: then w holds what is there already)
