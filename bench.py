@@ -149,7 +149,7 @@ def main():
                     "algorithmic_bytes_per_launch": alg_bytes,
                     "note": "the dominant kernel is a serial per-GOP chain (issue-bound), not bandwidth-shaped; see DESIGN.md §5"}
         cpu = None
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:  # the CPU baseline is a rank-0, one-GPU measurement
             import oracle_api as O
             nf = min(args.cpu_frames, N)
             sample = np.stack([np.ascontiguousarray(seq.frame(t) if BPP == 32 else pack24(seq.frame24(t))).reshape(-1) for t in range(nf)])
