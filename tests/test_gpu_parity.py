@@ -189,6 +189,32 @@ def test_p_frames_batch_api_1080p():
     assert torch.equal(torch.cat([o1, o2]).reshape(n, -1), d)
 
 
+def test_p_frame_with_several_coder_blocks():
+    """A P-frame that replaces the whole picture (different content, nothing to copy) has far more than 131072
+    coder entries: its pixel-coded rects run across several coder-block ends, where the decoder's rect runs switch
+    between their fast instance (no per-symbol block test) and the careful one.  Encode and decode against the oracle."""
+    import torch
+    w, h = 1920, 1080
+    a = DesktopSequence(w, h, seed=3).frame(0)
+    b = DesktopSequence(w, h, seed=9, sparkles=4000).frame(5)[::-1].copy()  # unrelated content, upside down
+    frames = [a, b, a]
+    ora = O.OracleCodec(w, h, 32)
+    ref = [ora.compress(f, key=(t == 0)) for t, f in enumerate(frames)]
+    assert ref[1][1] == 1 and len(ref[1][0]) > 60000  # a P-frame, and a big one
+    gpu = _codec(w, h)
+    dev = torch.from_numpy(np.stack(frames)).cuda().reshape(3, -1)
+    pk, sizes, fts = gpu.CompressBatch(dev, [0, 1, 1])
+    pk = pk.cpu().numpy()
+    o = 0
+    for t, s_ in enumerate(sizes):
+        g = pk[o:o + int(s_)].tobytes()
+        o += int(s_)
+        assert g == ref[t][0], (t, _first_diff(g, ref[t][0]))
+    dec = _codec(w, h)
+    r, out = dec.DecompressBatch(torch.from_numpy(pk[:o].copy()).cuda(), [int(x) for x in sizes], list(fts))
+    assert r == 3 and torch.equal(out.reshape(3, -1), dev)
+
+
 def test_4k_key_and_p_frames():
     """BASELINE configs[3] frame size: 3840x2160 (32400 blocks, 32 KiB pixel ring in the decoder)"""
     w, h = 3840, 2160
