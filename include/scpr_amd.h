@@ -58,7 +58,10 @@ void scpr_deinit(scpr_codec* c);
 void scpr_crash_happened(scpr_codec* c);
 
 /* ScreenCodec::CompressFrame (screencap.cpp:1632-1692).  Host pointers.
- * src: RGB32 rows of width*4 bytes, or RGB24/RGB16 rows padded to 4 bytes.
+ * src: RGB32 rows of width*4 bytes; RGB24 rows padded to 4 bytes; RGB16 rows of
+ *      width*2 bytes back to back (the reference indexes them `y*X*2`,
+ *      screencap.cpp:1668 - NOT DWORD-aligned, which only differs for odd widths;
+ *      the decompress side writes RGB16 rows at the caller's `pitch`, :1726-1734).
  * *ftype in: 0 = key frame wanted, 1 = P allowed; out: type produced.
  * Returns the compressed size, 0 when refused (crashed), < 0 on error. */
 int scpr_compress_frame(scpr_codec* c, const void* src, void* dst, int dst_len, int* ftype, int loss);
@@ -80,11 +83,25 @@ int scpr_decompress_frame(scpr_codec* c, const void* src, int src_len, void* dst
 int64_t scpr_compress_batch(scpr_codec* c, const void* d_frames, int nframes, int* ftypes, int loss,
                             void* d_out, size_t out_capacity, uint32_t* sizes);
 
-/* d_packets: the packets back to back in device memory; sizes/ftypes: host
+/* d_packets: the packets back to back in device memory (exactly sum(sizes)
+ * bytes: the decoder touches no address past the aligned 4-byte word that holds
+ * the last byte, so no slack is needed behind the buffer); sizes/ftypes: host
  * arrays.  d_frames_out: nframes frames of `pitch`-byte rows in device
  * memory.  Returns the number of frames decoded, or < 0. */
 int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* sizes, const int* ftypes,
                           int nframes, void* d_frames_out, int pitch);
+
+/* ---- sharding support (an addition) ----------------------------------------
+ * GOPs are independent except for what CScreenCapt keeps ACROSS key frames:
+ * `fn > 0` (a frame has been coded: P-frames are allowed, screencap.cpp:1504)
+ * and the flat-frame memory last_was_flat / last_flat_clr with `prev` holding
+ * that flat picture (:1490-1497).  Call after scpr_init on the codec of a shard
+ * that does not start the stream: frames_before = frames coded before the
+ * shard's first frame, last_was_flat / last_flat_rgb (b0 | b1<<8 | b2<<16 of the
+ * RGB24 pixel) = whether the frame just before the shard was a flat one.  The
+ * motion-vector memory mvs[] (:96-97, never reset) is NOT reproduced: P-frames
+ * of a shard equal the reference run on that shard's frames. */
+int scpr_seed_shard(scpr_codec* c, uint32_t frames_before, int last_was_flat, uint32_t last_flat_rgb);
 
 /* ---- instrumentation ------------------------------------------------------ */
 /* Kernel time of the last batch call, measured with HIP events on the codec's
@@ -98,6 +115,10 @@ const char* scpr_stage_name(int stage);
  * entries ({freq, cum} uint16 pairs, stream order, all frames of the batch)
  * to host memory; returns the entry count. */
 int64_t scpr_debug_entries(scpr_codec* c, uint16_t* out, int64_t cap);
+
+/* Debug tap (tests only): bytes currently allocated for the dense-table arenas of
+ * the compress side and of the decompress side. */
+int scpr_debug_arena(scpr_codec* c, uint64_t* enc_bytes, uint64_t* dec_bytes);
 
 /* Test hook: runs ONE colour context over `n` symbols through the wave-per-chain
  * encoder kernel and returns the coder entries ({freq, cum} pairs; freq 0 = raw). */

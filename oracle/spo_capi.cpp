@@ -45,6 +45,11 @@ int spo_decompress_frame(void* h, const uint8_t* src, int src_len, uint8_t* dst,
   return ((ScreenCodec*)h)->decompress_frame(src, src_len, dst, pitch, ftype);
 }
 void spo_crash_happened(void* h) { ((ScreenCodec*)h)->crash_happened(); }
+void spo_set_threads(void* h, int n) { ((ScreenCodec*)h)->set_threads(n); }
+void spo_seed_shard(void* h, uint32_t frames_before, int last_flat, uint32_t rgb) {
+  const uint8_t c[3] = {(uint8_t)rgb, (uint8_t)(rgb >> 8), (uint8_t)(rgb >> 16)};
+  ((ScreenCodec*)h)->seed_shard(frames_before, last_flat != 0, c);
+}
 
 // ---- taps on the last compressed frame -------------------------------------
 int spo_tap_entries(void* h, uint16_t* out, int cap_entries) {
@@ -167,15 +172,29 @@ int spo_rans_block(const uint16_t* entries, int n, uint8_t* out) {
 // Encodes then decodes `nframes` frames (RGB32 or RGB24, back to back in
 // `frames`), returns seconds spent in each leg and the total compressed bytes.
 // key_interval: 1 = every frame is a key frame; K = key frame every K frames.
+uint64_t spo_fnv1a(const uint8_t* p, uint64_t n) {
+  uint64_t h = 1469598103934665603ull;
+  for (uint64_t i = 0; i < n; i++) h = (h ^ p[i]) * 1099511628211ull;
+  return h;
+}
+// threads: 1 = everything on the calling thread; > 1 = the reference's shape (band pool of `threads` for key frames
+// + one coder thread).  frame_sizes / frame_fnv (optional, nframes entries): size and FNV-1a of every packet.
+int spo_time_stream2(const spo_params* p, uint8_t* frames, int nframes, int key_interval, int threads, double* t_enc, double* t_dec,
+                     uint64_t* out_bytes, uint64_t* fnv, uint32_t* frame_sizes, uint64_t* frame_fnv);
 int spo_time_stream(const spo_params* p, uint8_t* frames, int nframes, int key_interval, double* t_enc, double* t_dec,
                     uint64_t* out_bytes, uint64_t* fnv) {
+  return spo_time_stream2(p, frames, nframes, key_interval, 1, t_enc, t_dec, out_bytes, fnv, nullptr, nullptr);
+}
+int spo_time_stream2(const spo_params* p, uint8_t* frames, int nframes, int key_interval, int threads, double* t_enc, double* t_dec,
+                     uint64_t* out_bytes, uint64_t* fnv, uint32_t* frame_sizes, uint64_t* frame_fnv) {
   size_t pitch = ((size_t)p->width * (p->bits_per_pixel / 8) + 3) & ~(size_t)3;
   if (p->bits_per_pixel == 32) pitch = (size_t)p->width * 4;
-  size_t fsz = pitch * p->height;
+  size_t fsz = (p->bits_per_pixel == 16 ? (size_t)p->width * 2 : pitch) * p->height;  // RGB16 input rows back to back (screencap.cpp:1668)
   std::vector<std::vector<uint8_t>> packets(nframes);
   std::vector<int> types(nframes);
   std::vector<uint8_t> dst((size_t)p->width * p->height * 6 + 64);
   void* enc = spo_create(p);
+  spo_set_threads(enc, threads);
   auto t0 = std::chrono::steady_clock::now();
   uint64_t total = 0, hsh = 1469598103934665603ull;
   for (int i = 0; i < nframes; i++) {
@@ -188,8 +207,11 @@ int spo_time_stream(const spo_params* p, uint8_t* frames, int nframes, int key_i
   }
   auto t1 = std::chrono::steady_clock::now();
   spo_destroy(enc);
-  for (int i = 0; i < nframes; i++)
+  for (int i = 0; i < nframes; i++) {
     for (uint8_t b : packets[i]) hsh = (hsh ^ b) * 1099511628211ull;
+    if (frame_sizes) frame_sizes[i] = (uint32_t)packets[i].size();
+    if (frame_fnv) frame_fnv[i] = spo_fnv1a(packets[i].data(), packets[i].size());
+  }
   void* dec = spo_create(p);
   std::vector<uint8_t> outf(fsz);
   int bad = 0;

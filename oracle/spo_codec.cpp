@@ -4,6 +4,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <thread>
 
 namespace spo {
 
@@ -320,31 +321,42 @@ void FrameCodec::put_pixel(int t, int last_t, const uint8_t* px) {  // WritePixe
 }
 
 // RansMTCoder::writeBlock per 131072 entries, ransmt.h:116-134
-uint8_t* FrameCodec::flush_entries(uint8_t* dst) {
-  static thread_local std::vector<uint8_t> tmp;
-  tmp.resize((size_t)kBlockEntries * 2 + 8);
-  size_t n = out_.size();
-  for (size_t b0 = 0; b0 < n; b0 += kBlockEntries) {
-    size_t len = std::min<size_t>(kBlockEntries, n - b0);
-    const Ivl* e = &out_[b0];
-    uint32_t x = kRansL;
-    uint8_t* end = tmp.data() + tmp.size();
-    uint8_t* p = end;
-    for (size_t i = len; i-- > 0;) {
-      if (e[i].freq)
-        RansEnc::put(x, p, e[i].cum, e[i].freq);
-      else
-        *--p = (uint8_t)e[i].cum;
-    }
-    p -= 4;  // RansEncFlush, rans_byte.h:90-102
-    p[0] = (uint8_t)x;
-    p[1] = (uint8_t)(x >> 8);
-    p[2] = (uint8_t)(x >> 16);
-    p[3] = (uint8_t)(x >> 24);
-    size_t sz = (size_t)(end - p);
-    memcpy(dst, p, sz);
-    dst += sz;
+std::vector<uint8_t> FrameCodec::encode_block(const Ivl* e, size_t len) {
+  std::vector<uint8_t> tmp((size_t)kBlockEntries * 2 + 8);
+  uint32_t x = kRansL;
+  uint8_t* end = tmp.data() + tmp.size();
+  uint8_t* p = end;
+  for (size_t i = len; i-- > 0;) {
+    if (e[i].freq)
+      RansEnc::put(x, p, e[i].cum, e[i].freq);
+    else
+      *--p = (uint8_t)e[i].cum;
   }
+  p -= 4;  // RansEncFlush, rans_byte.h:90-102
+  p[0] = (uint8_t)x;
+  p[1] = (uint8_t)(x >> 8);
+  p[2] = (uint8_t)(x >> 16);
+  p[3] = (uint8_t)(x >> 24);
+  return std::vector<uint8_t>(p, end);
+}
+
+void FrameCodec::submit_block() {  // the block that has just filled up goes to the coder thread (one at a time, like the reference's single worker)
+  if (!block_jobs_.empty()) block_jobs_.back().wait();
+  std::vector<Ivl> blk(out_.end() - kBlockEntries, out_.end());
+  block_jobs_.push_back(std::async(std::launch::async, [b = std::move(blk)]() { return encode_block(b.data(), b.size()); }));
+}
+
+uint8_t* FrameCodec::flush_entries(uint8_t* dst) {
+  const size_t n = out_.size();
+  size_t bi = 0;
+  for (size_t b0 = 0; b0 < n; b0 += kBlockEntries, bi++) {
+    const size_t len = std::min<size_t>(kBlockEntries, n - b0);
+    // full blocks handed over on the way come back from the coder thread; the tail is coded here (RansMTCoder::finish, ransmt.h:83-90)
+    const std::vector<uint8_t> chunk = bi < block_jobs_.size() ? block_jobs_[bi].get() : encode_block(&out_[b0], len);
+    memcpy(dst, chunk.data(), chunk.size());
+    dst += chunk.size();
+  }
+  block_jobs_.clear();
   last_entries = out_;
   last_tags = tags_;
   return dst;
@@ -430,10 +442,24 @@ void FrameCodec::classify_intra(int worker, int y0, int ysize, const uint8_t* sr
 int FrameCodec::encode_intra(uint8_t* src, uint8_t* dst) {  // CompressI, :319-403
   apply_loss(src);
   cx_ = cx1_ = 0;
-  for (int k = 0; k < workers_; k++) {
-    int y0 = 0, ys = 1;
-    segment(H, k, workers_, y0, ys);
-    classify_intra(k, y0, ys, src);
+  if (threads_ > 1 && workers_ > 1) {  // CMD_CLASSIFYPIXELSI on the pool (:334, squad.cpp:116-130): bands are independent
+    const int nt = std::min(threads_, workers_);
+    std::vector<std::thread> pool;
+    for (int q = 0; q < nt; q++)
+      pool.emplace_back([&, q]() {
+        for (int k = q; k < workers_; k += nt) {
+          int y0 = 0, ys = 1;
+          segment(H, k, workers_, y0, ys);
+          classify_intra(k, y0, ys, src);
+        }
+      });
+    for (std::thread& t : pool) t.join();
+  } else {
+    for (int k = 0; k < workers_; k++) {
+      int y0 = 0, ys = 1;
+      segment(H, k, workers_, y0, ys);
+      classify_intra(k, y0, ys, src);
+    }
   }
   out_.clear();
   tags_.clear();
@@ -785,6 +811,20 @@ int FrameCodec::encode_inter(uint8_t* src, uint8_t* dst0) {  // CompressP, :1091
   return (int)(end - dst0);
 }
 
+void FrameCodec::seed_shard(uint32_t frames_before, bool last_flat, const uint8_t rgb[3]) {
+  frames_ = frames_before;
+  last_flat_ = last_flat;
+  if (last_flat) {  // the state the flat frame left behind (:1490-1494): prev := that picture, models renewed
+    memcpy(last_flat_rgb_, rgb, 3);
+    for (int y = 0; y < H; y++) {
+      uint8_t* row = prev_.data() + (size_t)y * stride_;
+      for (int x = 0; x < W; x++) memcpy(row + 3 * x, rgb, 3);
+      memset(row + 3 * W, 0, (size_t)stride_ - 3 * W);
+    }
+    reset_models();
+  }
+}
+
 int FrameCodec::compress(uint8_t* src, uint8_t* dst, int /*dst_len*/, int& ftype) {  // :1456-1518
   if (is_flat(src)) {
     ftype = 0;
@@ -1093,6 +1133,7 @@ void ScreenCodec::create(int version) {  // CreateCodec, :1587-1617
   const uint32_t stride24 = (W * 3 + 3) & ~3u;
   if (rgb32_ || rgb16_) buf_.assign((size_t)stride24 * H, 0);
   fc_ = new FrameCodec(p_, version);
+  fc_->set_threads(threads_);
 }
 
 void ScreenCodec::deinit() {  // :1619-1629

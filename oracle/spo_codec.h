@@ -7,6 +7,7 @@
 // /root/reference.
 #pragma once
 #include <stdint.h>
+#include <future>
 #include <vector>
 #include "spo_model.h"
 
@@ -102,6 +103,11 @@ class FrameCodec {  // CScreenCapt<UseANS>
   int compress(uint8_t* src, uint8_t* dst, int dst_len, int& ftype);
   int decompress(const uint8_t* src, int src_len, uint8_t* dst, int ftype);
   void set_loss(int loss);
+  void set_threads(int n) { threads_ = n < 1 ? 1 : n; }
+  // Sharding support (not in the reference): the cross-GOP state a single stream would have where a shard starts -
+  // whether a frame has been coded before (fn > 0, screencap.cpp:1504) and the flat-frame memory (last_was_flat /
+  // last_flat_clr, :1490-1497, with prev holding that flat picture).
+  void seed_shard(uint32_t frames_before, bool last_flat, const uint8_t rgb[3]);
 
   // debugging taps (stage-level known-answer tests)
   std::vector<Ivl> last_entries;     // every coder entry of the last compressed frame
@@ -131,7 +137,15 @@ class FrameCodec {  // CScreenCapt<UseANS>
   void put(Ivl e, int tag) {
     out_.push_back(e);
     tags_.push_back((uint16_t)tag);
+    if (threads_ > 1 && (out_.size() & (size_t)(kBlockEntries - 1)) == 0) submit_block();  // RansMTCoder::put, ransmt.h:73-81
   }
+  // The reference's two-stage shape for the CPU baseline (same bytes as the serial form): the row bands of a key
+  // frame classified by a pool of threads (CSquad::RunParallel, squad.cpp:116-130) and ONE coder thread that takes
+  // every full block of 131072 entries while the model thread goes on (RansMTCoder::threadProc, ransmt.h:92-105).
+  int threads_ = 1;
+  std::vector<std::future<std::vector<uint8_t>>> block_jobs_;
+  void submit_block();
+  static std::vector<uint8_t> encode_block(const Ivl* e, size_t len);
   void put_sym(FixedModel& m, int sym, int tag);  // encodeF / the EncodeVal family of version 2
   void reset_models();
   RangeCoderV2 rc_;
@@ -178,6 +192,14 @@ class ScreenCodec {  // screencap.h:519-541, screencap.cpp:1560-1743
   int compress_frame(uint8_t* src, uint8_t* dst, int dst_len, int* ftype, int loss);
   int decompress_frame(const uint8_t* src, int src_len, uint8_t* dst, int pitch, int ftype);
   void crash_happened() { crashed_ = true; }
+  void set_threads(int n) {
+    threads_ = n;
+    if (fc_) fc_->set_threads(n);
+  }
+  void seed_shard(uint32_t frames_before, bool last_flat, const uint8_t rgb[3]) {
+    if (!fc_) create(p_.version == 3 ? 3 : p_.version == 2 ? 2 : 4);
+    fc_->seed_shard(frames_before, last_flat, rgb);
+  }
   FrameCodec* inner() { return fc_; }
 
  private:
@@ -185,6 +207,7 @@ class ScreenCodec {  // screencap.h:519-541, screencap.cpp:1560-1743
   Params p_{};
   FrameCodec* fc_ = nullptr;
   bool rgb32_ = false, rgb16_ = false, crashed_ = false;
+  int threads_ = 1;
   uint32_t W = 0, H = 0, stride_ = 0, bpp_ = 0;
   int rs_ = 0, gs_ = 0, bs_ = 0, last_loss_ = 0;
   std::vector<uint8_t> buf_;

@@ -45,8 +45,8 @@ def build_host_harness() -> str:
     """test infrastructure: the kernels' model header compiled for the host"""
     out = os.path.join(ROOT, "tests", "libhostmodel.so")
     src = os.path.join(ROOT, "tests", "host_model_harness.cpp")
-    if _stale(out, [src, os.path.join(PKG, "csrc", "scpr_model.hpp")]):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I", os.path.join(PKG, "csrc"), "-o", out, src])
+    if _stale(out, [src, os.path.join(ROOT, "tests", "host_model_serial.hpp"), os.path.join(PKG, "csrc", "scpr_model.hpp")]):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I", os.path.join(PKG, "csrc"), "-I", os.path.join(ROOT, "tests"), "-o", out, src])
     return out
 
 

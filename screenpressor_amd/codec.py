@@ -18,7 +18,7 @@ _LIB_PATH = os.environ.get("SCPR_AMD_LIB", os.path.join(_PKG, "libscpr_amd.so"))
 SCPR_OK, SCPR_E_DEVICE, SCPR_E_PARAM, SCPR_E_BAD_VERSION, SCPR_E_CAPACITY, SCPR_E_STREAM = 0, -1, -2, -3, -4, -5
 EXPORTS = ["scpr_create", "scpr_destroy", "scpr_init", "scpr_deinit", "scpr_crash_happened", "scpr_compress_frame",
            "scpr_decompress_frame", "scpr_compress_batch", "scpr_decompress_batch", "scpr_last_timing", "scpr_stage_name",
-           "scpr_debug_entries", "scpr_debug_colour_chain", "scpr_version",
+           "scpr_seed_shard", "scpr_debug_entries", "scpr_debug_arena", "scpr_debug_colour_chain", "scpr_version",
            # include/scpr_driver.h, include/scpr_avi.h
            "scpr_driver_open", "scpr_driver_close", "scpr_driver_configure", "scpr_driver_compress_query", "scpr_driver_compress_get_format",
            "scpr_driver_compress_get_size", "scpr_driver_compress_begin", "scpr_driver_compress_end", "scpr_driver_compress",
@@ -66,6 +66,8 @@ def load_library() -> C.CDLL:
         L.scpr_stage_name.argtypes = [C.c_int]
         L.scpr_debug_entries.restype = C.c_int64
         L.scpr_debug_entries.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        L.scpr_seed_shard.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_uint32]
+        L.scpr_debug_arena.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.scpr_debug_colour_chain.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.scpr_version.restype = C.c_char_p
         _lib = L
@@ -90,13 +92,20 @@ class ScreenCodec:
         if rc != SCPR_OK:
             raise ValueError(f"scpr_init failed: {rc}")
         self.width, self.height, self.bpp, self.loss = width, height, bits_per_pixel, loss
-        self.pitch = width * 4 if bits_per_pixel == 32 else ((width * (bits_per_pixel // 8) + 3) & ~3)
-        self.frame_bytes = self.pitch * height
+        self.pitch = width * 4 if bits_per_pixel == 32 else ((width * (bits_per_pixel // 8) + 3) & ~3)  # decode side: DIB rows
+        # compress side: RGB16 rows are read back to back (screencap.cpp:1668), which differs from the DIB pitch for odd widths
+        self.in_pitch = width * 2 if bits_per_pixel == 16 else self.pitch
+        self.frame_bytes = self.in_pitch * height
         self.max_packet = width * height * 6 + 64  # CompressGetSize, screenpressor.cpp:386-388
         return self
 
     def Deinit(self):
         self._L.scpr_deinit(self._h)
+
+    def SeedShard(self, frames_before: int, last_was_flat: bool, last_flat_rgb: int = 0):
+        """scpr_seed_shard: the cross-GOP state of the single stream where this codec's shard starts"""
+        self._check(self._L.scpr_seed_shard(self._h, frames_before, 1 if last_was_flat else 0, last_flat_rgb))
+        return self
 
     def CrashHappened(self):
         self._L.scpr_crash_happened(self._h)
@@ -158,10 +167,7 @@ class ScreenCodec:
         n = len(sizes)
         pitch = self.pitch if pitch is None else pitch
         total = int(np.sum(sizes))
-        if packets.numel() < total + 16:  # the decoder may read a few bytes past the last packet
-            pad = torch.zeros(total + 16, dtype=torch.uint8, device=packets.device)
-            pad[:total] = packets[:total]
-            packets = pad
+        assert packets.is_cuda and packets.dtype == torch.uint8 and packets.numel() >= total  # exact size: the C side needs no slack
         if out is None:
             out = torch.empty(n * pitch * self.height, dtype=torch.uint8, device=packets.device)
         sz = (C.c_uint32 * n)(*[int(x) for x in sizes])
@@ -175,6 +181,12 @@ class ScreenCodec:
         st = (C.c_float * 32)()
         k = self._L.scpr_last_timing(self._h, C.byref(tot), st, 32)
         return tot.value, {self._L.scpr_stage_name(i).decode(): st[i] for i in range(k)}
+
+    def debug_arena(self):
+        """(compress side, decompress side) bytes allocated for dense tables"""
+        a, b = C.c_uint64(), C.c_uint64()
+        self._L.scpr_debug_arena(self._h, C.byref(a), C.byref(b))
+        return a.value, b.value
 
     def debug_entries(self):
         n = self._L.scpr_debug_entries(self._h, None, 0)

@@ -107,8 +107,9 @@ struct scpr_codec {
   int live_buf = 0;  // which half of fixed_persist / misc_persist / colour_persist holds the live generation
   size_t arena_used_bound = 0;  // upper bound of dense tables held by the live generation
   // decoder side of the same
-  DevBuf decgops, decfixed, dec_fixed_persist, dec_colour_persist;
+  DevBuf decgops, decfixed, dec_fixed_persist, dec_colour_persist, dec_arena, dec_arena_top;  // (its own dense-table arena: one codec may compress and decompress)
   bool dec_live = false;
+  size_t dec_arena_used = 1;  // tables held by the live GOP of the decoder (table 0 is the sink of an overflowing run, never a real table)
   // second stream: the fixed-model chains run beside the colour chains (they write disjoint entries)
   hipStream_t stream2 = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -230,6 +231,8 @@ static int ensure_codec(scpr_codec* c, int version) {  // CreateCodec + CScreenC
   c->live_buf = 0;
   c->arena_used_bound = 0;
   HIPCHK(c->arena_top.reserve(16));
+  HIPCHK(c->dec_arena_top.reserve(16));
+  c->dec_arena_used = 1;
   HIPCHK(c->err.reserve(64));
   HIPCHK(c->total64.reserve(16));
   // reciprocal table for every frequency on the 12-bit scale
@@ -497,7 +500,9 @@ int scpr_init(scpr_codec* c, const scpr_params* p) {  // ScreenCodec::Init, scre
   c->prm = *p;
   if (c->prm.workers < 1) c->prm.workers = 1;
   c->bpp = (int)p->bits_per_pixel / 8;
-  c->pitch_in = p->bits_per_pixel == 32 ? (int)p->width * 4 : (((int)p->width * c->bpp + 3) & ~3);
+  // input rows: RGB32 and RGB16 are read back to back (screencap.cpp:1655 `i = y*X*4`, :1668 `i = y*X*2`: no row padding,
+  // also for odd widths of RGB16), RGB24 rows are padded to 4 bytes (the plane's own stride, :1592)
+  c->pitch_in = p->bits_per_pixel == 24 ? (((int)p->width * 3 + 3) & ~3) : (int)p->width * c->bpp;
   c->last_loss = (int)p->loss;
   c->rs = c->gs = c->bs = 0;
   if (p->bits_per_pixel == 16) {
@@ -529,7 +534,7 @@ void scpr_destroy(scpr_codec* c) {
   DevBuf* all[] = {&c->planes, &c->exitmap, &c->entry, &c->runrec, &c->tilecnt, &c->tileoff, &c->hdrrec, &c->hdrcnt, &c->frametot, &c->flags, &c->slotlist, &c->genlist,
                    &c->bases, &c->totals, &c->runs, &c->runpos, &c->keys[0], &c->keys[1], &c->vals[0], &c->vals[1], &c->cstart, &c->sorttmp,
                    &c->entries, &c->ranges, &c->rblocks, &c->rscratch, &c->rsize, &c->packets, &c->pktoff, &c->blkdst, &c->outsizes, &c->total64, &c->arena,
-                   &c->arena_top, &c->err, &c->rcp, &c->decframes, &c->decstates, &c->hoststage_in, &c->hoststage_out, &c->chainlists, &c->chaincounts, &c->kinds, &c->pidx, &c->fidx, &c->pframes, &c->pflag, &c->binfo, &c->smv, &c->btype, &c->bmv, &c->bcnt, &c->boff, &c->bflag, &c->pinfo, &c->ptot, &c->pbase, &c->misc, &c->miscpos, &c->miscranges, &c->mvs, &c->fixed_persist, &c->misc_persist, &c->colour_persist, &c->decgops, &c->decfixed, &c->dec_fixed_persist, &c->dec_colour_persist, &c->mvdict, &c->mvpre, &c->gmask};
+                   &c->arena_top, &c->err, &c->rcp, &c->decframes, &c->decstates, &c->hoststage_in, &c->hoststage_out, &c->chainlists, &c->chaincounts, &c->kinds, &c->pidx, &c->fidx, &c->pframes, &c->pflag, &c->binfo, &c->smv, &c->btype, &c->bmv, &c->bcnt, &c->boff, &c->bflag, &c->pinfo, &c->ptot, &c->pbase, &c->misc, &c->miscpos, &c->miscranges, &c->mvs, &c->fixed_persist, &c->misc_persist, &c->colour_persist, &c->decgops, &c->decfixed, &c->dec_fixed_persist, &c->dec_colour_persist, &c->dec_arena, &c->dec_arena_top, &c->mvdict, &c->mvpre, &c->gmask};
   for (DevBuf* b : all) b->release();
   for (int s = 0; s < ST_COUNT + 1; s++)
     for (int k = 0; k < 2; k++) (void)hipEventDestroy(c->ev[s][k]);
@@ -542,6 +547,28 @@ void scpr_destroy(scpr_codec* c) {
 
 void scpr_crash_happened(scpr_codec* c) {
   if (c) c->crashed = true;
+}
+
+// Sharding support: the state CScreenCapt carries ACROSS key frames (fn > 0, screencap.cpp:1504; last_was_flat /
+// last_flat_clr with prev holding that flat picture, :1490-1497), so that a shard that starts after a flat frame
+// produces what the single stream produces there.
+int scpr_seed_shard(scpr_codec* c, uint32_t frames_before, int last_was_flat, uint32_t last_flat_rgb) {
+  if (!c || !c->inited) return SCPR_E_PARAM;
+  if (hipSetDevice(c->device) != hipSuccess) return SCPR_E_DEVICE;
+  int rc = ensure_codec(c, c->have_codec ? c->version : 4);
+  if (rc != SCPR_OK) return rc;
+  c->frames_done = frames_before;
+  c->last_flat = last_was_flat != 0;
+  if (last_was_flat) {
+    c->last_flat_rgb = last_flat_rgb & 0xFFFFFFu;
+    const Geom& g = c->g;
+    hipLaunchKernelGGL(k_fill_flat, dim3((g.H * g.S + 255) / 256), dim3(256), 0, c->stream, c->planes.as<u8>(), g, c->slots, c->last_flat_rgb);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->live_valid = true;       // that flat frame renewed the models ...
+    c->live_has_state = false;  // ... and nothing has been coded with them
+    c->dec_live = false;
+  }
+  return SCPR_OK;
 }
 
 int64_t scpr_compress_batch(scpr_codec* c, const void* d_frames, int nframes, int* ftypes, int loss, void* d_out, size_t out_capacity, uint32_t* sizes) {
@@ -686,13 +713,15 @@ int64_t scpr_compress_batch(scpr_codec* c, const void* d_frames, int nframes, in
                        c->blkdst.as<u64>(), (u8*)d_out + written, (u64)(out_capacity - (size_t)written), c->err.as<u32>());
     stage_end(c, ST_GATHER);
     u64 chunk_total = 0;
-    u32 err = 0;
+    u32 err = 0, atop = 0;
+    HIPCHK(hipMemcpyAsync(&atop, c->arena_top.p, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(sizes + f0, c->outsizes.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(&chunk_total, c->total64.p, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(&err, c->err.p, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipGetLastError());  // a kernel that could not be launched (the launches themselves are not checked one by one)
     timing_collect(c);
+    c->arena_used_bound = std::min<size_t>(c->arena_used_bound, atop);  // what the live generation really holds: the arena does not grow with the number of calls
     if (err & 2) return SCPR_E_CAPACITY;
     if (err & 1) {
       fprintf(stderr, "[scpr] dense-table arena overflow\n");
@@ -731,10 +760,19 @@ int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* 
     }
     const Geom& g = c->g;
     const int n = std::min(c->slots, nframes - f0);
+    // A chunk is decoded with a dense-table arena sized for what streams need in practice; the device reports an
+    // overflow (nothing is lost: the run scribbles on table 0, which is never a real table) and the chunk is then
+    // decoded again with the worst case (every context of every GOP dense, 12288 tables per GOP).
+    const bool host_crashed = c->crashed, host_flat = c->last_flat;
+    const u32 host_flat_rgb = c->last_flat_rgb, host_frames_done = c->frames_done;
+    u32 errv[8] = {0};
+    for (int attempt = 0;; attempt++) {
+    c->crashed = host_crashed, c->last_flat = host_flat, c->last_flat_rgb = host_flat_rgb, c->frames_done = host_frames_done;
     std::vector<DecFrame> fr;
     std::vector<DecGop> gops;
     HIPCHK(hipMemsetAsync(c->err.p, 0, 32, st));
     stage_begin(c, ST_DECODE);
+    u64 gop_bytes = 0;
     for (int i = 0; i < n; i++) {
       const int fi = f0 + i;
       if (c->crashed && ftypes[fi] > 0) return done;  // (:1697)
@@ -762,6 +800,7 @@ int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* 
       if (new_gop) gops.push_back({(int)fr.size(), 0, 0, 0});
       fr.push_back(d);
       gops.back().count++;
+      gop_bytes += sizes[fi];
     }
     const size_t ng = gops.size();
     if (ng) {
@@ -780,15 +819,19 @@ int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* 
         HIPCHK(hipMemcpyAsync(c->decstates.p, c->dec_colour_persist.p, state_bytes, hipMemcpyDeviceToDevice, st));
         HIPCHK(hipMemcpyAsync(c->decfixed.p, c->dec_fixed_persist.p, blob_bytes, hipMemcpyDeviceToDevice, st));
       } else {
-        c->arena_used_bound = 0;
-        HIPCHK(hipMemsetAsync(c->arena_top.p, 0, 4, st));
+        c->dec_arena_used = 1;
       }
-      const size_t arena_cap = c->arena_used_bound + (v2 ? 0 : ng * 12288) + 64;
-      HIPCHK(c->arena.reserve_keep(arena_cap * sizeof(DenseTab), c->arena_used_bound * sizeof(DenseTab), st));
-      c->arena_used_bound = arena_cap;
+      // Tables this chunk can allocate: a context goes dense once, after at least 16 of its symbols of which 15 came
+      // as raw bytes (ans_contexts.cpp:3-31), so never more than packet bytes / 15, nor than 12288 per GOP.
+      const size_t worst = v2 ? 0 : std::min<size_t>(ng * (size_t)NCOLCTX, (size_t)(gop_bytes / 15) + ng);
+      const size_t budget = attempt ? worst : std::min<size_t>(worst, ng * 1024);
+      const size_t arena_cap = c->dec_arena_used + budget + 64;
+      HIPCHK(c->dec_arena.reserve_keep(arena_cap * sizeof(DenseTab), c->dec_arena_used * sizeof(DenseTab), st));
+      const u32 top0 = (u32)c->dec_arena_used;
+      HIPCHK(hipMemcpyAsync(c->dec_arena_top.p, &top0, 4, hipMemcpyHostToDevice, st));
       HIPCHK(hipMemcpyAsync(c->decframes.p, fr.data(), fr.size() * sizeof(DecFrame), hipMemcpyHostToDevice, st));
       HIPCHK(hipMemcpyAsync(c->decgops.p, gops.data(), ng * sizeof(DecGop), hipMemcpyHostToDevice, st));
-      Arena ar{c->arena.as<DenseTab>(), c->arena_top.as<u32>(), (u32)arena_cap, c->err.as<u32>()};
+      Arena ar{c->dec_arena.as<DenseTab>(), c->dec_arena_top.as<u32>(), (u32)arena_cap, c->err.as<u32>()};
       // LDS ring of 32-bit pixels: the predictors look back one row + 1 pixel, a finished row is flushed at most
       // one run after it ends, and a run writes up to 255 pixels ahead: a power of two >= W + 512 pixels.
       // (Keeping static + dynamic LDS under 80 KiB lets two GOPs share a CU.)
@@ -799,25 +842,42 @@ int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* 
       for (const DecFrame& d : fr) has_p |= d.kind == 2;
       const int dyn = ring + (has_p ? ((nblocks + 15) & ~15) : 0);  // + one byte per block for P-frames
       const u8* pk = (const u8*)d_packets;
+      const u8* pk_end = pk + offs[nframes];  // nothing is read at or past this address (the reader supplies 0xFF there)
       if (v2) {
         auto kern = has_p ? k_decode_gop_v2<true> : k_decode_gop_v2<false>;
         HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
-        hipLaunchKernelGGL(kern, dim3((unsigned)ng), dim3(64), dyn, st, pk, pk + offs[nframes] + 8, c->decframes.as<DecFrame>(), c->decgops.as<DecGop>(), c->planes.as<u8>(), g,
+        hipLaunchKernelGGL(kern, dim3((unsigned)ng), dim3(64), dyn, st, pk, pk_end, c->decframes.as<DecFrame>(), c->decgops.as<DecGop>(), c->planes.as<u8>(), g,
                            c->decstates.as<u32>(), c->err.as<u32>(), ring, c->decfixed.as<V2Fixed>(), (int)c->prm.high_range_x, (int)c->prm.high_range_y);  // the caller's range, unclamped (:76-77)
       } else {
         auto kern = has_p ? k_decode_gop_w<true> : k_decode_gop_w<false>;  // key-frame-only GOPs: smaller kernel (instruction cache)
         HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
-        hipLaunchKernelGGL(kern, dim3((unsigned)ng), dim3(64), dyn, st, pk, pk + offs[nframes] + 8, c->decframes.as<DecFrame>(), c->decgops.as<DecGop>(), c->planes.as<u8>(), g,
+        hipLaunchKernelGGL(kern, dim3((unsigned)ng), dim3(64), dyn, st, pk, pk_end, c->decframes.as<DecFrame>(), c->decgops.as<DecGop>(), c->planes.as<u8>(), g,
                            c->decstates.as<DecRec>(), ar, c->f0, c->err.as<u32>(), ring, c->decfixed.as<FixedBlob>(), (int)std::min<u32>(c->prm.high_range_x, 256),
                            (int)std::min<u32>(c->prm.high_range_y, 256));
       }
-      // keep the state of the last GOP and the last plane for the next call
+    }
+    stage_end(c, ST_DECODE);
+    u32 atop = 0;
+    HIPCHK(hipMemcpyAsync(errv, c->err.p, 32, hipMemcpyDeviceToHost, st));
+    if (ng) HIPCHK(hipMemcpyAsync(&atop, c->dec_arena_top.p, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));  // also covers fr / gops (host memory)
+    HIPCHK(hipGetLastError());         // a kernel that could not be launched
+    if ((errv[0] & 1) && attempt == 0) continue;  // the arena was too small for this stream: once more with the worst case
+    if (ng && !(errv[0] & 5)) {
+      // keep the state of the last GOP for the next call; with one GOP in the chunk its tables stay where they are
+      // (top read back: the arena does not grow with the number of calls), with several the next call's first
+      // P-frame would need the last GOP's tables only, which sit anywhere below the top
+      const bool v2 = c->version == 2;
+      const size_t state_bytes = v2 ? (size_t)NCOLCTX * V2_COLTAB * 4 : (size_t)NCOLCTX * sizeof(DecRec);
+      const size_t blob_bytes = v2 ? sizeof(V2Fixed) : sizeof(FixedBlob);
       HIPCHK(hipMemcpyAsync(c->dec_colour_persist.p, (const u8*)c->decstates.p + (ng - 1) * state_bytes, state_bytes, hipMemcpyDeviceToDevice, st));
       HIPCHK(hipMemcpyAsync(c->dec_fixed_persist.p, (const u8*)c->decfixed.p + (ng - 1) * blob_bytes, blob_bytes, hipMemcpyDeviceToDevice, st));
+      c->dec_arena_used = std::max<size_t>(atop, 1);
       c->dec_live = true;
     }
+    break;
+    }
     HIPCHK(hipMemcpyAsync(c->planes.as<u8>() + (size_t)c->slots * g.plane_stride, c->planes.as<u8>() + (size_t)(n - 1) * g.plane_stride, g.plane_stride, hipMemcpyDeviceToDevice, st));
-    stage_end(c, ST_DECODE);
     stage_begin(c, ST_UNPACK);
     u8* out = (u8*)d_frames_out + (size_t)f0 * pitch * g.H;
     if (c->bpp == 4) {
@@ -831,10 +891,8 @@ int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* 
       hipLaunchKernelGGL(k_unpack_rows, gr, dim3(256), 0, st, c->planes.as<u8>(), out, g, pitch, c->bpp, c->rs, c->gs, c->bs);
     }
     stage_end(c, ST_UNPACK);
-    u32 errv[8] = {0};
-    HIPCHK(hipMemcpyAsync(errv, c->err.p, 32, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));  // also covers fr / gops (host memory)
-    HIPCHK(hipGetLastError());         // a kernel that could not be launched
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipGetLastError());
     timing_collect(c);
     const u32 err = errv[0];
     if (err & 4) return SCPR_E_STREAM;
@@ -872,7 +930,6 @@ int scpr_decompress_frame(scpr_codec* c, const void* src, int src_len, void* dst
   const size_t ob = (size_t)pitch * c->prm.height;
   HIPCHK(c->hoststage_in.reserve((size_t)src_len + 64));
   HIPCHK(c->hoststage_out.reserve(ob));
-  HIPCHK(hipMemsetAsync((u8*)c->hoststage_in.p + src_len, 0, 16, c->stream));
   HIPCHK(hipMemcpyAsync(c->hoststage_in.p, src, (size_t)src_len, hipMemcpyHostToDevice, c->stream));
   uint32_t sz = (uint32_t)src_len;
   int r = scpr_decompress_batch(c, c->hoststage_in.p, &sz, &ftype, 1, c->hoststage_out.p, pitch);
@@ -892,10 +949,10 @@ int scpr_last_timing(scpr_codec* c, float* total_ms, float* stage_ms, int cap) {
 #ifdef SCPR_PROFILE
 // design work only (libscpr_amd_prof.so): s_memtime ticks per decoder section summed over all GOPs since the last call
 extern "C" int scpr_debug_profile(unsigned long long* out) {
-  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long z[16] = {0};
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(scpr::g_prof), sizeof z) != hipSuccess) return -1;
   if (hipMemcpyToSymbol(HIP_SYMBOL(scpr::g_prof), z, sizeof z) != hipSuccess) return -1;
-  return 8;
+  return 16;
 }
 #endif
 int scpr_debug_colour_chain(int device, const uint8_t* syms, int n, int f0, uint16_t* out) {
@@ -930,6 +987,13 @@ int scpr_debug_colour_chain(int device, const uint8_t* syms, int n, int f0, uint
   HIPCHK(hipMemcpy(out, de.p, (size_t)n * 4, hipMemcpyDeviceToHost));
   for (DevBuf* b : {&dk, &dv, &dc, &dl, &dn, &de, &da, &dt}) b->release();
   return n;
+}
+
+int scpr_debug_arena(scpr_codec* c, uint64_t* enc_bytes, uint64_t* dec_bytes) {
+  if (!c) return SCPR_E_PARAM;
+  if (enc_bytes) *enc_bytes = (uint64_t)c->arena.cap;
+  if (dec_bytes) *dec_bytes = (uint64_t)c->dec_arena.cap;
+  return SCPR_OK;
 }
 
 int64_t scpr_debug_entries(scpr_codec* c, uint16_t* out, int64_t cap) {

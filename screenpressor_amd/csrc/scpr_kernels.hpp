@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void k_pack24(const u8* __restrict__ src, u8* 
 __global__ __launch_bounds__(256) void k_pack16(const u8* __restrict__ src, u8* __restrict__ planes, Geom g, u32* flat, u32* first,
                                                 u32 rm, u32 gm, u32 bm, int rs, int gs, int bs) {
   const int f = blockIdx.y, total = g.H * g.W;
-  const int pitch = (g.W * 2 + 3) & ~3;
+  const int pitch = g.W * 2;  // rows back to back, as the reference reads them (screencap.cpp:1668: i = y*X*2)
   const u8* fr = src + (size_t)f * pitch * g.H;
   auto conv = [&](u32 w) { return ((w & rm) >> rs) | (((w & gm) >> gs) << 8) | (((w & bm) >> bs) << 16); };
   const u32 v0 = conv(*(const u16*)fr) & 0xFFFFFFu;

@@ -59,6 +59,8 @@ struct WaveDecV2 {
   __device__ __forceinline__ void tick() {}
   template <int SEC>
   __device__ __forceinline__ void stamp() {}
+  template <int EV>
+  __device__ __forceinline__ void event() {}
 
   __device__ __forceinline__ u32 fetch_word(u32 i) {
     const u32 m = i < wmax ? i : wmax;
@@ -83,8 +85,8 @@ struct WaveDecV2 {
     const size_t a = (size_t)rfl64((u64)(size_t)s);
     wbase = (const u32*)(a & ~(size_t)3);
     const u32 skip = (u32)(a & 3);
-    wmax = (u32)(((size_t)rfl64((u64)(size_t)src_end) - (a & ~(size_t)3)) >> 2);
-    wmax = wmax ? wmax - 1 : 0;
+    const size_t e = (size_t)rfl64((u64)(size_t)src_end), ab = a & ~(size_t)3;
+    wmax = e > ab ? (u32)((e - 1 - ab) >> 2) : 0u;  // the aligned word that holds the last byte of the packet buffer: nothing past it is touched (`left` guards the bytes)
     buf = (u64)(fetch_word(0) >> (8 * skip));
     nb = 4 - (int)skip;
     wpos = 1;

@@ -528,7 +528,7 @@ struct WaveModel {
 };
 
 #ifdef SCPR_PROFILE
-__device__ u64 g_prof[8];
+__device__ u64 g_prof[16];
 #endif
 struct WaveDec : WaveModel {
   WaveLds& L;
@@ -536,7 +536,8 @@ struct WaveDec : WaveModel {
   const u8* src;
   const u8* src_end;
   const u32* wbase = nullptr;  // 4-byte aligned base of the current packet
-  u32 wpos = 0, wmax = 0;       // next word to take, last word of the packet buffer
+  u32 wpos = 0, wmax = 0;       // next word to take, the word that holds the last byte of the packet buffer
+  u32 tailmask = 0;             // the bytes of word wmax that lie at or past the end of the buffer
   u32 blk = 0;                  // lane i: word i of the current 64-word block
   u64 buf = 0;
   int nb = 0;
@@ -555,8 +556,9 @@ struct WaveDec : WaveModel {
   // The packet is read 256 bytes at a time: one load gives every lane one 4-byte word of the block and the
   // coder takes them out with a lane read: one memory wait per 256 bytes instead of one per word.  (Asking
   // for the next block ahead of use was tried: the register in flight gets copied at every join of the
-  // control flow, and each copy waits for the load.)  Word indices are clamped to the last word of the
-  // packet buffer (nothing is read past it).
+  // control flow, and each copy waits for the load.)  Word indices are clamped to the aligned word that holds
+  // the last byte of the packet buffer: no address at or past the end of that word is ever touched (an aligned
+  // dword never crosses a page), and the bytes of it that lie past the buffer's end are replaced by 0xFF.
   __device__ __forceinline__ u32 load_block(u32 b) {
     const u32 i = b * 64u + (u32)lane;
     return __builtin_nontemporal_load(&wbase[i < wmax ? i : wmax]);
@@ -566,10 +568,14 @@ struct WaveDec : WaveModel {
     const size_t a = (size_t)rfl64((u64)(size_t)s);  // wave-uniform: keeps the whole stream state in scalar registers
     wbase = (const u32*)(a & ~(size_t)3);
     const u32 skip = (u32)(a & 3);
-    wmax = (u32)(((size_t)rfl64((u64)(size_t)src_end) - (a & ~(size_t)3)) >> 2);
-    wmax = wmax ? wmax - 1 : 0;
+    const size_t e = (size_t)rfl64((u64)(size_t)src_end), ab = a & ~(size_t)3;
+    wmax = e > ab ? (u32)((e - 1 - ab) >> 2) : 0u;
+    const u32 valid = (u32)((e - 1) & 3) + 1u;  // bytes of word wmax inside the buffer
+    tailmask = valid == 4u ? 0u : 0xFFFFFFFFu << (8u * valid);
     blk = load_block(0);
-    buf = (u64)(rdl(blk, 0) >> (8 * skip));
+    u32 w0 = rdl(blk, 0);
+    if (SCPR_UNLIKELY(wmax == 0)) w0 |= tailmask;
+    buf = (u64)(w0 >> (8 * skip));
     nb = 4 - (int)skip;
     wpos = 1;
     ndec = 0;
@@ -578,7 +584,9 @@ struct WaveDec : WaveModel {
   __device__ __forceinline__ void tick() {}
   // section timing for design work (only with -DSCPR_PROFILE): time since the previous stamp goes to section `sec`
 #ifdef SCPR_PROFILE
-  u64 prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prof_last = 0;
+  u64 prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, prof_last = 0;
+  template <int EV>
+  __device__ __forceinline__ void event() { prof[EV]++; }  // 8 colour symbols, 9 record cache misses, 10 dense, 11 raw, 12 small-table slow path, 13 runs, 14 literal runs, 15 run lengths above 63
   template <int SEC>
   __device__ __forceinline__ void stamp() {
     const u64 t = __builtin_readcyclecounter();
@@ -588,13 +596,15 @@ struct WaveDec : WaveModel {
 #else
   template <int SEC>
   __device__ __forceinline__ void stamp() {}
+  template <int EV>
+  __device__ __forceinline__ void event() {}
 #endif
   __device__ __forceinline__ void need(int k) {
     while (SCPR_UNLIKELY(nb < k)) {
       u32 w = rdl(blk, (int)(wpos & 63u));
       // Past the end of the packet buffer the reader supplies 0xFF bytes: a damaged stream can run off the end,
       // and the refill loop of the coder (advance) must still terminate (on zero bytes it would not).
-      if (SCPR_UNLIKELY(wpos > wmax)) w = 0xFFFFFFFFu;
+      if (SCPR_UNLIKELY(wpos >= wmax)) w = wpos > wmax ? 0xFFFFFFFFu : (w | tailmask);
       buf |= (u64)w << (8 * nb);
       nb += 4;
       wpos++;
@@ -743,6 +753,7 @@ struct WaveDec : WaveModel {
     int sym = __builtin_popcountll(__ballot(e0 < lim)) - 1;
     u32 s = rdl(e0, sym);
     if (SCPR_UNLIKELY(rfl(e1) < lim)) {  // cum of symbol 64 is not above v: the symbol is further up
+      event<15>();
       const u32 e2 = tab[128 + lane], e3 = tab[192 + lane];
       sym = 63 + __builtin_popcountll(__ballot(e1 < lim)) + __builtin_popcountll(__ballot(e2 < lim)) + __builtin_popcountll(__ballot(e3 < lim));
       const int q = sym >> 6, l = sym & 63;
@@ -892,6 +903,7 @@ struct WaveDec : WaveModel {
     asm volatile("ds_read_b128 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=v"(hw), "=v"(w) : "v"(ra), "v"(ea) : "memory");
     const u32 tag = rfl(hw.w);  // the context the slot holds (kNoCtx: none)
     if (SCPR_UNLIKELY(tag != (u32)ctxid)) {
+      event<9>();
       if (lane < DECREC_WORDS) {
         if (tag != kNoCtx) gstates[tag].w[lane] = r[lane];
         r[lane] = lane == 3 ? (u32)ctxid : gstates[ctxid].w[lane];
@@ -928,6 +940,7 @@ struct WaveDec : WaveModel {
     ColHdr h;
     u32 w, ra, ea, h0, hz;
     u32* r = record(ctxid, h, w, ra, ea, h0, hz);
+    event<8>();
     const int maxpos0 = h.maxpos;
     // Plain ifs, the common case first (an else costs it a taken branch): a raw symbol leaves the coder alone,
     // which is an advance over the whole range.
@@ -938,7 +951,10 @@ struct WaveDec : WaveModel {
     if (SCPR_LIKELY(small0 < 0)) {
       int t = small_hit(h, w, (int)v, c, fr, cf);
       asm volatile("" : "+s"(t));  // (keeps the test inside small_hit and this one apart)
-      if (SCPR_UNLIKELY(t >= 0)) c = small_op<true>(r, h, w, (int)v, fr, cf);
+      if (SCPR_UNLIKELY(t >= 0)) {
+        event<12>();
+        c = small_op<true>(r, h, w, (int)v, fr, cf);
+      }
       wave_fence();
       // the entries go back from every row of 16 lanes alike: no lane mask (a full table has just become a dense
       // one: then w holds what is there already)
@@ -949,6 +965,7 @@ struct WaveDec : WaveModel {
       h.fshift = (int)((h0 >> 16) & 15u);
       h.dense = rfl(hz);
       if (h.kind < 4) {
+        event<11>();
         fr = kProbScale, cf = 0;
         c = (int)take_byte();
         note_raw(r, h, c, w);
@@ -956,6 +973,7 @@ struct WaveDec : WaveModel {
         if ((h.kind == 4 || h.kind == 5) && lane < 16) r[4 + lane] = w;  // promoted to a small table
         wave_fence();
       } else {
+        event<10>();
         c = dense_op<true>(r, h, (int)v, fr, cf);
       }
       scalar_hdr(h);
@@ -1054,6 +1072,8 @@ __device__ __forceinline__ void decode_intra_frame(DEC& D, const Geom& g, u8* __
     if constexpr (FAST) t = D.template fixed_p<false>(t);
     else if (lim == NP) t = D.fixed_p(t);
     D.template stamp<0>();
+    D.template event<13>();
+    if (t == 0) D.template event<14>();
     u32 px = lastpix;
     if (t == 0) {  // DecodeRGB, screencap.cpp:662-679: contexts are the two previous bytes >> 2 (MAKECX1, screencap.h:35-36)
       u32 a = (lastpix >> 18) & 63, b = (lastpix >> 10) & 63;
@@ -1453,7 +1473,7 @@ __global__ __launch_bounds__(64) void k_decode_gop_w(const u8* __restrict__ pack
   if (D.bad && lane == 0) atomicOr(status, 4u);
 #ifdef SCPR_PROFILE
   if (lane == 0)
-    for (int i = 0; i < 8; i++) atomicAdd((unsigned long long*)&g_prof[i], (unsigned long long)D.prof[i]);
+    for (int i = 0; i < 16; i++) atomicAdd((unsigned long long*)&g_prof[i], (unsigned long long)D.prof[i]);
 #endif
 }
 

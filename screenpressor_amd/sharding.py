@@ -6,7 +6,10 @@ contiguous GOP ranges, one per rank; each rank encodes its range as an independe
 the packets are gathered to rank 0 in frame order.  No collective touches the data path until
 that gather.
 
-Note: the reference's motion search also remembers, per block, the last vector found in ANY
+Two pieces of state do cross key frames in the reference.  (1) The flat-frame rule compares with the previous
+flat frame and P-frames need "a frame has been coded" (last_was_flat / last_flat_clr / fn, screencap.cpp:1490-1504):
+`shard_seed` computes that state from the frames right before a cut and `scpr_seed_shard` installs it, so a shard
+that starts at or after a repeated flat colour produces the single stream's bytes.  (2) The reference's motion search also remembers, per block, the last vector found in ANY
 earlier frame (mvs[], screencap.cpp:96-97, :726-735, never reset), so a shard is byte-identical
 to the reference run on that shard's frames from a fresh codec, not to a single process that
 encoded the whole stream.  Key-frame-only streams have no such memory and shard exactly.
@@ -34,6 +37,35 @@ def shard_gops(ftypes_in, world: int) -> list[tuple[int, int]]:
         cuts.append(max(best, cuts[-1]))
     cuts.append(n)
     return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
+def flat_colour(frame: np.ndarray, width: int, height: int, bpp: int):
+    """b0 | b1 << 8 | b2 << 16 of the picture's one colour, or None if it is not a flat picture (IsFlat,
+    screencap.cpp:1436-1444, on the colour bytes the codec sees: RGB32 drops byte 3, :1652-1664)"""
+    assert bpp in (24, 32), "flat-frame seeding is implemented for RGB32 / RGB24 input"
+    px = bpp // 8
+    pitch = width * 4 if bpp == 32 else (width * 3 + 3) & ~3
+    rows = np.asarray(frame, dtype=np.uint8).reshape(height, pitch)[:, : width * px].reshape(height, width, px)[..., :3]
+    c = rows[0, 0]
+    if not (rows == c).all():
+        return None
+    return int(c[0]) | (int(c[1]) << 8) | (int(c[2]) << 16)
+
+
+def shard_seed(get_frame, lo: int, width: int, height: int, bpp: int):
+    """Arguments of scpr_seed_shard / ScreenCodec.SeedShard for a shard whose first frame is `lo` of the stream:
+    (frames_before, last_was_flat, last_flat_rgb).  `get_frame(t)` returns input frame t; only the frames right
+    before the cut are looked at (one, unless they are flat).  GOPs share nothing else except the motion-vector
+    memory (module docstring)."""
+    if lo <= 0:
+        return 0, False, 0
+    last = flat_colour(get_frame(lo - 1), width, height, bpp)
+    # fn counts coded (non-flat) frames only (flat frames return before fn++, screencap.cpp:1488-1500)
+    coded, t = 0, lo - 1
+    while t >= 0 and coded == 0:
+        coded += flat_colour(get_frame(t), width, height, bpp) is None
+        t -= 1
+    return coded, last is not None, (last or 0)
 
 
 def gather_packets(dist, rank: int, world: int, payload: np.ndarray, sizes: np.ndarray, device=None):

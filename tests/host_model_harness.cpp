@@ -4,7 +4,7 @@
 // without a GPU.  Not linked into the product library.
 #include <stdint.h>
 #include <string.h>
-#include "scpr_model.hpp"
+#include "host_model_serial.hpp"
 
 using namespace scpr;
 

@@ -37,6 +37,7 @@ def lib():
         L.spo_compress_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_int]
         L.spo_decompress_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int]
         L.spo_crash_happened.argtypes = [C.c_void_p]
+        L.spo_seed_shard.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_uint32]
         L.spo_tap_entries.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.spo_tap_tags.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.spo_tap_blocks.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
@@ -48,6 +49,11 @@ def lib():
         L.spo_rans_block.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.spo_time_stream.argtypes = [C.POINTER(SpoParams), C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double),
                                       C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.spo_time_stream2.argtypes = [C.POINTER(SpoParams), C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                       C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_void_p, C.c_void_p]
+        L.spo_set_threads.argtypes = [C.c_void_p, C.c_int]
+        L.spo_fnv1a.restype = C.c_uint64
+        L.spo_fnv1a.argtypes = [C.c_void_p, C.c_uint64]
         _lib = L
     return _lib
 
@@ -65,6 +71,7 @@ class OracleCodec:
         self.h_ = lib().spo_create(C.byref(self.params))
         self.cap = w * h * 6 + 64
         self.pitch = w * 4 if bpp == 32 else ((w * (bpp // 8) + 3) & ~3)
+        self.in_pitch = w * 2 if bpp == 16 else self.pitch  # RGB16 input rows back to back (screencap.cpp:1668)
         self.stride24 = (w * 3 + 3) & ~3
         self.nblocks = ((w + 15) // 16) * ((h + 15) // 16)
 
@@ -78,11 +85,17 @@ class OracleCodec:
 
     def compress(self, frame, key=False, loss=None):
         src = np.ascontiguousarray(frame, dtype=np.uint8).copy()  # the codec may write into src
-        assert src.size == self.pitch * self.h, (src.size, self.pitch, self.h)
+        assert src.size == self.in_pitch * self.h, (src.size, self.in_pitch, self.h)
         dst = np.empty(self.cap, dtype=np.uint8)
         ft = C.c_int(0 if key else 1)
         n = lib().spo_compress_frame(self.h_, _ptr(src), _ptr(dst), self.cap, C.byref(ft), self.loss if loss is None else loss)
         return bytes(dst[:n]), ft.value
+
+    def set_threads(self, n):
+        lib().spo_set_threads(self.h_, n)
+
+    def seed_shard(self, frames_before, last_flat, rgb):
+        lib().spo_seed_shard(self.h_, frames_before, 1 if last_flat else 0, rgb)
 
     def decompress(self, data, ftype, pitch=None):
         pitch = self.pitch if pitch is None else pitch
@@ -146,10 +159,18 @@ def rans_block(entries):
     return bytes(out[:sz])
 
 
-def time_stream(frames, w, h, bpp, key_interval, loss=0, workers=1):
+def time_stream(frames, w, h, bpp, key_interval, loss=0, workers=1, threads=1):
+    """encode + decode `frames` on the host CPU.  workers = row bands of a key frame (bitstream-visible, as in the
+    reference); threads = 1: one thread; > 1: the reference's two-stage shape (band pool + one coder thread)."""
     p = make_params(w, h, bpp, loss, workers)
     te, td, nb, hv = C.c_double(), C.c_double(), C.c_uint64(), C.c_uint64()
     frames = np.ascontiguousarray(frames, dtype=np.uint8).copy()
     n = frames.shape[0]
-    bad = lib().spo_time_stream(C.byref(p), _ptr(frames), n, key_interval, C.byref(te), C.byref(td), C.byref(nb), C.byref(hv))
-    return dict(bad=bad, t_enc=te.value, t_dec=td.value, bytes=nb.value, fnv=hv.value)
+    sizes, fnvs = np.zeros(n, np.uint32), np.zeros(n, np.uint64)
+    bad = lib().spo_time_stream2(C.byref(p), _ptr(frames), n, key_interval, threads, C.byref(te), C.byref(td), C.byref(nb), C.byref(hv), _ptr(sizes), _ptr(fnvs))
+    return dict(bad=bad, t_enc=te.value, t_dec=td.value, bytes=nb.value, fnv=hv.value, sizes=sizes, frame_fnv=fnvs)
+
+
+def fnv1a(data) -> int:
+    a = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, dtype=np.uint8)
+    return int(lib().spo_fnv1a(_ptr(a), a.size))

@@ -513,3 +513,149 @@ def test_random_streams_rgb24_and_rgb16(bpp, w, h, seed):
         nb = w * (bpp // 8)
         assert np.array_equal(out.reshape(h, pitch)[:, :nb], want.reshape(h, pitch)[:, :nb]), t
         assert np.array_equal(out.reshape(h, pitch)[:, :nb], frames[t][:, :nb]) or bpp == 16, t
+
+
+def test_rgb24_1080p_batch_is_the_rgb32_stream():
+    """BASELINE configs[4] (1920x1080, 3-byte pixels, pitch 5760) at reduced length: the batch-encoded packets equal
+    the oracle's, equal the stream of the same content given as RGB32 (`must hash-equal`), equal the
+    committed golden hashes, and decode back to the source rows."""
+    import json
+    import os
+    import torch
+    w, h, n = 1920, 1080, 3
+    seq = DesktopSequence(w, h, seed=1)
+    f24 = np.stack([pack24(seq.frame24(t)) for t in range(n)])
+    f32 = seq.frames(n)
+    assert f24.shape == (n, h, 5760)
+    g24, g32 = _codec(w, h, 24), _codec(w, h, 32)
+    d24 = torch.from_numpy(f24).cuda().reshape(n, -1)
+    pk24, s24, ft24 = g24.CompressBatch(d24, [0] * n)
+    pk32, s32, _ = g32.CompressBatch(torch.from_numpy(f32).cuda().reshape(n, -1), [0] * n)
+    host = pk24.cpu().numpy().tobytes()
+    assert list(s24) == list(s32) and host == pk32.cpu().numpy().tobytes()
+    man = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "manifest.json")))["desktop_1080p_rgb24"]
+    off = 0
+    for t in range(n):
+        want, _ = O.OracleCodec(w, h, 24).compress(f24[t], key=True)
+        got = host[off:off + int(s24[t])]
+        off += int(s24[t])
+        assert got == want, (t, _first_diff(got, want))
+        assert hashlib.sha256(got).hexdigest() == man["frame_sha256"][t]
+    r, dec = _codec(w, h, 24).DecompressBatch(pk24, s24, ft24)
+    assert r == n and torch.equal(dec.reshape(n, -1), d24)
+
+
+def _chan0_noise(rng, w, h):
+    f = np.full((h, w, 4), 255, np.uint8)
+    f[..., 0] = rng.integers(0, 256, (h, w))
+    f[..., 1] = 40 + 8 * rng.integers(0, 2, (h, w))
+    f[..., 2] = 80 + 8 * rng.integers(0, 2, (h, w))
+    return f
+
+
+@pytest.mark.parametrize("w,h,seed", [(64, 48, 1), (100, 37, 2), (320, 240, 3), (33, 50, 4)])
+def test_version3_streams_decode(w, h, seed):
+    """Version 3 streams (header 0x22 / 0x21, f0 = 64: screencap.cpp:1613, :1700) are decode-only like version 2.
+    Streams from the oracle's version 3 encoder - key frames, P-frames, unchanged and flat frames, and frames whose
+    contexts go through the Cx2 -> Cx6 promotion where f0 matters - decoded frame by frame and in random batches."""
+    import torch
+    rng = np.random.default_rng(300 + seed)
+    seq = DesktopSequence(w, h, seed=70 + seed, sparkles=25)
+    flat = np.full((h, w, 4), 255, np.uint8)
+    flat[..., :3] = (7, 99, 201)
+    frames, keys = [], []
+    for t in range(16):
+        k = rng.random()
+        if k < 0.5 or not frames:
+            f = seq.frame(t)
+        elif k < 0.7:
+            f = seq.frame(t).copy()
+            y0, x0 = int(rng.integers(0, h // 2)), int(rng.integers(0, w // 2))
+            f[y0:y0 + h // 2, x0:x0 + w // 2] = _chan0_noise(rng, w // 2, h // 2)
+        elif k < 0.85:
+            f = frames[-1].copy()
+        else:
+            f = flat.copy()
+        frames.append(f)
+        keys.append(t == 0 or rng.random() < 0.25)
+    enc3, enc4 = O.OracleCodec(w, h, 32, version=3), O.OracleCodec(w, h, 32)
+    pk = [enc3.compress(f, key=k) for f, k in zip(frames, keys)]
+    pk4 = [enc4.compress(f, key=k) for f, k in zip(frames, keys)]
+    assert pk[0][0][0] == 0x22
+    assert any(a[0][1:] != b[0][1:] for a, b in zip(pk, pk4)), "the content never reached the place where f0 matters"
+    gpu = _codec(w, h)
+    for (p, ft), f in zip(pk, frames):  # one call per frame
+        r, out = gpu.DecompressFrame(p, ft)
+        assert r == 1 and np.array_equal(out.reshape(h, w, 4), f)
+    gb = _codec(w, h)
+    i = 0
+    while i < len(pk):  # batches
+        j = min(len(pk), i + int(rng.integers(1, 6)))
+        blob = b"".join(p for p, _ in pk[i:j])
+        dev = torch.from_numpy(np.frombuffer(blob, np.uint8).copy()).cuda()
+        r, out = gb.DecompressBatch(dev, [len(p) for p, _ in pk[i:j]], [ft for _, ft in pk[i:j]])
+        assert r == j - i
+        out = out.cpu().numpy().reshape(j - i, h, w, 4)
+        for t in range(i, j):
+            assert np.array_equal(out[t - i], frames[t]), t
+        i = j
+
+
+@pytest.mark.parametrize("w,h", [(33, 21), (101, 18), (7, 9)])
+def test_rgb16_odd_width_rows_back_to_back(w, h):
+    """The reference reads RGB16 input rows at y*X*2 (screencap.cpp:1668), without the DWORD row padding a DIB has;
+    for odd widths that is a different layout.  Key + P frames against the oracle (which follows the same line),
+    per-frame and batch entry points; the decode side writes rows at the caller's pitch (:1726-1734)."""
+    import torch
+    rng = np.random.default_rng(w * 100 + h)
+    n = 5
+    frames = []
+    base = rng.integers(0, 1 << 15, (h, w), dtype=np.uint16)
+    base[:, : w // 2] = 0x1234
+    for t in range(n):
+        f = base.copy()
+        f[(3 * t) % h, :] = rng.integers(0, 1 << 15, w, dtype=np.uint16)
+        frames.append(np.ascontiguousarray(f).view(np.uint8).reshape(h, w * 2))
+    ora = O.OracleCodec(w, h, 16)
+    ref = [ora.compress(f, key=(t == 0)) for t, f in enumerate(frames)]
+    gpu = _codec(w, h, 16)
+    got = [gpu.CompressFrame(f, 0 if t == 0 else 1) for t, f in enumerate(frames)]
+    assert got == ref
+    gb = _codec(w, h, 16)
+    dev = torch.from_numpy(np.stack(frames)).cuda().reshape(n, -1)
+    pk, sizes, fts = gb.CompressBatch(dev, [0] + [1] * (n - 1))
+    assert pk.cpu().numpy().tobytes() == b"".join(p for p, _ in ref) and list(fts) == [ft for _, ft in ref]
+    pitch = (w * 2 + 3) & ~3
+    od, gd = O.OracleCodec(w, h, 16), _codec(w, h, 16)
+    for t in range(n):
+        r1, want = od.decompress(ref[t][0], ref[t][1])
+        r2, out = gd.DecompressFrame(ref[t][0], ref[t][1])
+        assert r1 == 1 and r2 == 1
+        assert np.array_equal(out.reshape(h, pitch)[:, : w * 2], want.reshape(h, pitch)[:, : w * 2]), t
+        assert np.array_equal(out.reshape(h, pitch)[:, : w * 2], frames[t]), t
+
+
+def test_dense_table_arenas_stay_bounded_over_a_long_gop():
+    """A GOP that goes on over many calls (the reference's default key interval is 500, conf.h:7) must not make the
+    dense-table arenas grow with the number of calls: what a call reserves is what the live GOP really holds plus
+    what this call's packets can allocate.  One codec compresses AND decompresses here (separate arenas)."""
+    w, h, n = 96, 64, 400
+    rng = np.random.default_rng(17)
+    seq = DesktopSequence(w, h, seed=17, sparkles=30)
+    both = _codec(w, h)
+    ora = O.OracleCodec(w, h, 32)
+    sizes = []
+    for t in range(n):
+        f = seq.frame(t).copy()
+        if t % 7 == 3:  # a patch whose contexts go dense (many different bytes per context)
+            y0, x0 = int(rng.integers(0, h - 24)), int(rng.integers(0, w - 32))
+            f[y0:y0 + 24, x0:x0 + 32] = _chan0_noise(rng, 32, 24)
+        want, wft = ora.compress(f, key=(t == 0))
+        got, ft = both.CompressFrame(f, 0 if t == 0 else 1)
+        assert (got, ft) == (want, wft), t
+        r, out = both.DecompressFrame(got, ft)
+        assert r == 1 and np.array_equal(out.reshape(h, w, 4), f), t
+        if t in (50, n - 1):
+            sizes.append(both.debug_arena())
+    assert sizes[1][0] <= max(sizes[0][0], 4 << 20) and sizes[1][1] <= max(sizes[0][1], 4 << 20), sizes
+    assert max(sizes[1]) < 64 << 20, sizes  # (the old policy reserved 19 MB more per decoded P-frame: 7 GB by now)

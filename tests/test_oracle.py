@@ -277,3 +277,26 @@ def test_version2_range_coder_round_trip():
         r, out = dec.decompress(p, ft)
         assert r == 1 and np.array_equal(out.reshape(h, w, 4)[..., :3], f[..., :3]), t
     assert heads == [0x12, 0x01, 0x00, 0x11, 0x01, 0x01]
+
+
+def test_threaded_two_stage_shape_keeps_the_bytes():
+    """The CPU baseline's multi-thread form (row bands of a key frame on a pool, squad.cpp:116-130, and one coder thread
+    taking the full 131072-entry blocks, ransmt.h:92-105) must give the bytes of the one-thread form at the same
+    `workers`: key frames with several coder blocks, and P-frames behind them."""
+    from screenpressor_amd.synth import DesktopSequence
+    w, h, n = 640, 480, 4
+    fr = DesktopSequence(w, h, seed=5, noise_fraction=0.6).frames(n).reshape(n, -1)
+    for workers in (1, 4):
+        a = O.time_stream(fr, w, h, 32, 2, workers=workers, threads=1)
+        b = O.time_stream(fr, w, h, 32, 2, workers=workers, threads=4)
+        assert a["bad"] == 0 and b["bad"] == 0
+        assert a["fnv"] == b["fnv"] and list(a["sizes"]) == list(b["sizes"]) and a["sizes"].max() > 2 * 131072 // 4
+    enc = O.OracleCodec(w, h, 32, workers=4)
+    enc.set_threads(4)
+    one = O.OracleCodec(w, h, 32, workers=4)
+    f = DesktopSequence(w, h, seed=5, noise_fraction=0.6).frame(0)
+    assert enc.compress(f, key=True) == one.compress(f, key=True)
+    hv = 1469598103934665603  # (the checksum helper bench.py's parity field uses: same recurrence as spo_time_stream's)
+    for b in b"abc":
+        hv = ((hv ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    assert O.fnv1a(b"abc") == hv

@@ -27,16 +27,19 @@ c.Init(W, H, 32)
 IP = "--ip" in sys.argv  # one GOP: a key frame and n-1 P-frames (sections 5-7 of decode_inter_frame)
 pk, sizes, ft = c.CompressBatch(frames, [0] + [1] * (n - 1) if IP else [0] * n)
 L = K.load_library()
-out = (C.c_ulonglong * 8)()
+out = (C.c_ulonglong * 16)()
 L.scpr_debug_profile(out)
 r, dec = c.DecompressBatch(pk, sizes, ft)
 torch.cuda.synchronize()
 assert torch.equal(dec.reshape(-1), frames.reshape(-1))
 L.scpr_debug_profile(out)
-v = np.array(list(out), dtype=np.float64)
+ev = np.array(list(out)[8:], dtype=np.float64)
+v = np.array(list(out)[:8], dtype=np.float64)
 names = ["P", "colour", "N", "fill", "rows/loop", "P-frame: plane copy, header, block types", "P-frame: rect border + write-back, motion copies", "P-frame: runs"]
 tot = v.sum()
 print("ticks per frame: %.0f" % (tot / n))
 for nm, x in zip(names, v):
     if x:
         print("%-50s %5.1f %%   %.0f ticks/frame" % (nm, 100 * x / tot, x / n))
+for nm, x in zip(["colour symbols", "record cache misses", "dense-table symbols", "raw symbols", "small-table slow path", "runs", "literal runs", "run lengths above 63"], ev):
+    print("%-50s %.0f per frame" % (nm, x / n))
