@@ -1,76 +1,327 @@
 #!/usr/bin/env python3
-"""bench.py — MPix/s encode+decode on the BASELINE.json workload.
+"""bench.py - MPix/s encode+decode of the ScreenPressor hot path on MI355X.
 
   python bench.py --gpus N --steps K --warmup W
 
-Workload (config.workload): 1920x1080 RGB32, every frame a key frame, 300 frames per
-GPU (BASELINE.json configs[1]).  One step = one pass of the hot path over the batch:
-compress the 300 frames (resident in HBM) to packets in HBM, then decompress them back
-to RGB32 in HBM.  value = pixels of all ranks / max-over-ranks step time, i.e. the
-combined figure W*H*N/(t_enc+t_dec) of SURVEY.md §8d.  Multi-GPU: frames are sharded
-across ranks (weak scaling, one process per GPU); every step ends with the gather of the
-compressed chunks to rank 0 over RCCL.
+One step = one pass of the hot path over one batch resident in HBM: compress the frames to packets
+(scpr_compress_batch), decompress them back (scpr_decompress_batch), and - with more than one rank - gather
+the compressed chunks to rank 0 over RCCL.  value = pixels of all ranks / max-over-ranks step time
+(W*H*N / (t_enc + t_dec)).
+
+Workloads (config.workload names the one measured):
+  keys  BASELINE configs[1]: 1920x1080 RGB32, every frame a key frame, 300 frames per GPU - the default, at every N
+        (--bpp 24: configs[4]).  Multi-GPU: every rank its own 300 frames, weak scaling, no data-path collective
+        but the final gather (frames are independent units: the task's rule for paths that partition).
+  ip    configs[2]: the same frames, key frame every --gop frames.
+  c4    configs[3]: 3840x2160, ONE stream of 1200 frames with a key frame every 150, cut at key frames into one
+        contiguous GOP range per rank (screenpressor_amd.sharding.shard_gops), strong scaling.
+With N = 1 and no --no-others the line also carries config.others: configs[2] (K = 50 and one 300-frame GOP),
+configs[3]'s one-GPU share (4K x 150, as key frames and as one GOP) and configs[4], each with encode / decode /
+combined MPix/s, compressed bytes, sha256 of the stream, a bounded CPU sample and the parity flag against it.
+
+Launching: `--gpus N` with N > 1 and no WORLD_SIZE in the environment makes THIS process a launcher: it starts N
+ranks (one process per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set) before anything touches the GPU and
+relays rank 0's line.  Under `python -m torch.distributed.run` (WORLD_SIZE set) the process is a rank.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
-import numpy as np
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
-
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
+METRIC = "MPix/s encode+decode, 1080p/4K RGB32; bitstream byte-identical to ref"  # BASELINE.json's metric; see "parity" in the line for what was checked
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--frames", type=int, default=300)
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--cpu-frames", type=int, default=300, help="frames of the same workload timed on the host CPU (oracle): the default is the whole 300-frame workload, ~8 s of one core")
-    ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--workload", choices=["keys", "ip"], default="keys",
-                    help="keys: every frame a key frame (BASELINE configs[1], the headline); ip: key frame every --gop frames (configs[2])")
-    ap.add_argument("--gop", type=int, default=50)
+    ap.add_argument("--workload", choices=["keys", "ip", "c4"], default="keys")
+    ap.add_argument("--frames", type=int, default=None, help="frames per GPU (keys, ip: default 300) or of the whole stream (c4: default 1200)")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--bpp", type=int, choices=[32, 24], default=32, help="24: packed 3-byte pixels, rows padded to 4 bytes (BASELINE configs[4])")
-    args = ap.parse_args()
+    ap.add_argument("--gop", type=int, default=None, help="key frame interval (ip: default 50; c4: default 150)")
+    ap.add_argument("--cpu-frames", type=int, default=None, help="frames of the workload timed on the host CPU (default: the whole workload at 1080p keys, a bounded sample otherwise)")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-others", action="store_true", help="N = 1: do not measure the other single-GPU configs")
+    ap.add_argument("--selftest-launcher", action="store_true", help="no codec, no GPU: ranks exchange synthetic packets over gloo (tests the launcher, the sharding and the gather)")
+    return ap.parse_args(argv)
 
-    import torch
-    import torch.distributed as dist
-    from screenpressor_amd.codec import ScreenCodec
+
+# ------------------------------------------------------------------------------------------------ launcher ---
+def spawn_ranks(args, argv):
+    """the parent of a `--gpus N` run: starts N ranks and relays rank 0's JSON line; never touches the GPU itself"""
+    n = args.gpus
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
+
+
+# ------------------------------------------------------------------------------------------------ workloads ---
+def _render(job):
+    """worker of the frame pool (spawned processes: numpy only)"""
+    w, h, seed, bpp, t0, t1 = job
+    import numpy as np
+    sys.path.insert(0, ROOT)
     from screenpressor_amd.synth import DesktopSequence, pack24
+    seq = DesktopSequence(w, h, seed=seed)
+    return np.stack([np.ascontiguousarray(seq.frame(t) if bpp == 32 else pack24(seq.frame24(t))).reshape(-1) for t in range(t0, t1)])
 
+
+def make_frames(w, h, seed, bpp, t0, t1, dev=None):
+    """frames t0..t1-1 of the seeded synthetic desktop, rendered by a pool of host processes (a 4K frame takes
+    0.4 s of numpy); returned as one torch uint8 tensor (n, frame_bytes) on `dev` (or a numpy array)"""
+    import multiprocessing as mp
+    import numpy as np
+    n = t1 - t0
+    nproc = max(1, min(8, (os.cpu_count() or 2) // 2, n // 4))
+    pitch = w * 4 if bpp == 32 else (w * 3 + 3) & ~3
+    if dev is not None:
+        import torch
+        out = torch.empty((n, h * pitch), dtype=torch.uint8, device=dev)
+    else:
+        out = np.empty((n, h * pitch), dtype=np.uint8)
+    per = max(1, min(16, (n + nproc - 1) // nproc))  # frames per job (bounded: 16 4K frames are 0.5 GB through a pipe)
+    jobs = [(w, h, seed, bpp, a, min(t1, a + per)) for a in range(t0, t1, per)]
+
+    def put(a, block):
+        if dev is not None:
+            out[a - t0:a - t0 + len(block)] = torch.from_numpy(block).to(dev)
+        else:
+            out[a - t0:a - t0 + len(block)] = block
+    if nproc == 1:
+        for j in jobs:
+            put(j[4], _render(j))
+    else:
+        with mp.get_context("spawn").Pool(nproc) as pool:
+            for j, block in zip(jobs, pool.imap(_render, jobs)):
+                put(j[4], block)
+    return out
+
+
+class Workload:
+    """what one rank encodes: frames [lo, hi) of stream `seed`, with the caller's key-frame requests"""
+
+    def __init__(self, name, w, h, bpp, seed, lo, hi, ftypes, scaling, total_frames, note=""):
+        self.name, self.w, self.h, self.bpp, self.seed, self.lo, self.hi = name, w, h, bpp, seed, lo, hi
+        self.ftypes, self.scaling, self.total_frames, self.note = ftypes, scaling, total_frames, note
+        self.n = hi - lo
+        self.pitch = w * 4 if bpp == 32 else (w * 3 + 3) & ~3
+
+
+def describe(args, rank, world):
+    sys.path.insert(0, ROOT)
+    from screenpressor_amd.sharding import shard_gops
+    wl = args.workload
+    if wl == "c4":
+        w, h, total, k = args.width or 3840, args.height or 2160, args.frames or 1200, args.gop or 150
+        ft = [0 if t % k == 0 else 1 for t in range(total)]
+        lo, hi = shard_gops(ft, world)[rank]
+        name = (f"BASELINE configs[3]: {w}x{h} RGB{args.bpp}, one stream of {total} frames, key frame every {k}, cut at key frames into "
+                f"{world} contiguous GOP range(s), synthetic desktop seed 1")
+        return Workload(name, w, h, args.bpp, 1, lo, hi, ft[lo:hi], "strong", total)
+    w, h, n = args.width or 1920, args.height or 1080, args.frames or 300
+    if wl == "keys":
+        ft = [0] * n
+        name = f"BASELINE configs[{1 if args.bpp == 32 else 4}]: {w}x{h} RGB{args.bpp} key-frame-only (I-frames), {n} frames per GPU, synthetic desktop seed 1+rank"
+    else:
+        k = args.gop or 50
+        ft = [0 if t % k == 0 else 1 for t in range(n)]
+        name = f"BASELINE configs[2]: {w}x{h} RGB{args.bpp} I+P, key frame every {k}, {n} frames per GPU, synthetic desktop seed 1+rank"
+    return Workload(name, w, h, args.bpp, 1 + rank, 0, n, ft, "weak", n * world)
+
+
+# ------------------------------------------------------------------------------------------------ one config ---
+class Runner:
+    """codec pair + device buffers for one frame geometry; run() = timed passes of the hot path over a batch"""
+
+    def __init__(self, dev, local_rank, w, h, bpp, n):
+        import torch
+        from screenpressor_amd.codec import ScreenCodec
+        self.torch, self.dev, self.w, self.h, self.bpp, self.n = torch, dev, w, h, bpp, n
+        self.pitch = w * 4 if bpp == 32 else (w * 3 + 3) & ~3
+        self.enc = ScreenCodec(local_rank).Init(w, h, bpp)
+        self.dec = ScreenCodec(local_rank).Init(w, h, bpp)
+        self.packets = torch.empty(max(256 << 20, n * w * h // 2), dtype=torch.uint8, device=dev)
+        self.decoded = torch.empty(n * h * self.pitch, dtype=torch.uint8, device=dev)
+
+    def step(self, frames, ftypes, seed_args=None, after=None):
+        W, H, BPP = self.w, self.h, self.bpp
+        self.enc.Deinit(); self.enc.Init(W, H, BPP)
+        self.dec.Deinit(); self.dec.Init(W, H, BPP)
+        if seed_args:
+            self.enc.SeedShard(*seed_args)
+        t0 = time.perf_counter()
+        out, sizes, ft = self.enc.CompressBatch(frames, ftypes, out=self.packets)
+        t1 = time.perf_counter()
+        _, se = self.enc.last_timing()
+        r, dec = self.dec.DecompressBatch(out, sizes, ft, out=self.decoded)
+        t2 = time.perf_counter()
+        _, sd = self.dec.last_timing()
+        assert r == len(ftypes)
+        if after:
+            after(out, sizes)
+        return out, sizes, ft, dec, t1 - t0, t2 - t1, {k: v for k, v in list(se.items()) + list(sd.items()) if v > 0}
+
+
+def stream_sha256(packets_host):
+    return hashlib.sha256(packets_host.tobytes()).hexdigest()
+
+
+def cpu_sample(wl, frames_host, nf, gop, threads_all):
+    """the CPU port (oracle/libspo.so) over the first nf frames of the workload: the one-thread canonical run (workers = 1:
+    the stream the GPU is compared with) and, for key frames, the reference's two-stage shape on every host core
+    (workers = threads = cores: another, equally valid stream - the band count is bitstream-visible)"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_api as O
+    pix = nf * wl.w * wl.h / 1e6
+    one = O.time_stream(frames_host[:nf], wl.w, wl.h, wl.bpp, key_interval=gop, workers=1, threads=1)
+    assert one["bad"] == 0
+    res = {"one_thread": {"value": round(pix / (one["t_enc"] + one["t_dec"]), 2), "enc_MPix_s": round(pix / one["t_enc"], 2), "dec_MPix_s": round(pix / one["t_dec"], 2), "cores": 1, "workers": 1}}
+    if threads_all and threads_all > 1:
+        nfa = max(1, min(nf, 100))
+        allc = O.time_stream(frames_host[:nfa], wl.w, wl.h, wl.bpp, key_interval=gop, workers=threads_all, threads=threads_all)
+        assert allc["bad"] == 0
+        pa = nfa * wl.w * wl.h / 1e6
+        res["all_cores"] = {"value": round(pa / (allc["t_enc"] + allc["t_dec"]), 2), "enc_MPix_s": round(pa / allc["t_enc"], 2), "dec_MPix_s": round(pa / allc["t_dec"], 2),
+                            "cores": threads_all, "workers": threads_all, "frames": nfa,
+                            "shape": "row bands of a key frame on a pool of `cores` threads + one rANS thread (squad.cpp:116-130, ransmt.h:92-105); the model stage and the whole decoder are one thread, as in the reference"}
+    return one, res
+
+
+def parity_of(packets_host, sizes, one, nf):
+    """packets of the first nf frames against the oracle's (size and FNV-1a of every packet)"""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_api as O
+    offs = np.concatenate([[0], np.cumsum(np.asarray(sizes, dtype=np.int64))])
+    ok = [int(s) for s in sizes[:nf]] == [int(s) for s in one["sizes"][:nf]]
+    if ok:
+        for t in range(nf):
+            if O.fnv1a(packets_host[offs[t]:offs[t + 1]]) != int(one["frame_fnv"][t]):
+                ok = False
+                break
+    return ok
+
+
+def measure(runner, wl, frames, steps, warmup, barrier=None, seed_args=None, after=None):
+    tor = runner.torch
+    for _ in range(warmup):
+        runner.step(frames, wl.ftypes, seed_args, after)
+    if barrier:
+        barrier()
+    acc, te, td = {}, 0.0, 0.0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out, sizes, ft, dec, a, b, st = runner.step(frames, wl.ftypes, seed_args, after)
+        te, td = te + a, td + b
+        for k, v in st.items():
+            acc[k] = acc.get(k, 0.0) + v
+    if barrier:
+        barrier()
+    else:
+        tor.cuda.synchronize(runner.dev)
+    elapsed = time.perf_counter() - t0
+    assert bool(tor.equal(dec.reshape(wl.n, -1), frames)), "the decoded frames differ from the input: the round trip is not lossless"
+    return dict(out=out, sizes=sizes, ft=ft, elapsed=elapsed, t_enc=te / steps, t_dec=td / steps, stage_ms={k: v / steps for k, v in acc.items()})
+
+
+def other_config(runner_cache, dev, local_rank, label, wl, frames, gop, cpu_frames, no_cpu, golden=None):
+    """one of the single-GPU configs that is not the headline: 1 warm-up + 1 timed pass, CPU sample, parity"""
+    key = (wl.w, wl.h, wl.bpp)
+    if key not in runner_cache or runner_cache[key].n < wl.n:
+        runner_cache[key] = Runner(dev, local_rank, wl.w, wl.h, wl.bpp, wl.n)
+    r = measure(runner_cache[key], wl, frames, 1, 1)
+    host = r["out"].cpu().numpy()
+    pix = wl.n * wl.w * wl.h / 1e6
+    res = {"config": label, "workload": wl.name, "frames": wl.n, "enc_MPix_s": round(pix / r["t_enc"], 1), "dec_MPix_s": round(pix / r["t_dec"], 1),
+           "combined_MPix_s": round(pix / (r["t_enc"] + r["t_dec"]), 1), "compressed_bytes": int(host.size), "sha256": stream_sha256(host), "lossless_roundtrip": True,
+           "stage_ms": {k: round(v, 2) for k, v in r["stage_ms"].items()}}
+    if golden:
+        res["golden"] = golden(host, r["sizes"])
+    if not no_cpu:
+        nf = min(cpu_frames, wl.n)
+        one, cpu = cpu_sample(wl, frames[:nf].cpu().numpy(), nf, gop, 0)
+        res["cpu_baseline"] = dict(cpu["one_thread"], sample=f"first {nf} frames, oracle/libspo.so, one thread")
+        res["parity"] = {"vs": "oracle (CPU restatement; pinned to the reference only for rANS)", "frames_checked": nf, "ok": parity_of(host, r["sizes"], one, nf)}
+    return res
+
+
+# ------------------------------------------------------------------------------------------------ a rank ---
+def selftest_rank(args, rank, world):
+    """launcher / sharding / gather without a codec (CPU, gloo): every rank makes the synthetic packets of its GOP range"""
+    import numpy as np
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from screenpressor_amd.sharding import gather_packets, shard_gops
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    total, k = args.frames or 24, args.gop or 4
+    ft = [0 if t % k == 0 else 1 for t in range(total)]
+    lo, hi = shard_gops(ft, world)[rank]
+    pk = [bytes([(7 * t + j) & 255 for j in range(5 + t % 3)]) for t in range(lo, hi)]
+    payload = np.frombuffer(b"".join(pk), dtype=np.uint8).copy()
+    sizes = [len(p) for p in pk]
+    if world > 1:
+        out_p, out_s = gather_packets(dist, rank, world, payload, sizes)
+    else:
+        out_p, out_s = payload, sizes
+    if rank == 0:
+        blob = bytes(np.asarray(out_p).tobytes()) if not hasattr(out_p, "numpy") else out_p.numpy().tobytes()
+        want = b"".join(bytes([(7 * t + j) & 255 for j in range(5 + t % 3)]) for t in range(total))
+        print(json.dumps({"selftest": "launcher", "n_gpus": world, "frames": total, "ranges": shard_gops(ft, world), "gathered_ok": blob == want,
+                          "sizes_ok": [int(s) for s in (out_s.tolist() if hasattr(out_s, "tolist") else out_s)] == [5 + t % 3 for t in range(total)]}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+def run_rank(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.selftest_launcher:
+        return selftest_rank(args, rank, world)
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from screenpressor_amd.sharding import gather_packets
+
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        world = dist.get_world_size()  # the ranks RCCL actually has
     dev = torch.device("cuda", local_rank)
-    W, H, N = args.width, args.height, args.frames
+    wl = describe(args, rank, world)
+    W, H, BPP, N = wl.w, wl.h, wl.bpp, wl.n
+    gop = 1 if args.workload == "keys" else (args.gop or (50 if args.workload == "ip" else 150))
 
-    # synthetic input, resident in HBM before the timed region (rank r: its own seed/shard)
-    seq = DesktopSequence(W, H, seed=1 + rank)
-    BPP = args.bpp
-    pitch = W * 4 if BPP == 32 else (W * 3 + 3) & ~3
-    frames = torch.empty((N, H * pitch), dtype=torch.uint8, device=dev)
-    for t in range(N):
-        f = seq.frame(t) if BPP == 32 else pack24(seq.frame24(t))
-        frames[t] = torch.from_numpy(np.ascontiguousarray(f).reshape(-1)).to(dev)
-    codec_e = ScreenCodec(local_rank).Init(W, H, BPP)
-    codec_d = ScreenCodec(local_rank).Init(W, H, BPP)
-    packets = torch.empty(max(256 << 20, N * W * H // 2), dtype=torch.uint8, device=dev)
-    decoded = torch.empty(N * H * pitch, dtype=torch.uint8, device=dev)
-    ftypes = [0] * N if args.workload == "keys" else [0 if t % args.gop == 0 else 1 for t in range(N)]
+    # synthetic input, resident in HBM before the timed region
+    frames = make_frames(W, H, wl.seed, BPP, wl.lo, wl.hi, dev)
+    runner = Runner(dev, local_rank, W, H, BPP, N)
+    seed_args = (wl.lo, False, 0) if wl.lo else None  # a shard that does not start the stream (the synthetic desktop has no flat frames)
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -78,103 +329,141 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    stage_acc, t_enc_acc, t_dec_acc, comp_bytes = {}, 0.0, 0.0, 0
+    gathered = {}
 
-    def step(timed):
-        nonlocal t_enc_acc, t_dec_acc, comp_bytes
-        codec_e.Deinit(); codec_e.Init(W, H, BPP)
-        codec_d.Deinit(); codec_d.Init(W, H, BPP)
-        t0 = time.perf_counter()
-        out, sizes, ft = codec_e.CompressBatch(frames, ftypes, out=packets)
-        t1 = time.perf_counter()
-        te, se = codec_e.last_timing()
-        r, dec = codec_d.DecompressBatch(out, sizes, ft, out=decoded)
-        t2 = time.perf_counter()
-        td, sd = codec_d.last_timing()
-        assert r == N
-        if world > 1:  # exchange step: compressed chunks + sizes to rank 0, frame order (RCCL over xGMI)
-            from screenpressor_amd.sharding import gather_packets
-            gather_packets(dist, rank, world, out, sizes, device=dev)
-        if timed:
-            t_enc_acc += t1 - t0
-            t_dec_acc += t2 - t1
-            comp_bytes = int(out.numel())
-            for k, v in list(se.items()) + list(sd.items()):
-                if v > 0:
-                    stage_acc[k] = stage_acc.get(k, 0.0) + v
-        return out, sizes, dec
+    def exchange(out, sizes):  # the exchange step: compressed chunks + sizes to rank 0 in frame order (RCCL over xGMI)
+        if world > 1:
+            gathered["p"], gathered["s"] = gather_packets(dist, rank, world, out, sizes, device=dev)
 
-    for _ in range(args.warmup):
-        step(False)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out, sizes, dec = step(True)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    lossless = bool(torch.equal(dec.reshape(N, -1), frames))
-
-    tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    m = measure(runner, wl, frames, args.steps, args.warmup, barrier, seed_args, exchange)
+    tmax = torch.tensor([m["elapsed"]], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
     ms_per_step = elapsed / args.steps * 1e3
-    value = world * N * W * H / 1e6 / (elapsed / args.steps)
+    total_frames = wl.total_frames
+    value = total_frames * W * H / 1e6 / (elapsed / args.steps)
 
     if rank == 0:
-        # dominant kernel stage by device time (HIP events on the codec's stream, scpr_last_timing)
-        per_step = {k: v / args.steps for k, v in stage_acc.items()}
+        host = m["out"].cpu().numpy()
+        comp_bytes = int(host.size)
+        per_step = m["stage_ms"]
         dom = max(per_step, key=per_step.get)
-        raw = N * H * pitch
-        # algorithmic bytes per SURVEY.md §8(d): encode I = raw + c, decode I = c + raw, per frame
-        alg_bytes = raw + comp_bytes if args.workload == "keys" else 2 * raw + comp_bytes  # P-frames also read the previous frame
+        raw = N * H * wl.pitch
+        # algorithmic bytes per SURVEY.md 8(d): encode I = raw + c, encode P = 2 raw + c; decode I = c + raw, decode P = c + 2 raw
+        np_frames = sum(1 for f in m["ft"] if f)
+        is_dec = dom in ("decode", "unpack")
+        alg_bytes = raw + comp_bytes + np_frames * H * wl.pitch
         dom_ms = per_step[dom]
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
-        # HBM bytes per launch of that kernel from the PMC passes recorded under profiles/ (rocprofv3 --pmc
-        # FETCH_SIZE / WRITE_SIZE in separate runs of this same command, FETCH doubled for gfx950); only
-        # quoted when the recorded run used this workload
-        traffic = None
-        kernel_of = {"decode": "k_decode_gop_w", "rans": "k_rans", "colour_chain": "k_colour_chain_w", "pack": "k_pack32"}
+        # HBM bytes per launch of that kernel: PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+        # separate runs, FETCH doubled for gfx950), recorded under profiles/; quoted only for the workload they were taken on
+        traffic, traffic_src = None, None
+        kernel_of = {"decode": "k_decode_gop_w", "rans": "k_rans", "colour_chain": "k_colour_chain_w", "pack": "k_pack32", "classify": "k_tiles"}
         try:
             import glob
-            rec = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")))[-1]))  # the latest recorded pass
-            if args.workload == "keys" and N == 300 and (W, H) == (1920, 1080):
+            recs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")))
+            rec = json.load(open(recs[-1]))
+            if args.workload == "keys" and N == 300 and (W, H, BPP) == (1920, 1080, 32):
                 for kq in rec["kernels"]:
                     if kernel_of.get(dom, "?") in kq["kernel"]:
-                        traffic = round(kq["hbm_bytes_per_launch"])
+                        traffic, traffic_src = round(kq["hbm_bytes_per_launch"]), os.path.relpath(recs[-1], ROOT) + " (recorded rocprofv3 --pmc passes of this command)"
         except Exception:
             traffic = None
-        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "launch_ms": round(dom_ms, 3),
+        roofline = {"bound": "hbm", "kernel": kernel_of.get(dom, dom), "stage": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src, "launch_ms": round(dom_ms, 3),
                     "algorithmic_bytes_per_launch": alg_bytes,
-                    "note": "the dominant kernel is a serial per-GOP chain (issue-bound), not bandwidth-shaped; see DESIGN.md §5"}
+                    "note": ("the dominant kernel is a serial per-GOP chain (issue/latency-bound), not bandwidth-shaped; see DESIGN.md" if is_dec else "see DESIGN.md for what bounds this stage")}
+        parity = {"vs": "oracle (CPU restatement of the reference; pinned to the reference itself only for rANS, see DESIGN.md 1)", "ok": None,
+                  "lossless_roundtrip": True, "sha256": stream_sha256(host), "compressed_bytes": comp_bytes}
+        if (args.workload, W, H, wl.seed) == ("keys", 1920, 1080, 1) and N >= 3:  # the committed fixture holds the hashes of the first three packets
+            try:
+                man = json.load(open(os.path.join(ROOT, "tests", "golden", "manifest.json")))["desktop_1080p_keys" if BPP == 32 else "desktop_1080p_rgb24"]
+                offs = np.concatenate([[0], np.cumsum(m["sizes"].astype(np.int64))])
+                parity["golden_fixture_ok"] = all(hashlib.sha256(host[offs[t]:offs[t + 1]].tobytes()).hexdigest() == man["frame_sha256"][t] for t in range(3))
+            except Exception as e:  # noqa: BLE001
+                parity["golden_fixture_ok"] = f"not checked: {e}"
         cpu = None
         if not args.no_cpu and world == 1:  # the CPU baseline is a rank-0, one-GPU measurement
-            import oracle_api as O
-            nf = min(args.cpu_frames, N)
-            sample = np.stack([np.ascontiguousarray(seq.frame(t) if BPP == 32 else pack24(seq.frame24(t))).reshape(-1) for t in range(nf)])
-            r = O.time_stream(sample, W, H, BPP, key_interval=1 if args.workload == "keys" else args.gop)
-            assert r["bad"] == 0
-            cpu = {"value": round(nf * W * H / 1e6 / (r["t_enc"] + r["t_dec"]), 2), "unit": "MPix/s", "cores": 1, "kind": "port",
-                   "sample": (f"the whole workload ({nf} frames)" if nf == N else f"first {nf} frames of the same workload") + ", encode+decode, oracle/libspo.so (single thread)",
-                   "enc_MPix_s": round(nf * W * H / 1e6 / r["t_enc"], 2), "dec_MPix_s": round(nf * W * H / 1e6 / r["t_dec"], 2)}
-        line = {
-            "metric": "MPix/s encode+decode, 1080p RGB32; bitstream byte-identical to ref", "value": round(value, 2), "unit": "MPix/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": (f"{W}x{H} RGB{BPP} key-frame-only (I-frames), {N} frames per GPU, synthetic desktop seed 1+rank" if args.workload == "keys"
-                                    else f"{W}x{H} RGB{BPP} I+P (key frame every {args.gop}), {N} frames per GPU, synthetic desktop seed 1+rank"),
-                       "frames_per_gpu": N, "parallelism": f"frame-sharded x{world}", "lossless_roundtrip": lossless,
-                       "compressed_bytes_per_gpu": comp_bytes,
-                       "enc_MPix_s_rank0": round(N * W * H / 1e6 / (t_enc_acc / args.steps), 2),
-                       "dec_MPix_s_rank0": round(N * W * H / 1e6 / (t_dec_acc / args.steps), 2),
-                       "stage_ms_per_step": {k: round(v, 3) for k, v in per_step.items()}},
-            "roofline": roofline, "cpu_baseline": cpu,
-        }
+            big = W * H > 1920 * 1080 or args.workload != "keys"
+            nf = min(args.cpu_frames or (40 if big else N), N)
+            ncores = os.cpu_count() or 1
+            one, res = cpu_sample(wl, frames[:nf].cpu().numpy(), nf, gop, ncores if args.workload == "keys" else 0)
+            parity["ok"] = parity_of(host, m["sizes"], one, nf)
+            parity["frames_checked"] = nf
+            best = res.get("all_cores", res["one_thread"])
+            if res["one_thread"]["value"] >= best["value"]:
+                best = res["one_thread"]
+            cpu = {"value": best["value"], "unit": "MPix/s", "cores": best["cores"], "kind": "port",
+                   "sample": (f"the whole workload ({nf} frames)" if nf == N else f"first {nf} frames of the same workload") + ", encode+decode, oracle/libspo.so; "
+                   "`value` is the faster of one thread and the all-cores two-stage shape", "host_cores": ncores, **res}
+            assert parity["ok"], "the packets of the timed run differ from the oracle's"
+        config = {"workload": wl.name, "frames_per_gpu": N, "frames_total": total_frames, "parallelism": f"GOP/frame-sharded x{world}, one process per GPU",
+                  "compressed_bytes_rank0": comp_bytes,
+                  "enc_MPix_s_rank0": round(N * W * H / 1e6 / m["t_enc"], 2), "dec_MPix_s_rank0": round(N * W * H / 1e6 / m["t_dec"], 2),
+                  "stage_ms_per_step": {k: round(v, 3) for k, v in per_step.items()}}
+        if world > 1 and gathered.get("s") is not None:
+            config["gathered_frames_rank0"] = int(gathered["s"].numel())
+            config["gathered_bytes_rank0"] = int(gathered["p"].numel())
+        if world == 1:
+            # the boundary hands over host buffers (ScreenCodec::CompressFrame takes host pointers, screencap.cpp:1632): the
+            # same pass with the frames coming from and going back to pinned host memory, packets crossing both ways
+            try:
+                h_in = frames.cpu().pin_memory()
+                h_pk = torch.empty(comp_bytes, dtype=torch.uint8).pin_memory()
+                h_out = torch.empty_like(h_in).pin_memory()
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                d_in = h_in.to(dev, non_blocking=True)
+                out, sizes, ft, dec, _, _, _ = runner.step(d_in, wl.ftypes)
+                h_pk.copy_(out, non_blocking=True)
+                h_out.copy_(dec.reshape(N, -1), non_blocking=True)
+                torch.cuda.synchronize(dev)
+                config["incl_host_transfer_MPix_s"] = round(N * W * H / 1e6 / (time.perf_counter() - t0), 1)
+                del h_in, h_out, d_in
+            except Exception as e:  # noqa: BLE001
+                config["incl_host_transfer_MPix_s"] = f"not measured: {e}"
+        if world == 1 and not args.no_others and args.workload == "keys" and (W, H, BPP) == (1920, 1080, 32) and not args.frames:
+            others, cache = [], {(W, H, BPP): runner}
+            cf = args.cpu_frames or 60
+
+            def sub(label, w, h, bpp, n, ft, fr, k, cpu_n):
+                owl = Workload(label, w, h, bpp, 1, 0, n, ft, "weak", n)
+                try:
+                    others.append(other_config(cache, dev, local_rank, label, owl, fr, k, cpu_n, args.no_cpu))
+                except Exception as e:  # noqa: BLE001
+                    others.append({"config": label, "error": repr(e)})
+            sub("configs[2]: 1920x1080 RGB32 I+P, key frame every 50 (6 GOPs), 300 frames", W, H, 32, N, [0 if t % 50 == 0 else 1 for t in range(N)], frames, 50, cf)
+            sub("configs[2] as ONE GOP: key frame 0 then 299 P-frames (the reference's default key interval is 500, conf.h:7)", W, H, 32, N, [0] + [1] * (N - 1), frames, N, cf)
+            f24 = make_frames(W, H, 1, 24, 0, N, dev)
+            sub("configs[4]: 1920x1080 RGB24 (3-byte pixels, pitch 5760) key-frame-only, 300 frames", W, H, 24, N, [0] * N, f24, 1, cf)
+            others[-1]["stream_equals_rgb32_stream"] = others[-1].get("sha256") == parity["sha256"]
+            del f24
+            del frames
+            runner.packets = runner.decoded = None
+            cache.clear()
+            torch.cuda.empty_cache()
+            f4k = make_frames(3840, 2160, 1, 32, 0, 150, dev)
+            sub("configs[3], one GPU's share of 8: 3840x2160 RGB32, 150 frames as key frames (a frame-sharded stream)", 3840, 2160, 32, 150, [0] * 150, f4k, 1, 10)
+            sub("configs[3], one GPU's share of 8: 3840x2160 RGB32, ONE GOP of 150 frames (key frame every 150)", 3840, 2160, 32, 150, [0] + [1] * 149, f4k, 150, 10)
+            config["others"] = others
+        line = {"metric": METRIC, "value": round(value, 2), "unit": "MPix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+                "higher_is_better": True, "scaling": wl.scaling, "vs_baseline": None, "dtype": "u8", "data": "synthetic", "config": config,
+                "roofline": roofline, "cpu_baseline": cpu, "parity": parity}
         print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+    return 0
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args, argv)  # (before anything imports torch or touches the GPU)
+    return run_rank(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -109,6 +109,7 @@ struct scpr_codec {
   // decoder side of the same
   DevBuf decgops, decfixed, dec_fixed_persist, dec_colour_persist, dec_arena, dec_arena_top;  // (its own dense-table arena: one codec may compress and decompress)
   bool dec_live = false;
+  u32 h_dec_top0 = 1;
   size_t dec_arena_used = 1;  // tables held by the live GOP of the decoder (table 0 is the sink of an overflowing run, never a real table)
   // second stream: the fixed-model chains run beside the colour chains (they write disjoint entries)
   hipStream_t stream2 = nullptr;
@@ -823,12 +824,12 @@ int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* 
       }
       // Tables this chunk can allocate: a context goes dense once, after at least 16 of its symbols of which 15 came
       // as raw bytes (ans_contexts.cpp:3-31), so never more than packet bytes / 15, nor than 12288 per GOP.
-      const size_t worst = v2 ? 0 : std::min<size_t>(ng * (size_t)NCOLCTX, (size_t)(gop_bytes / 15) + ng);
+      const size_t worst = v2 ? 0 : std::min<size_t>(ng * (size_t)NCOLCTX, (size_t)(gop_bytes / 15) + 8 * ng);
       const size_t budget = attempt ? worst : std::min<size_t>(worst, ng * 1024);
       const size_t arena_cap = c->dec_arena_used + budget + 64;
       HIPCHK(c->dec_arena.reserve_keep(arena_cap * sizeof(DenseTab), c->dec_arena_used * sizeof(DenseTab), st));
-      const u32 top0 = (u32)c->dec_arena_used;
-      HIPCHK(hipMemcpyAsync(c->dec_arena_top.p, &top0, 4, hipMemcpyHostToDevice, st));
+      c->h_dec_top0 = (u32)c->dec_arena_used;  // (a member: the source of an asynchronous copy must outlive the call)
+      HIPCHK(hipMemcpyAsync(c->dec_arena_top.p, &c->h_dec_top0, 4, hipMemcpyHostToDevice, st));
       HIPCHK(hipMemcpyAsync(c->decframes.p, fr.data(), fr.size() * sizeof(DecFrame), hipMemcpyHostToDevice, st));
       HIPCHK(hipMemcpyAsync(c->decgops.p, gops.data(), ng * sizeof(DecGop), hipMemcpyHostToDevice, st));
       Arena ar{c->dec_arena.as<DenseTab>(), c->dec_arena_top.as<u32>(), (u32)arena_cap, c->err.as<u32>()};

@@ -217,3 +217,20 @@ def test_gpu_shard_seed_reproduces_the_single_stream_across_a_flat_boundary():
     for (p, ft), f in zip(got, frames):
         r, out = dec.DecompressFrame(p, ft)
         assert r == 1 and np.array_equal(out.reshape(h, w, 4), f)
+
+
+def test_bench_launcher_spawns_ranks_and_gathers_in_frame_order():
+    """`python bench.py --gpus 2` without WORLD_SIZE must itself start two ranks (one process per GPU) before anything
+    touches a GPU; here the ranks run the launcher's self-test (no codec: synthetic packets, gloo)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    for n in (2, 3):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--selftest-launcher", "--frames", "24", "--gop", "4"],
+                           capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = json.loads(r.stdout.strip().splitlines()[-1])
+        assert line["n_gpus"] == n and line["gathered_ok"] and line["sizes_ok"], line
+        assert line["ranges"][0][0] == 0 and line["ranges"][-1][1] == 24 and all(lo % 4 == 0 for lo, _ in line["ranges"])
