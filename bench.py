@@ -387,7 +387,11 @@ def run_rank(args):
         if not args.no_cpu and world == 1:  # the CPU baseline is a rank-0, one-GPU measurement
             big = W * H > 1920 * 1080 or args.workload != "keys"
             nf = min(args.cpu_frames or (40 if big else N), N)
-            ncores = os.cpu_count() or 1
+            try:
+                ncores = len(os.sched_getaffinity(0))  # the cores this process may run on, not the machine's
+            except Exception:  # noqa: BLE001
+                ncores = os.cpu_count() or 1
+            ncores = min(ncores, 16)  # the GPU box gives one GPU's share of its host: 16 cores
             one, res = cpu_sample(wl, frames[:nf].cpu().numpy(), nf, gop, ncores if args.workload == "keys" else 0)
             parity["ok"] = parity_of(host, m["sizes"], one, nf)
             parity["frames_checked"] = nf

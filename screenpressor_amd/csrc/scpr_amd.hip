@@ -105,12 +105,14 @@ struct scpr_codec {
   bool live_has_state = false;  // ... and it has coded symbols (a flat frame renews the models without coding any)
   u32 live_stamp = 0, next_stamp = 1;
   int live_buf = 0;  // which half of fixed_persist / misc_persist / colour_persist holds the live generation
-  size_t arena_used_bound = 0;  // upper bound of dense tables held by the live generation
+  size_t arena_used_bound = 0;  // dense tables held by the live generation (the arena top read back after every call)
+  size_t live_symbols = 0;      // colour symbols coded so far in the live generation (a bound on the tables it can own)
   // decoder side of the same
   DevBuf decgops, decfixed, dec_fixed_persist, dec_colour_persist, dec_arena, dec_arena_top;  // (its own dense-table arena: one codec may compress and decompress)
   bool dec_live = false;
   u32 h_dec_top0 = 1;
   size_t dec_arena_used = 1;  // tables held by the live GOP of the decoder (table 0 is the sink of an overflowing run, never a real table)
+  u64 dec_live_bytes = 0;     // packet bytes of the live GOP so far (a bound on the tables it can own)
   // second stream: the fixed-model chains run beside the colour chains (they write disjoint entries)
   hipStream_t stream2 = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -231,9 +233,11 @@ static int ensure_codec(scpr_codec* c, int version) {  // CreateCodec + CScreenC
   c->next_stamp = 1;
   c->live_buf = 0;
   c->arena_used_bound = 0;
+  c->live_symbols = 0;
   HIPCHK(c->arena_top.reserve(16));
   HIPCHK(c->dec_arena_top.reserve(16));
   c->dec_arena_used = 1;
+  c->dec_live_bytes = 0;
   HIPCHK(c->err.reserve(64));
   HIPCHK(c->total64.reserve(16));
   // reciprocal table for every frequency on the 12-bit scale
@@ -366,11 +370,16 @@ static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int n
   // dense-table arena: tables of the live generation stay valid while it continues
   if (!load_first) {
     c->arena_used_bound = 0;
+    c->live_symbols = 0;
     HIPCHK(hipMemsetAsync(c->arena_top.p, 0, 4, st));
   }
-  const size_t arena_cap = c->arena_used_bound + Ctot / 16 + 64;
+  // A context gets its table once, after at least 16 of its symbols (ans_contexts.cpp:3-50) - counted over the whole
+  // generation, not over this call: a context may meet its 16th symbol here after 15 in earlier calls.  So the tables
+  // alive at the end of this call are at most (symbols of the live generation so far + this call's) / 16, and 12288 per generation.
+  c->live_symbols += Ctot;
+  const size_t arena_cap = std::max(c->arena_used_bound, std::min<size_t>((size_t)ngens * NCOLCTX, c->live_symbols / 16 + (size_t)ngens)) + 64;
   HIPCHK(c->arena.reserve_keep(arena_cap * sizeof(DenseTab), c->arena_used_bound * sizeof(DenseTab), st));
-  c->arena_used_bound = arena_cap;
+  if (ngens > 1) c->live_symbols = Ctot;  // (an upper bound for the generation that is live after this call)
   c->dbg_entries = (int64_t)Ttot;
 
   stage_begin(c, ST_SYMBOLS);
@@ -722,7 +731,7 @@ int64_t scpr_compress_batch(scpr_codec* c, const void* d_frames, int nframes, in
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipGetLastError());  // a kernel that could not be launched (the launches themselves are not checked one by one)
     timing_collect(c);
-    c->arena_used_bound = std::min<size_t>(c->arena_used_bound, atop);  // what the live generation really holds: the arena does not grow with the number of calls
+    c->arena_used_bound = atop;  // what the arena really holds: it does not grow with the number of calls
     if (err & 2) return SCPR_E_CAPACITY;
     if (err & 1) {
       fprintf(stderr, "[scpr] dense-table arena overflow\n");
@@ -821,12 +830,15 @@ int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* 
         HIPCHK(hipMemcpyAsync(c->decfixed.p, c->dec_fixed_persist.p, blob_bytes, hipMemcpyDeviceToDevice, st));
       } else {
         c->dec_arena_used = 1;
+        c->dec_live_bytes = 0;
       }
-      // Tables this chunk can allocate: a context goes dense once, after at least 16 of its symbols of which 15 came
-      // as raw bytes (ans_contexts.cpp:3-31), so never more than packet bytes / 15, nor than 12288 per GOP.
-      const size_t worst = v2 ? 0 : std::min<size_t>(ng * (size_t)NCOLCTX, (size_t)(gop_bytes / 15) + 8 * ng);
-      const size_t budget = attempt ? worst : std::min<size_t>(worst, ng * 1024);
-      const size_t arena_cap = c->dec_arena_used + budget + 64;
+      // Tables alive at the end of this chunk: a context goes dense once, after at least 16 of its symbols, each of which cost
+      // the stream about a byte or more (raw bytes while nothing repeats, one-slot intervals of a small table after that:
+      // ans_contexts.cpp:3-50) - counted over the whole GOP, earlier calls included - and never more than 12288 per GOP.
+      const size_t worst = v2 ? 0 : std::min<size_t>(ng * (size_t)NCOLCTX, (size_t)((c->dec_live_bytes + gop_bytes) / 12) + 8 * ng);
+      // (a chunk that continues a GOP is not decoded twice: its run changes the tables that GOP already owns)
+      const size_t budget = (attempt || cont) ? worst : std::min<size_t>(worst, ng * 1024);
+      const size_t arena_cap = std::max<size_t>(c->dec_arena_used, 1 + budget) + 64;
       HIPCHK(c->dec_arena.reserve_keep(arena_cap * sizeof(DenseTab), c->dec_arena_used * sizeof(DenseTab), st));
       c->h_dec_top0 = (u32)c->dec_arena_used;  // (a member: the source of an asynchronous copy must outlive the call)
       HIPCHK(hipMemcpyAsync(c->dec_arena_top.p, &c->h_dec_top0, 4, hipMemcpyHostToDevice, st));
@@ -863,7 +875,7 @@ int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* 
     if (ng) HIPCHK(hipMemcpyAsync(&atop, c->dec_arena_top.p, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));  // also covers fr / gops (host memory)
     HIPCHK(hipGetLastError());         // a kernel that could not be launched
-    if ((errv[0] & 1) && attempt == 0) continue;  // the arena was too small for this stream: once more with the worst case
+    if ((errv[0] & 1) && attempt == 0 && !(ng && gops[0].load)) continue;  // the arena was too small for this stream: once more with the worst case
     if (ng && !(errv[0] & 5)) {
       // keep the state of the last GOP for the next call; with one GOP in the chunk its tables stay where they are
       // (top read back: the arena does not grow with the number of calls), with several the next call's first
@@ -874,6 +886,7 @@ int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* 
       HIPCHK(hipMemcpyAsync(c->dec_colour_persist.p, (const u8*)c->decstates.p + (ng - 1) * state_bytes, state_bytes, hipMemcpyDeviceToDevice, st));
       HIPCHK(hipMemcpyAsync(c->dec_fixed_persist.p, (const u8*)c->decfixed.p + (ng - 1) * blob_bytes, blob_bytes, hipMemcpyDeviceToDevice, st));
       c->dec_arena_used = std::max<size_t>(atop, 1);
+      c->dec_live_bytes = ng > 1 ? gop_bytes : c->dec_live_bytes + gop_bytes;  // (an upper bound for the GOP that is live after this chunk)
       c->dec_live = true;
     }
     break;

@@ -61,6 +61,7 @@ struct WaveDecV2 {
   __device__ __forceinline__ void stamp() {}
   template <int EV>
   __device__ __forceinline__ void event() {}
+  __device__ __forceinline__ void prefetch_n() {}
 
   __device__ __forceinline__ u32 fetch_word(u32 i) {
     const u32 m = i < wmax ? i : wmax;

@@ -92,7 +92,12 @@ constexpr int DECREC_WORDS = 20;
 // words per run-length table: 256 entries (freq | cum << 16), the running total at 256, padding, and the 256 counts from
 // NTAB_CNT on (the lane that holds an entry reaches its count and lane 0 the total with a constant offset from one address)
 constexpr int NTAB_STRIDE = 640, NTAB_CNT = 320;
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 struct FixedLds {
+  // entries of symbols 0..63 of the run-length tables 0, 1, 2 and 5 (literal, previous pixel, pixel above, above-left: almost
+  // every run), symbol j in nq[j]: ONE 16-byte read per lane, asked for before the pixel type is decoded, brings what the
+  // run-length lookup needs whichever of the four types comes out (a copy of ntab[t][0..63], rewritten with it)
+  u32x4 nq[64];
   u32 ntab[6][NTAB_STRIDE];
   u32 mfc[2][512];
   u32 mcnt[2][512];
@@ -130,7 +135,6 @@ struct ColHdr {
 // per symbol and saves the prefix scan.  Counts and P stay below 4096 (the total does).
 // Unused lanes hold kSmallNone: count 0 and a start above every coder value.
 constexpr u32 kSmallNone = 0xFFF000FFu;
-typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ int dpp_row_shr1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true); }
 __device__ __forceinline__ u32 sm_sym(u32 w) { return w & 255u; }
 __device__ __forceinline__ u32 sm_fq(u32 w) { return (w >> 8) & 4095u; }
@@ -546,6 +550,14 @@ struct WaveDec : WaveModel {
   int ndec = 0;
   // pixel-type tables (ptypetab) in registers: table t in lanes 8t..8t+5 (entries) and 8t+7 (the running total, in pcnt)
   u32 pfc = 0xFFFFFFFFu, pcnt = 0;
+  // run-length tables: lane 2t holds where symbol 64 of table t starts (everything below it is found among the first 64
+  // entries), lane 2t+1 the table's running total; nq = this lane's FixedLds::nq row as last asked for (prefetch_n)
+  u32 nscal = 0;
+  u32x4 nq = {0u, 0u, 0u, 0u};
+  __device__ __forceinline__ void prefetch_n() {
+    wave_fence();
+    nq = L.fx.nq[lane];
+  }
   // models
   DecRec* gstates;
   bool bad = false;
@@ -657,8 +669,13 @@ struct WaveDec : WaveModel {
     };
     wave_fence();
     for (int t = 0; t < 6; t++) {
-      for (int j = lane; j < NTAB_CNT; j += 64) F.ntab[t][j] = j < 256 ? (16u | ((u32)(16 * j) << 16)) : j == 256 ? 8u * 256u : 0u;
+      for (int j = lane; j < NTAB_CNT; j += 64) F.ntab[t][j] = j < 256 ? (16u | ((u32)(16 * j) << 16)) : 0u;
       for (int j = lane; j < 256; j += 64) F.ntab[t][NTAB_CNT + j] = 8u;
+    }
+    {
+      const u32 e = 16u | ((u32)(16 * lane) << 16);
+      F.nq[lane] = u32x4{e, e, e, e};
+      nscal = (lane & 1) ? 8u * 256u : 16u * 64u;
     }
     {
       const int j = lane & 7, fr = kProbScale / 6, c0 = fr - (fr >> 1);
@@ -678,9 +695,11 @@ struct WaveDec : WaveModel {
     FixedLds& F = L.fx;
     wave_fence();
     for (int t = 0; t < 6; t++) {
-      for (int j = lane; j < NTAB_CNT; j += 64) F.ntab[t][j] = j < 256 ? B->nfc[t][j] : j == 256 ? (u32)B->ftot[t] : 0u;
+      for (int j = lane; j < NTAB_CNT; j += 64) F.ntab[t][j] = j < 256 ? B->nfc[t][j] : 0u;
       for (int j = lane; j < 256; j += 64) F.ntab[t][NTAB_CNT + j] = B->ncnt[t][j];
     }
+    F.nq[lane] = u32x4{B->nfc[0][lane], B->nfc[1][lane], B->nfc[2][lane], B->nfc[5][lane]};
+    nscal = lane < 12 ? ((lane & 1) ? (u32)B->ftot[lane >> 1] : B->nfc[lane >> 1][64] >> 16) : 0u;
     {
       const int t = lane >> 3, j = lane & 7;
       pfc = lane < 48 ? B->pfc[t][j] : 0xFFFFFFFFu;
@@ -711,8 +730,8 @@ struct WaveDec : WaveModel {
         B->nfc[t][j] = F.ntab[t][j];
         B->ncnt[t][j] = F.ntab[t][NTAB_CNT + j];
       }
-      if (lane == 0) B->ftot[t] = (int)F.ntab[t][256];
     }
+    if (lane < 12 && (lane & 1)) B->ftot[lane >> 1] = (int)nscal;
     for (int i = lane; i < 1024; i += 64) {
       (&B->mfc[0][0])[i] = (&F.mfc[0][0])[i];
       (&B->mcnt[0][0])[i] = (&F.mcnt[0][0])[i];
@@ -737,24 +756,30 @@ struct WaveDec : WaveModel {
   }
 
   // Run length after a pixel of type t (decode + incrCnt, ans_contexts.h:1093-1112, :1070-1091).
-  // Symbol j of a table is LDS word j: the first 64 symbols (almost every run) are one per lane and
-  // are found with one compare and a population count; word 64 tells whether that is enough, word
-  // 256 is the running total.  The three words come back from one wait.
+  // Symbol j of a table is LDS word j; the first 64 symbols (almost every run) are one per lane and are found with one
+  // compare and a population count.  Nothing on this path waits for LDS: the entries of the four common tables were asked for
+  // before the pixel type was decoded (prefetch_n), "is the symbol among the first 64" and the running total are lanes of a
+  // register, and the count goes out as one ds_add nobody waits for (LDS operations of a wave execute in order).
   template <bool CHK = true>
   __device__ __forceinline__ int fixed_n(int t) {
-    wave_fence();
     const u32 v = x & (kProbScale - 1), lim = (v + 1) << 16;  // cum <= v  <=>  (freq | cum << 16) < lim
     u32* tab = L.fx.ntab[t];
     const u32 addr = (u32)(size_t)tab + 4u * (u32)lane;  // LDS offset = low 32 bits of the flat address
-    u32 e0, e1, et;
-    asm volatile("ds_read_b32 %0, %3\n\tds_read_b32 %1, %3 offset:256\n\tds_read_b32 %2, %3 offset:1024\n\ts_waitcnt lgkmcnt(0)" : "=v"(e0), "=v"(e1), "=v"(et) : "v"(addr) : "memory");
-    const int tot0 = (int)rfl(et);
+    u32 e0 = t == 0 ? nq.x : t == 1 ? nq.y : t == 2 ? nq.z : nq.w;
+    int slow = (0x18 >> t) & 1;  // types 3 (P-frames: the pixel of the previous frame) and 4 (gradient) read their row now
+    if (SCPR_UNLIKELY(slow)) {
+      wave_fence();
+      e0 = tab[lane];
+    }
+    const u32 c64 = rdl(nscal, 2 * t);
+    const int tot0 = (int)rdl(nscal, 2 * t + 1);
     // (plain ifs only: an else on this path costs the common case a taken branch)
     int sym = __builtin_popcountll(__ballot(e0 < lim)) - 1;
     u32 s = rdl(e0, sym);
-    if (SCPR_UNLIKELY(rfl(e1) < lim)) {  // cum of symbol 64 is not above v: the symbol is further up
+    if (SCPR_UNLIKELY(c64 <= v)) {  // symbol 64 does not start above v: the symbol is further up
       event<15>();
-      const u32 e2 = tab[128 + lane], e3 = tab[192 + lane];
+      wave_fence();
+      const u32 e1 = tab[64 + lane], e2 = tab[128 + lane], e3 = tab[192 + lane];
       sym = 63 + __builtin_popcountll(__ballot(e1 < lim)) + __builtin_popcountll(__ballot(e2 < lim)) + __builtin_popcountll(__ballot(e3 < lim));
       const int q = sym >> 6, l = sym & 63;
       s = q == 1 ? rdl(e1, l) : q == 2 ? rdl(e2, l) : rdl(e3, l);
@@ -764,28 +789,32 @@ struct WaveDec : WaveModel {
       }
     }
     {
-      // the count of the symbol (from the lane that holds it: none for a symbol above 63, counted above) and the
-      // total (lane 0); the other lanes add 0 to padding
-      const u32 dc = lane == sym ? (u32)kStepDense : 0u, dt = lane == 0 ? (u32)kStepDense : 0u;
-      asm volatile("ds_add_u32 %0, %1 offset:%3\n\tds_add_u32 %0, %2 offset:1024" ::"v"(addr), "v"(dc), "v"(dt), "n"(4 * NTAB_CNT) : "memory");
+      // the count of the symbol, from the lane that holds it (none for a symbol above 63, counted above); the other lanes add 0
+      const u32 dc = lane == sym ? (u32)kStepDense : 0u;
+      asm volatile("ds_add_u32 %0, %1 offset:%2" ::"v"(addr), "v"(dc), "n"(4 * NTAB_CNT) : "memory");
     }
+    nscal = lane == 2 * t + 1 ? (u32)(tot0 + kStepDense) : nscal;
     advance(s >> 16, s & 0xFFFF, v);
     if (SCPR_UNLIKELY(tot0 + 2 * kStepDense > kProbScale)) {  // rebuild from the counts, ans_contexts.h:1075-1090
       wave_fence();
       u32* cnt = tab + NTAB_CNT;
-      int base = 0, ns = 0;
+      int base = 0, ns = 0, c64n = 0;
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         const int c = (int)cnt[lane + 64 * q];
         const int inc = wave_incl_scan(c);
-        tab[lane + 64 * q] = (u32)c | ((u32)(base + inc - c) << 16);
+        const u32 e = (u32)c | ((u32)(base + inc - c) << 16);
+        tab[lane + 64 * q] = e;
+        if (q == 0 && !slow) ((u32*)&L.fx.nq[lane])[t == 5 ? 3 : t] = e;
         base += (int)rdl((u32)inc, 63);
+        if (q == 0) c64n = base;
         const int h = c - (c >> 1);
         cnt[lane + 64 * q] = (u32)h;
         ns += h;
       }
       ns = wave_sum(ns);
-      if (lane == 0) tab[256] = (u32)ns;
+      nscal = lane == 2 * t ? (u32)c64n : nscal;
+      nscal = lane == 2 * t + 1 ? (u32)ns : nscal;
       wave_fence();
     }
     count<CHK>();
@@ -1069,6 +1098,7 @@ __device__ __forceinline__ void decode_intra_frame(DEC& D, const Geom& g, u8* __
   auto run = [&](auto fast_tag) __attribute__((always_inline)) {
     constexpr bool FAST = decltype(fast_tag)::value;
     D.template stamp<4>();
+    D.prefetch_n();  // the run-length rows, asked for before the type is known (fixed_n)
     if constexpr (FAST) t = D.template fixed_p<false>(t);
     else if (lim == NP) t = D.fixed_p(t);
     D.template stamp<0>();
@@ -1355,6 +1385,7 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
     auto prun = [&](auto fast_tag) __attribute__((always_inline)) {
       constexpr bool FAST = decltype(fast_tag)::value;
       const int last_t = pt;
+      D.prefetch_n();
       pt = D.template fixed_p<!FAST>(last_t);
       u32 px = lastpix;
       if (pt == 0) {
