@@ -853,7 +853,17 @@ int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* 
       const int nblocks = ((g.W + 15) / 16) * ((g.H + 15) / 16);
       bool has_p = false;
       for (const DecFrame& d : fr) has_p |= d.kind == 2;
-      const int dyn = ring + (has_p ? ((nblocks + 15) & ~15) : 0);  // + one byte per block for P-frames
+      int dyn = ring + (has_p ? ((nblocks + 15) & ~15) : 0);  // + one byte per block for P-frames
+      // + the dense-table cache (scpr_wave.hpp, WaveModel::tab_of) with what LDS is left: of the whole CU (160 KiB) when every
+      // GOP gets a CU to itself anyway, of half a CU otherwise (two GOPs per CU: a batch of key frames lives on GOPs in flight)
+      int ndc = 0;
+      const int dcache_off = dyn;
+      if (!v2) {
+        const size_t lds_budget = (ng <= 256 ? 160 * 1024 : 80 * 1024) - sizeof(WaveLds) - 1024;
+        while (ndc < 32 && (size_t)dyn + (size_t)(ndc ? 2 * ndc : 1) * sizeof(DenseTab) <= lds_budget) ndc = ndc ? 2 * ndc : 1;
+        if (ndc < 16) ndc = 0;  // a handful of slots would only be evicted all the time (a miss moves two tables, an uncached symbol 32 bytes per lane)
+        dyn += ndc * (int)sizeof(DenseTab);
+      }
       const u8* pk = (const u8*)d_packets;
       const u8* pk_end = pk + offs[nframes];  // nothing is read at or past this address (the reader supplies 0xFF there)
       if (v2) {
@@ -864,9 +874,13 @@ int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* 
       } else {
         auto kern = has_p ? k_decode_gop_w<true> : k_decode_gop_w<false>;  // key-frame-only GOPs: smaller kernel (instruction cache)
         HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
-        hipLaunchKernelGGL(kern, dim3((unsigned)ng), dim3(64), dyn, st, pk, pk_end, c->decframes.as<DecFrame>(), c->decgops.as<DecGop>(), c->planes.as<u8>(), g,
+        // P-frame GOPs run as a workgroup: the chain's wave + helper waves for the bulk copies (scpr_wave.hpp, helper_loop) -
+        // seven when every GOP has a CU to itself, three when CUs are shared (two waves per SIMD at most: the chain keeps its
+        // 256 registers)
+        const unsigned threads = has_p ? (ng <= 256 ? 512u : 256u) : 64u;
+        hipLaunchKernelGGL(kern, dim3((unsigned)ng), dim3(threads), dyn, st, pk, pk_end, c->decframes.as<DecFrame>(), c->decgops.as<DecGop>(), c->planes.as<u8>(), g,
                            c->decstates.as<DecRec>(), ar, c->f0, c->err.as<u32>(), ring, c->decfixed.as<FixedBlob>(), (int)std::min<u32>(c->prm.high_range_x, 256),
-                           (int)std::min<u32>(c->prm.high_range_y, 256));
+                           (int)std::min<u32>(c->prm.high_range_y, 256), ndc, dcache_off);
       }
     }
     stage_end(c, ST_DECODE);
@@ -963,10 +977,10 @@ int scpr_last_timing(scpr_codec* c, float* total_ms, float* stage_ms, int cap) {
 #ifdef SCPR_PROFILE
 // design work only (libscpr_amd_prof.so): s_memtime ticks per decoder section summed over all GOPs since the last call
 extern "C" int scpr_debug_profile(unsigned long long* out) {
-  unsigned long long z[16] = {0};
+  unsigned long long z[24] = {0};
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(scpr::g_prof), sizeof z) != hipSuccess) return -1;
   if (hipMemcpyToSymbol(HIP_SYMBOL(scpr::g_prof), z, sizeof z) != hipSuccess) return -1;
-  return 16;
+  return 24;
 }
 #endif
 int scpr_debug_colour_chain(int device, const uint8_t* syms, int n, int f0, uint16_t* out) {

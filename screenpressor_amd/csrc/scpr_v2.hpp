@@ -36,6 +36,7 @@ constexpr u32 V2_BOT = 1u << 16;        // BOT_C, sub.h:17
 constexpr u32 V2_TOP = 1u << 24;        // TOP, sub.h:14
 
 struct WaveDecV2 {
+  static constexpr bool kHelpers = false;  // one wave per GOP, no helper waves
   static constexpr bool kFastRuns = false;  // decode_intra_frame: no second instance of the run body for this coder
   int ndec = 0;                             // (unused: the range coder has no blocks)
   const int lane;
@@ -61,7 +62,6 @@ struct WaveDecV2 {
   __device__ __forceinline__ void stamp() {}
   template <int EV>
   __device__ __forceinline__ void event() {}
-  __device__ __forceinline__ void prefetch_n() {}
 
   __device__ __forceinline__ u32 fetch_word(u32 i) {
     const u32 m = i < wmax ? i : wmax;

@@ -92,12 +92,7 @@ constexpr int DECREC_WORDS = 20;
 // words per run-length table: 256 entries (freq | cum << 16), the running total at 256, padding, and the 256 counts from
 // NTAB_CNT on (the lane that holds an entry reaches its count and lane 0 the total with a constant offset from one address)
 constexpr int NTAB_STRIDE = 640, NTAB_CNT = 320;
-typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 struct FixedLds {
-  // entries of symbols 0..63 of the run-length tables 0, 1, 2 and 5 (literal, previous pixel, pixel above, above-left: almost
-  // every run), symbol j in nq[j]: ONE 16-byte read per lane, asked for before the pixel type is decoded, brings what the
-  // run-length lookup needs whichever of the four types comes out (a copy of ntab[t][0..63], rewritten with it)
-  u32x4 nq[64];
   u32 ntab[6][NTAB_STRIDE];
   u32 mfc[2][512];
   u32 mcnt[2][512];
@@ -115,7 +110,16 @@ struct __attribute__((aligned(16))) WaveLds {
   u16 tmp[256];
   u32 tile[17 * 17];   // P-frame block under reconstruction, with one row above and one column to the left
   uint2 jobs[256];     // deferred motion-block copies of the current P-frame
+  u32 dtag[64];        // tags of the dense-table cache (WaveModel::tab_of)
+  // Helper waves (P-frame GOPs: the workgroup is the chain's wave + helpers, see helper_loop): commands go out by bumping
+  // `seq` after the arguments are in place, every helper adds 1 to `done` when it has finished the command it saw.
+  struct {
+    u32 seq, op, done, nhelp;
+    u64 src, dst;
+    u32 bytes, pad;
+  } hc;
 };
+enum : u32 { HOP_COPY = 1, HOP_JOBS = 2, HOP_EXIT = 3 };
 
 // The colour model of one context, operated by a whole wave.  The header is
 // wave-uniform (scalar registers), a small table is one entry per lane (lanes
@@ -135,10 +139,27 @@ struct ColHdr {
 // per symbol and saves the prefix scan.  Counts and P stay below 4096 (the total does).
 // Unused lanes hold kSmallNone: count 0 and a start above every coder value.
 constexpr u32 kSmallNone = 0xFFF000FFu;
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ int dpp_row_shr1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true); }
 __device__ __forceinline__ u32 sm_sym(u32 w) { return w & 255u; }
 __device__ __forceinline__ u32 sm_fq(u32 w) { return (w >> 8) & 4095u; }
 __device__ __forceinline__ u32 sm_p(u32 w) { return w >> 20; }
+
+// Dense tables are read and written 8 bytes per lane.  A table may sit in the arena (global memory) or in the decoder's LDS
+// cache; the address space is part of the instruction (a FLAT access to LDS goes through the vector memory pipeline first and
+// costs several hundred cycles), so the table code exists once per space.
+typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+#define SCPR_LDS_AS __attribute__((address_space(3)))
+template <bool LDS>
+__device__ __forceinline__ u32x2 tab_ld(const u16* arr, int lane) {
+  if constexpr (LDS) return ((const SCPR_LDS_AS u32x2*)(size_t)(u32)(size_t)arr)[lane];  // LDS offset = low 32 bits of the flat address
+  else return ((const u32x2*)arr)[lane];
+}
+template <bool LDS>
+__device__ __forceinline__ void tab_st(u16* arr, int lane, u32x2 v) {
+  if constexpr (LDS) ((SCPR_LDS_AS u32x2*)(size_t)(u32)(size_t)arr)[lane] = v;
+  else ((u32x2*)arr)[lane] = v;
+}
 
 struct WaveModel {
   const int lane;
@@ -146,7 +167,49 @@ struct WaveModel {
   u16* tmp;  // 256 x u16 LDS scratch
   Arena arena;
   int f0;
+  // Decoder only: an LDS cache of dense tables (direct mapped by table index, write-back).  A symbol of a dense context reads
+  // 24 bytes per lane of its table and writes 8 back: from the arena that is an L2 round trip of ~2500 cycles on the one
+  // chain of the GOP, and in a GOP that has been going for a while more than half of the colour symbols are such symbols.
+  u8* dcache = nullptr;   // ndc slots of sizeof(DenseTab) bytes in LDS (null: tables are used where they are, in the arena)
+  u32* dtag = nullptr;    // per slot: table index + 1 (0: empty)
+  u32 dmask = 0;          // ndc - 1 (ndc is a power of two)
+#ifdef SCPR_PROFILE
+  u32 dmiss = 0;
+#endif
   __device__ __forceinline__ WaveModel(u16* tmp_, Arena a, int f0_) : lane(lane_id()), l15(lane_id() & 15), tmp(tmp_), arena(a), f0(f0_) {}
+  template <bool DST_LDS>
+  static __device__ __forceinline__ void copy_tab(DenseTab* dst, const DenseTab* src, int lane) {
+    const u32x2 a = tab_ld<!DST_LDS>(src->freq, lane), b = tab_ld<!DST_LDS>(src->cum, lane), c = tab_ld<!DST_LDS>(src->cnt, lane);
+    tab_st<DST_LDS>(dst->freq, lane, a);
+    tab_st<DST_LDS>(dst->cum, lane, b);
+    tab_st<DST_LDS>(dst->cnt, lane, c);
+  }
+  // where table idx is to be read and written (fresh: it is about to be written whole, its old contents do not matter)
+  __device__ __forceinline__ DenseTab* tab_of(u32 idx, bool fresh = false) {
+    if (!dcache) return arena.tabs + idx;
+    wave_fence();
+    const u32 slot = idx & dmask;
+    const u32 tag = rfl(dtag[slot]);
+    DenseTab* c = (DenseTab*)(dcache + (size_t)slot * sizeof(DenseTab));
+    if (SCPR_UNLIKELY(tag != idx + 1u)) {
+#ifdef SCPR_PROFILE
+      dmiss++;
+#endif
+      if (tag) copy_tab<false>(arena.tabs + (tag - 1u), c, lane);
+      if (!fresh) copy_tab<true>(c, arena.tabs + idx, lane);
+      if (lane == 0) dtag[slot] = idx + 1u;
+      wave_fence();
+    }
+    return c;
+  }
+  __device__ __forceinline__ void flush_tabs() {
+    if (!dcache) return;
+    wave_fence();
+    for (u32 slot = 0; slot <= dmask; slot++) {
+      const u32 tag = rfl(dtag[slot]);
+      if (tag) copy_tab<false>(arena.tabs + (tag - 1u), (const DenseTab*)(dcache + (size_t)slot * sizeof(DenseTab)), lane);
+    }
+  }
   __device__ __forceinline__ int small_fmax(const ColHdr& h, u32 w) { return (int)sm_fq(rdl(w, h.maxpos)); }
   // The header fields are wave-uniform wherever they were computed; after the rare paths (which work on the vector
   // unit) this says so to the compiler: without it the common path keeps the header in vector registers too.
@@ -210,13 +273,14 @@ struct WaveModel {
   __device__ __forceinline__ u32 set_bits4(const u32* r) { return (r[4 + (lane >> 3)] >> ((lane & 7) * 4)) & 15u; }
 
   // writes a dense table from per-lane (freq, count) of symbols 4*lane..+3; returns the count total
+  template <bool LDS = false>
   __device__ __forceinline__ int write_dense(DenseTab* t, const int fr[4], const int cn[4]) {
     const int s = fr[0] + fr[1] + fr[2] + fr[3];
     int cf = wave_incl_scan(s) - s;
     u32 c0 = (u32)cf, c1 = c0 + fr[0], c2 = c1 + fr[1], c3 = c2 + fr[2];
-    ((uint2*)t->freq)[lane] = make_uint2((u32)(fr[0] & 0xFFFF) | ((u32)fr[1] << 16), (u32)(fr[2] & 0xFFFF) | ((u32)fr[3] << 16));
-    ((uint2*)t->cum)[lane] = make_uint2((c0 & 0xFFFF) | (c1 << 16), (c2 & 0xFFFF) | (c3 << 16));
-    ((uint2*)t->cnt)[lane] = make_uint2((u32)(cn[0] & 0xFFFF) | ((u32)cn[1] << 16), (u32)(cn[2] & 0xFFFF) | ((u32)cn[3] << 16));
+    tab_st<LDS>(t->freq, lane, u32x2{(u32)(fr[0] & 0xFFFF) | ((u32)fr[1] << 16), (u32)(fr[2] & 0xFFFF) | ((u32)fr[3] << 16)});
+    tab_st<LDS>(t->cum, lane, u32x2{(c0 & 0xFFFF) | (c1 << 16), (c2 & 0xFFFF) | (c3 << 16)});
+    tab_st<LDS>(t->cnt, lane, u32x2{(u32)(cn[0] & 0xFFFF) | ((u32)cn[1] << 16), (u32)(cn[2] & 0xFFFF) | ((u32)cn[3] << 16)});
     return wave_sum(cn[0] + cn[1] + cn[2] + cn[3]);
   }
 
@@ -258,7 +322,7 @@ struct WaveModel {
     }
     h.dense = alloc_dense();
     if (lane == 0) r[2] = h.dense;  // the table index only changes here: the per-symbol header store leaves word 2 alone
-    DenseTab* t = arena.tabs + h.dense;
+    DenseTab* t = tab_of(h.dense, true);
     int fr[4], cn[4];
     if (h.kind == 2) {  // Cx6::create23, ans_contexts.h:491-531
       const int tot = 256 - d + d * f0 + f0, sh = shift_for(tot), wdt = 1 << sh;
@@ -443,7 +507,7 @@ struct WaveModel {
     wave_fence();
     h.dense = alloc_dense();
     if (lane == 0) r[2] = h.dense;  // the table index only changes here: the per-symbol header store leaves word 2 alone
-    const int sum = write_dense(arena.tabs + h.dense, fr, cn);
+    const int sum = write_dense(tab_of(h.dense, true), fr, cn);
     h.kind = 6;
     h.fshift = s2;
     h.d = d + 1;
@@ -458,8 +522,13 @@ struct WaveModel {
   template <bool DEC>
   __device__ __forceinline__ int dense_op(u32* r, ColHdr& h, int in, u32& ofr, u32& ocf) {
     wave_fence();
-    DenseTab* t = arena.tabs + h.dense;
-    const uint2 cu = ((const uint2*)t->cum)[lane], fq = ((const uint2*)t->freq)[lane], cq = ((const uint2*)t->cnt)[lane];
+    DenseTab* t = tab_of(h.dense);
+    if (dcache) return dense_impl<DEC, true>(t, r, h, in, ofr, ocf);
+    return dense_impl<DEC, false>(t, r, h, in, ofr, ocf);
+  }
+  template <bool DEC, bool LDS>
+  __device__ __forceinline__ int dense_impl(DenseTab* t, u32* r, ColHdr& h, int in, u32& ofr, u32& ocf) {
+    const u32x2 cu = tab_ld<LDS>(t->cum, lane), fq = tab_ld<LDS>(t->freq, lane), cq = tab_ld<LDS>(t->cnt, lane);
     const u32 v = (u32)in;
     const u32 c0 = cu.x & 0xFFFF, c1 = cu.x >> 16, c2 = cu.y & 0xFFFF, c3 = cu.y >> 16;
     const u64 m = DEC ? __ballot(c0 <= v) : 0;
@@ -484,7 +553,7 @@ struct WaveModel {
           const int wdt = 1 << h.fshift, base = wdt - (wdt >> 1);
           for (int q = 0; q < 4; q++)
             if (!((bits >> q) & 1u)) cn[q] = base;
-          ((uint2*)t->cnt)[lane] = make_uint2((u32)cn[0] | ((u32)cn[1] << 16), (u32)cn[2] | ((u32)cn[3] << 16));
+          tab_st<LDS>(t->cnt, lane, u32x2{(u32)cn[0] | ((u32)cn[1] << 16), (u32)cn[2] | ((u32)cn[3] << 16)});
           h.kind = 7;
           return j;
         }
@@ -508,7 +577,7 @@ struct WaveModel {
           fr[q] = cn[q];
           cn[q] -= cn[q] >> 1;
         }
-        h.total = write_dense(t, fr, cn);
+        h.total = write_dense<LDS>(t, fr, cn);
       } else {  // Cx6::rescale, :742-796
         const int wdt = 1 << (h.fshift > 0 ? h.fshift - 1 : 0);
         if (h.fshift > 0) h.fshift--;
@@ -521,18 +590,18 @@ struct WaveModel {
             cn[q] = 0;
           }
         }
-        const int sum = write_dense(t, fr, cn);
+        const int sum = write_dense<LDS>(t, fr, cn);
         h.total = ((256 - h.d) << (h.fshift > 0 ? h.fshift - 1 : 0)) + sum;
       }
     } else if (lane == own) {
-      ((uint2*)t->cnt)[lane] = make_uint2((u32)cn[0] | ((u32)cn[1] << 16), (u32)cn[2] | ((u32)cn[3] << 16));
+      tab_st<LDS>(t->cnt, lane, u32x2{(u32)cn[0] | ((u32)cn[1] << 16), (u32)cn[2] | ((u32)cn[3] << 16)});
     }
     return j;
   }
 };
 
 #ifdef SCPR_PROFILE
-__device__ u64 g_prof[16];
+__device__ u64 g_prof[24];
 #endif
 struct WaveDec : WaveModel {
   WaveLds& L;
@@ -550,14 +619,6 @@ struct WaveDec : WaveModel {
   int ndec = 0;
   // pixel-type tables (ptypetab) in registers: table t in lanes 8t..8t+5 (entries) and 8t+7 (the running total, in pcnt)
   u32 pfc = 0xFFFFFFFFu, pcnt = 0;
-  // run-length tables: lane 2t holds where symbol 64 of table t starts (everything below it is found among the first 64
-  // entries), lane 2t+1 the table's running total; nq = this lane's FixedLds::nq row as last asked for (prefetch_n)
-  u32 nscal = 0;
-  u32x4 nq = {0u, 0u, 0u, 0u};
-  __device__ __forceinline__ void prefetch_n() {
-    wave_fence();
-    nq = L.fx.nq[lane];
-  }
   // models
   DecRec* gstates;
   bool bad = false;
@@ -596,7 +657,7 @@ struct WaveDec : WaveModel {
   __device__ __forceinline__ void tick() {}
   // section timing for design work (only with -DSCPR_PROFILE): time since the previous stamp goes to section `sec`
 #ifdef SCPR_PROFILE
-  u64 prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, prof_last = 0;
+  u64 prof[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, prof_last = 0;
   template <int EV>
   __device__ __forceinline__ void event() { prof[EV]++; }  // 8 colour symbols, 9 record cache misses, 10 dense, 11 raw, 12 small-table slow path, 13 runs, 14 literal runs, 15 run lengths above 63
   template <int SEC>
@@ -646,6 +707,7 @@ struct WaveDec : WaveModel {
   // CHK = false: the caller has made sure the block does not end within this run and adds the run's symbols to ndec itself
   // (decode_intra_frame's fast runs): a test-and-branch per symbol is ~20 cycles of a lone wave's time.
   static constexpr bool kFastRuns = true;
+  static constexpr bool kHelpers = true;  // decode_inter_frame: the workgroup may have helper waves (WaveLds::hc)
   template <bool CHK = true>
   __device__ __forceinline__ void count() {  // screencap.h:327-331
     if (!CHK) return;
@@ -669,13 +731,8 @@ struct WaveDec : WaveModel {
     };
     wave_fence();
     for (int t = 0; t < 6; t++) {
-      for (int j = lane; j < NTAB_CNT; j += 64) F.ntab[t][j] = j < 256 ? (16u | ((u32)(16 * j) << 16)) : 0u;
+      for (int j = lane; j < NTAB_CNT; j += 64) F.ntab[t][j] = j < 256 ? (16u | ((u32)(16 * j) << 16)) : j == 256 ? 8u * 256u : 0u;
       for (int j = lane; j < 256; j += 64) F.ntab[t][NTAB_CNT + j] = 8u;
-    }
-    {
-      const u32 e = 16u | ((u32)(16 * lane) << 16);
-      F.nq[lane] = u32x4{e, e, e, e};
-      nscal = (lane & 1) ? 8u * 256u : 16u * 64u;
     }
     {
       const int j = lane & 7, fr = kProbScale / 6, c0 = fr - (fr >> 1);
@@ -695,11 +752,9 @@ struct WaveDec : WaveModel {
     FixedLds& F = L.fx;
     wave_fence();
     for (int t = 0; t < 6; t++) {
-      for (int j = lane; j < NTAB_CNT; j += 64) F.ntab[t][j] = j < 256 ? B->nfc[t][j] : 0u;
+      for (int j = lane; j < NTAB_CNT; j += 64) F.ntab[t][j] = j < 256 ? B->nfc[t][j] : j == 256 ? (u32)B->ftot[t] : 0u;
       for (int j = lane; j < 256; j += 64) F.ntab[t][NTAB_CNT + j] = B->ncnt[t][j];
     }
-    F.nq[lane] = u32x4{B->nfc[0][lane], B->nfc[1][lane], B->nfc[2][lane], B->nfc[5][lane]};
-    nscal = lane < 12 ? ((lane & 1) ? (u32)B->ftot[lane >> 1] : B->nfc[lane >> 1][64] >> 16) : 0u;
     {
       const int t = lane >> 3, j = lane & 7;
       pfc = lane < 48 ? B->pfc[t][j] : 0xFFFFFFFFu;
@@ -730,8 +785,8 @@ struct WaveDec : WaveModel {
         B->nfc[t][j] = F.ntab[t][j];
         B->ncnt[t][j] = F.ntab[t][NTAB_CNT + j];
       }
+      if (lane == 0) B->ftot[t] = (int)F.ntab[t][256];
     }
-    if (lane < 12 && (lane & 1)) B->ftot[lane >> 1] = (int)nscal;
     for (int i = lane; i < 1024; i += 64) {
       (&B->mfc[0][0])[i] = (&F.mfc[0][0])[i];
       (&B->mcnt[0][0])[i] = (&F.mcnt[0][0])[i];
@@ -756,30 +811,24 @@ struct WaveDec : WaveModel {
   }
 
   // Run length after a pixel of type t (decode + incrCnt, ans_contexts.h:1093-1112, :1070-1091).
-  // Symbol j of a table is LDS word j; the first 64 symbols (almost every run) are one per lane and are found with one
-  // compare and a population count.  Nothing on this path waits for LDS: the entries of the four common tables were asked for
-  // before the pixel type was decoded (prefetch_n), "is the symbol among the first 64" and the running total are lanes of a
-  // register, and the count goes out as one ds_add nobody waits for (LDS operations of a wave execute in order).
+  // Symbol j of a table is LDS word j: the first 64 symbols (almost every run) are one per lane and
+  // are found with one compare and a population count; word 64 tells whether that is enough, word
+  // 256 is the running total.  The three words come back from one wait.
   template <bool CHK = true>
   __device__ __forceinline__ int fixed_n(int t) {
+    wave_fence();
     const u32 v = x & (kProbScale - 1), lim = (v + 1) << 16;  // cum <= v  <=>  (freq | cum << 16) < lim
     u32* tab = L.fx.ntab[t];
     const u32 addr = (u32)(size_t)tab + 4u * (u32)lane;  // LDS offset = low 32 bits of the flat address
-    u32 e0 = t == 0 ? nq.x : t == 1 ? nq.y : t == 2 ? nq.z : nq.w;
-    int slow = (0x18 >> t) & 1;  // types 3 (P-frames: the pixel of the previous frame) and 4 (gradient) read their row now
-    if (SCPR_UNLIKELY(slow)) {
-      wave_fence();
-      e0 = tab[lane];
-    }
-    const u32 c64 = rdl(nscal, 2 * t);
-    const int tot0 = (int)rdl(nscal, 2 * t + 1);
+    u32 e0, e1, et;
+    asm volatile("ds_read_b32 %0, %3\n\tds_read_b32 %1, %3 offset:256\n\tds_read_b32 %2, %3 offset:1024\n\ts_waitcnt lgkmcnt(0)" : "=v"(e0), "=v"(e1), "=v"(et) : "v"(addr) : "memory");
+    const int tot0 = (int)rfl(et);
     // (plain ifs only: an else on this path costs the common case a taken branch)
     int sym = __builtin_popcountll(__ballot(e0 < lim)) - 1;
     u32 s = rdl(e0, sym);
-    if (SCPR_UNLIKELY(c64 <= v)) {  // symbol 64 does not start above v: the symbol is further up
+    if (SCPR_UNLIKELY(rfl(e1) < lim)) {  // cum of symbol 64 is not above v: the symbol is further up
       event<15>();
-      wave_fence();
-      const u32 e1 = tab[64 + lane], e2 = tab[128 + lane], e3 = tab[192 + lane];
+      const u32 e2 = tab[128 + lane], e3 = tab[192 + lane];
       sym = 63 + __builtin_popcountll(__ballot(e1 < lim)) + __builtin_popcountll(__ballot(e2 < lim)) + __builtin_popcountll(__ballot(e3 < lim));
       const int q = sym >> 6, l = sym & 63;
       s = q == 1 ? rdl(e1, l) : q == 2 ? rdl(e2, l) : rdl(e3, l);
@@ -789,32 +838,28 @@ struct WaveDec : WaveModel {
       }
     }
     {
-      // the count of the symbol, from the lane that holds it (none for a symbol above 63, counted above); the other lanes add 0
-      const u32 dc = lane == sym ? (u32)kStepDense : 0u;
-      asm volatile("ds_add_u32 %0, %1 offset:%2" ::"v"(addr), "v"(dc), "n"(4 * NTAB_CNT) : "memory");
+      // the count of the symbol (from the lane that holds it: none for a symbol above 63, counted above) and the
+      // total (lane 0); the other lanes add 0 to padding
+      const u32 dc = lane == sym ? (u32)kStepDense : 0u, dt = lane == 0 ? (u32)kStepDense : 0u;
+      asm volatile("ds_add_u32 %0, %1 offset:%3\n\tds_add_u32 %0, %2 offset:1024" ::"v"(addr), "v"(dc), "v"(dt), "n"(4 * NTAB_CNT) : "memory");
     }
-    nscal = lane == 2 * t + 1 ? (u32)(tot0 + kStepDense) : nscal;
     advance(s >> 16, s & 0xFFFF, v);
     if (SCPR_UNLIKELY(tot0 + 2 * kStepDense > kProbScale)) {  // rebuild from the counts, ans_contexts.h:1075-1090
       wave_fence();
       u32* cnt = tab + NTAB_CNT;
-      int base = 0, ns = 0, c64n = 0;
+      int base = 0, ns = 0;
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         const int c = (int)cnt[lane + 64 * q];
         const int inc = wave_incl_scan(c);
-        const u32 e = (u32)c | ((u32)(base + inc - c) << 16);
-        tab[lane + 64 * q] = e;
-        if (q == 0 && !slow) ((u32*)&L.fx.nq[lane])[t == 5 ? 3 : t] = e;
+        tab[lane + 64 * q] = (u32)c | ((u32)(base + inc - c) << 16);
         base += (int)rdl((u32)inc, 63);
-        if (q == 0) c64n = base;
         const int h = c - (c >> 1);
         cnt[lane + 64 * q] = (u32)h;
         ns += h;
       }
       ns = wave_sum(ns);
-      nscal = lane == 2 * t ? (u32)c64n : nscal;
-      nscal = lane == 2 * t + 1 ? (u32)ns : nscal;
+      if (lane == 0) tab[256] = (u32)ns;
       wave_fence();
     }
     count<CHK>();
@@ -963,6 +1008,46 @@ struct WaveDec : WaveModel {
       if (tag != kNoCtx && lane < DECREC_WORDS) gstates[tag].w[lane] = L.crec[slot][lane];
     }
   }
+  // The common case of dense_op<true>() in straight-line form, like small_hit(): the table is in the LDS cache (or comes into
+  // it), the coder value falls on a symbol the context has met (kind 7: every symbol), and no rescale is due after it.
+  // Returns a negative number and has applied the symbol (c, ofr, ocf set; the symbol's count and h.total bumped) - or a
+  // non-negative one with nothing touched: dense_op() then does the symbol from scratch.  The lane that owns the interval is
+  // found with one ballot over each lane's first start; the other three starts of that lane, its four widths and the
+  // met-symbol set (lanes 0..7 of w, read with the record) are taken out with lane reads, so everything after the table read
+  // is scalar; the counts go back from all lanes alike (no lane mask).
+  __device__ __forceinline__ int dense_hit(ColHdr& h, u32 w, int v, int& c, u32& ofr, u32& ocf) {
+    if (!dcache) return 0;
+    DenseTab* t = tab_of(h.dense);
+    const u32 ta = (u32)(size_t)t + 8u * (u32)lane;  // LDS offset of this lane's four symbols (freq at +0, cum at +512, cnt at +1024)
+    u32x2 fq, cu, cq;
+    asm volatile("ds_read_b64 %0, %3\n\tds_read_b64 %1, %3 offset:512\n\tds_read_b64 %2, %3 offset:1024\n\ts_waitcnt lgkmcnt(0)" : "=v"(fq), "=v"(cu), "=v"(cq) : "v"(ta) : "memory");
+    const u64 m = __ballot((cu.x & 0xFFFFu) <= (u32)v);  // never empty: symbol 0 starts at 0
+    const int own = 63 - __builtin_clzll(m);
+    const u32 sc0 = rdl(cu.x, own), sc1 = rdl(cu.y, own), sf0 = rdl(fq.x, own), sf1 = rdl(fq.y, own);
+    const u32 c1 = sc0 >> 16, c2 = sc1 & 0xFFFFu, c3 = sc1 >> 16;
+    const int kk = (int)(c1 <= (u32)v) + (int)(c2 <= (u32)v) + (int)(c3 <= (u32)v);  // the starts inside a lane go up strictly (no symbol is empty)
+    const u32 cw = kk < 2 ? sc0 : sc1, fw = kk < 2 ? sf0 : sf1;
+    const u32 sh16 = (u32)(kk & 1) * 16u;
+    const int j = own * 4 + kk;
+    const int is7 = h.kind == 7;
+    const int step = is7 ? kStepDense : kStepHash << h.fshift;
+    const u32 met = is7 ? 1u : (rdl(w, j >> 5) >> (j & 31)) & 1u;
+    // each negative when fine: the symbol has been met, no rescale after it
+    const int tst = ((int)met - 1 >= 0 ? -1 : 0) & (h.total + 2 * step - kProbScale - 1);
+    if (SCPR_LIKELY(tst < 0)) {
+      ocf = (cw >> sh16) & 0xFFFFu;
+      ofr = (fw >> sh16) & 0xFFFFu;
+      c = j;
+      const u32 inc = (u32)step << sh16;
+      const bool mine = lane == own;
+      cq.x += (mine && kk < 2) ? inc : 0u;
+      cq.y += (mine && kk >= 2) ? inc : 0u;
+      asm volatile("ds_write_b64 %0, %1 offset:1024" ::"v"(ta), "v"(cq) : "memory");
+      h.total += step;
+      event<16>();
+    }
+    return tst;
+  }
   // decodeC (screencap.h:318-333)
   template <bool CHK = true>
   __device__ __forceinline__ int colour(int ctxid) {
@@ -1001,11 +1086,16 @@ struct WaveDec : WaveModel {
         wave_fence();
         if ((h.kind == 4 || h.kind == 5) && lane < 16) r[4 + lane] = w;  // promoted to a small table
         wave_fence();
+        scalar_hdr(h);
       } else {
         event<10>();
-        c = dense_op<true>(r, h, (int)v, fr, cf);
+        int t = dense_hit(h, w, (int)v, c, fr, cf);
+        asm volatile("" : "+s"(t));
+        if (SCPR_UNLIKELY(t >= 0)) {
+          c = dense_op<true>(r, h, (int)v, fr, cf);
+          scalar_hdr(h);
+        }
       }
-      scalar_hdr(h);
     }
     advance(cf, fr, v);
     wave_fence();
@@ -1098,7 +1188,6 @@ __device__ __forceinline__ void decode_intra_frame(DEC& D, const Geom& g, u8* __
   auto run = [&](auto fast_tag) __attribute__((always_inline)) {
     constexpr bool FAST = decltype(fast_tag)::value;
     D.template stamp<4>();
-    D.prefetch_n();  // the run-length rows, asked for before the type is known (fixed_n)
     if constexpr (FAST) t = D.template fixed_p<false>(t);
     else if (lim == NP) t = D.fixed_p(t);
     D.template stamp<0>();
@@ -1221,6 +1310,96 @@ __device__ __forceinline__ void decode_intra_frame(DEC& D, const Geom& g, u8* __
   if (!D.bad) flush_rows(H);
 }
 
+// ---- helper waves -------------------------------------------------------------------------------------------------
+// Whatever a P-frame needs that is not the symbol chain is bulk copying: the new plane starts as the previous one (6 MB at
+// 1080p: 2 ms for one wave, an eighth of the frame) and motion blocks are copied from it.  A GOP with P-frames therefore runs as
+// a workgroup: wave 0 is the chain, the other waves sleep on an LDS word and do those copies when told - at the start of a frame
+// the plane copy runs while the chain decodes the frame header and the block types (which touch no pixel), motion blocks are
+// queued and copied in batches while the chain goes on with the next symbols.
+__device__ __forceinline__ u32 lds_peek(const u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+struct HelpJobs;  // (the motion-block queue is WaveLds::jobs)
+__device__ __forceinline__ void copy_motion_jobs(const uint2* jobs, int first, int njobs, int stride_jobs, u8* __restrict__ cur, const u8* __restrict__ prv, int S, int lane) {
+  for (int base = first; base < njobs; base += stride_jobs) {
+    const int jb = base + (lane >> 4), r = lane & 15;
+    if (jb < njobs) {
+      const uint2 j = jobs[jb];
+      const int jx1 = (int)(j.x & 0x1FFF), jy1 = (int)((j.x >> 13) & 0x1FFF), jw = (int)((j.x >> 26) & 15) + 1;
+      const int jh = (int)(j.y & 15) + 1, jmx = (int)((j.y >> 4) & 0x3FF) - 512, jmy = (int)((j.y >> 14) & 0x3FF) - 512;
+      if (r < jh) {
+        const u8* sp = prv + (size_t)(jy1 + r + jmy) * S + (jx1 + jmx) * 3;
+        u8* dp = cur + (size_t)(jy1 + r) * S + jx1 * 3;
+        const int wb = jw * 3;
+        u32 v[12];
+#pragma unroll
+        for (int k = 0; k < 12; k++)
+          if (k * 4 < wb) __builtin_memcpy(&v[k], sp + k * 4, 4);
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+          if (k * 4 + 4 <= wb) __builtin_memcpy(dp + k * 4, &v[k], 4);
+          else if (k * 4 < wb)
+            for (int q = 0; q < wb - k * 4; q++) dp[k * 4 + q] = (u8)(v[k] >> (8 * q));
+        }
+      }
+    }
+  }
+}
+// slice `part` of `parts` of a plane copy (16 KiB pieces, sixteen 16-byte loads in flight per lane)
+__device__ __forceinline__ void copy_plane_part(u8* __restrict__ cur, const u8* __restrict__ prv, size_t bytes, int part, int parts, int lane) {
+  size_t o = (size_t)part * 16384 + (size_t)lane * 16;
+  const size_t step = (size_t)parts * 16384;
+  for (; o + 15 * 1024 + 16 <= bytes; o += step) {
+    uint4 v[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) v[k] = *(const uint4*)(prv + o + k * 1024);
+#pragma unroll
+    for (int k = 0; k < 16; k++) *(uint4*)(cur + o + k * 1024) = v[k];
+  }
+  if (part == 0) {  // what is left of the last, partial piece
+    const size_t whole = (bytes / 16384) * 16384;
+    // (a piece that did not fit the test above although it starts inside the plane)
+    for (size_t q = whole + (size_t)lane * 16; q + 16 <= bytes; q += 1024) *(uint4*)(cur + q) = *(const uint4*)(prv + q);
+    for (size_t q = (bytes & ~(size_t)15) + lane; q < bytes; q += 64) cur[q] = prv[q];
+  }
+}
+__device__ __forceinline__ void helper_loop(WaveLds& L, int S) {
+  const int lane = lane_id(), hw = (int)(threadIdx.x >> 6) - 1, nh = (int)(blockDim.x >> 6) - 1;
+  u32 seen = 0;
+  for (;;) {
+    u32 sq = lds_peek(&L.hc.seq);
+    while (sq == seen) {
+      __builtin_amdgcn_s_sleep(4);
+      sq = lds_peek(&L.hc.seq);
+    }
+    seen = sq;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const u32 op = lds_peek(&L.hc.op);
+    if (op == HOP_EXIT) break;
+    u8* cur = (u8*)(size_t)L.hc.dst;
+    const u8* prv = (const u8*)(size_t)L.hc.src;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the planes were written by other waves: nothing stale from this CU's L1
+    if (op == HOP_COPY) copy_plane_part(cur, prv, (size_t)L.hc.bytes, hw, nh, lane);
+    else copy_motion_jobs(L.jobs, 4 * hw, (int)L.hc.bytes, 4 * nh, cur, prv, S, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores have reached L2
+    if (lane == 0) __hip_atomic_fetch_add(&L.hc.done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+}
+// the chain's side
+__device__ __forceinline__ void help_post(WaveLds& L, u32 op, const u8* src, u8* dst, u32 bytes) {
+  if (lane_id() == 0) {
+    L.hc.op = op;
+    L.hc.src = (u64)(size_t)src;
+    L.hc.dst = (u64)(size_t)dst;
+    L.hc.bytes = bytes;
+    __hip_atomic_store(&L.hc.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add(&L.hc.seq, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+}
+__device__ __forceinline__ void help_wait(WaveLds& L) {
+  const u32 nh = L.hc.nhelp;
+  while (lds_peek(&L.hc.done) < nh) __builtin_amdgcn_s_sleep(2);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 // P-frame (DecompressP, screencap.cpp:1275-1432).  The new plane starts as a copy of the previous
 // one; motion blocks are copied from the previous plane, pixel-coded rects are rebuilt in an LDS
 // tile (with the row above and the column to the left as predictor context) and written back.
@@ -1231,21 +1410,27 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
   const int nbx = (W + 15) >> 4, nby = (H + 15) >> 4, nblocks = nbx * nby;
   D.template stamp<4>();
   __threadfence();  // the previous plane was written by this wave (or by another kernel): make it readable
-  {
-    const size_t bytes = (size_t)H * S;
-    size_t o = (size_t)lane * 16;
-    for (; o + 15 * 1024 + 16 <= bytes; o += 16384) {  // 16 KiB per trip, sixteen 16-byte loads in flight per lane
-      uint4 v[16];
-#pragma unroll
-      for (int k = 0; k < 16; k++) v[k] = *(const uint4*)(prv + o + k * 1024);
-#pragma unroll
-      for (int k = 0; k < 16; k++) *(uint4*)(cur + o + k * 1024) = v[k];
-    }
-    for (; o + 16 <= bytes; o += 1024) *(uint4*)(cur + o) = *(const uint4*)(prv + o);
-    for (size_t q = (bytes & ~(size_t)15) + lane; q < bytes; q += 64) cur[q] = prv[q];
+  int nhelp = 0;
+  if constexpr (DEC::kHelpers) nhelp = (int)D.L.hc.nhelp;
+  auto hpost = [&](u32 op, u32 bytes) __attribute__((always_inline)) {
+    if constexpr (DEC::kHelpers) help_post(D.L, op, prv, cur, bytes);
+  };
+  auto hwait = [&]() __attribute__((always_inline)) {
+    if constexpr (DEC::kHelpers) help_wait(D.L);
+  };
+  bool copy_pending = false;
+  if (nhelp) {  // the helpers copy the plane while this wave decodes the header and the block types
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (this wave's stores to the previous plane have reached L2)
+    hpost(HOP_COPY, (u32)((size_t)H * S));
+    copy_pending = true;
+  } else {
+    copy_plane_part(cur, prv, (size_t)H * S, 0, 1, lane);
   }
   const u32 first = *(const volatile u8*)head;
-  if (SCPR_UNLIKELY(!(first & 1u))) return;  // nothing changed (:1286-1291)
+  if (SCPR_UNLIKELY(!(first & 1u))) {  // nothing changed (:1286-1291)
+    if (copy_pending) hwait();
+    return;
+  }
   D.stream_init(head + 1);
   auto get_x = [&]() __attribute__((always_inline)) {
     D.tick();
@@ -1258,6 +1443,7 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
   const int xx2 = (hi << 8) + lo;
   if (SCPR_UNLIKELY(xx2 >= nblocks || xx1 > xx2)) {
     D.bad = true;
+    if (copy_pending) hwait();
     return;
   }
   for (int i = lane; i < nblocks; i += 64) bts[i] = 0;
@@ -1275,6 +1461,7 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
     b += n;
   }
   wave_fence();
+  if (copy_pending) hwait();  // from here on the plane is touched
   D.template stamp<5>();
   u32 lastpix = 0;  // cx = cx1 = 0 (:1317)
   int lastmx = 0, lastmy = 0;
@@ -1285,6 +1472,13 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
   // bytes in flight together); the source is the previous plane, which this frame never modifies
   auto flush_jobs = [&]() __attribute__((always_inline)) {
     wave_fence();
+    if (nhelp && njobs > 8) {  // enough blocks to be worth a hand-over: the helpers take four blocks per wave and trip
+      hpost(HOP_JOBS, (u32)njobs);
+      hwait();
+      njobs = 0;
+      wave_fence();
+      return;
+    }
     for (int base = 0; base < njobs; base += 4) {
       const int jb = base + (lane >> 4), r = lane & 15;
       if (jb < njobs) {
@@ -1385,8 +1579,11 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
     auto prun = [&](auto fast_tag) __attribute__((always_inline)) {
       constexpr bool FAST = decltype(fast_tag)::value;
       const int last_t = pt;
-      D.prefetch_n();
+      D.template stamp<7>();
       pt = D.template fixed_p<!FAST>(last_t);
+      D.template stamp<0>();
+      D.template event<13>();
+      if (pt == 0) D.template event<14>();
       u32 px = lastpix;
       if (pt == 0) {
         u32 a = (lastpix >> 18) & 63, bb = (lastpix >> 10) & 63;
@@ -1399,7 +1596,9 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
           a = c >> 2;
         }
       }
+      D.template stamp<1>();
       int rem = D.template fixed_n<!FAST>(pt);
+      D.template stamp<2>();
       if (FAST) D.ndec += pt == 0 ? 5 : 2;
       if (SCPR_UNLIKELY(rem < 1)) {
         D.bad = true;
@@ -1477,15 +1676,30 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
 }
 
 template <bool HAS_P>
-__global__ __launch_bounds__(64) void k_decode_gop_w(const u8* __restrict__ packets, const u8* packets_end, const DecFrame* __restrict__ frames, const DecGop* __restrict__ gops,
+__global__ __launch_bounds__(HAS_P ? 512 : 64) void k_decode_gop_w(const u8* __restrict__ packets, const u8* packets_end, const DecFrame* __restrict__ frames, const DecGop* __restrict__ gops,
                                                      u8* __restrict__ planes, Geom g, DecRec* __restrict__ states, Arena arena, int f0, u32* __restrict__ status, int ring_bytes,
-                                                     FixedBlob* __restrict__ fixedstore, int far_x, int far_y) {
+                                                     FixedBlob* __restrict__ fixedstore, int far_x, int far_y, int ndc, int dcache_off) {
   __shared__ WaveLds L;
-  extern __shared__ __align__(16) u8 pix[];  // ring_bytes = 4 * (power of two >= W + 512) pixels, then (P-frames) one byte per 16x16 block
+  // ring_bytes = 4 * (power of two >= W + 512) pixels, then (P-frames) one byte per 16x16 block, then (at dcache_off) ndc dense tables
+  extern __shared__ __align__(16) u8 pix[];
   const DecGop gop = gops[blockIdx.x];
   const int lane = lane_id();
   for (int i = lane; i < CACHE_N; i += 64) L.crec[i][3] = kNoCtx;  // empty cache
+  if (threadIdx.x < 64) L.dtag[lane] = 0;
+  if (HAS_P) {
+    if (threadIdx.x == 0) L.hc.seq = 0, L.hc.op = 0, L.hc.done = 0, L.hc.nhelp = (blockDim.x >> 6) - 1;
+    __syncthreads();
+    if (threadIdx.x >= 64) {  // helper waves: bulk copies for the chain (wave 0), until it says stop
+      helper_loop(L, g.S);
+      return;
+    }
+  }
   WaveDec D(L, packets, packets_end, states + (size_t)blockIdx.x * NCOLCTX, arena, f0);
+  if (ndc) {
+    D.dcache = pix + dcache_off;
+    D.dtag = L.dtag;
+    D.dmask = (u32)ndc - 1u;
+  }
   if (gop.load) D.fixed_load(&fixedstore[blockIdx.x]);
   else D.fixed_init();
   for (int fi = gop.first; fi < gop.first + gop.count && !D.bad; fi++) {
@@ -1499,12 +1713,14 @@ __global__ __launch_bounds__(64) void k_decode_gop_w(const u8* __restrict__ pack
       decode_inter_frame(D, g, dst, planes + (size_t)fr.prev_slot * g.plane_stride, packets + fr.src_off, pix + ring_bytes, far_x, far_y);
     }
   }
+  if (HAS_P && L.hc.nhelp) help_post(L, HOP_EXIT, nullptr, nullptr, 0);
   D.flush_records();
+  D.flush_tabs();
   D.fixed_store(&fixedstore[blockIdx.x]);
   if (D.bad && lane == 0) atomicOr(status, 4u);
 #ifdef SCPR_PROFILE
   if (lane == 0)
-    for (int i = 0; i < 16; i++) atomicAdd((unsigned long long*)&g_prof[i], (unsigned long long)D.prof[i]);
+    for (int i = 0; i < 24; i++) atomicAdd((unsigned long long*)&g_prof[i], (unsigned long long)(i == 15 ? D.dmiss : D.prof[i]));
 #endif
 }
 

@@ -19,6 +19,7 @@ from screenpressor_amd import codec as K
 from screenpressor_amd.synth import DesktopSequence
 K._LIB_PATH = LIB
 n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 16
+skip = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 0  # --ip: P-frames decoded before the profiled ones (an aged GOP)
 W, H = 1920, 1080
 seq = DesktopSequence(W, H, seed=1)
 frames = torch.from_numpy(seq.frames(n)).cuda().reshape(n, -1)
@@ -27,13 +28,25 @@ c.Init(W, H, 32)
 IP = "--ip" in sys.argv  # one GOP: a key frame and n-1 P-frames (sections 5-7 of decode_inter_frame)
 pk, sizes, ft = c.CompressBatch(frames, [0] + [1] * (n - 1) if IP else [0] * n)
 L = K.load_library()
-out = (C.c_ulonglong * 16)()
+out = (C.c_ulonglong * 24)()
+if IP and skip:  # age the GOP: the first skip + 1 frames are decoded before the counters are cleared
+    off = int(np.sum(sizes[:skip + 1]))
+    d = K.ScreenCodec()
+    d.Init(W, H, 32)
+    r, dec0 = d.DecompressBatch(pk[:off], sizes[:skip + 1], ft[:skip + 1])
+    L.scpr_debug_profile(out)
+    r, dec = d.DecompressBatch(pk[off:].clone(), sizes[skip + 1:], ft[skip + 1:])
+    torch.cuda.synchronize()
+    assert torch.equal(dec.reshape(-1), frames[skip + 1:].reshape(-1))
+    n = n - skip - 1
+else:
+    L.scpr_debug_profile(out)
+    r, dec = c.DecompressBatch(pk, sizes, ft)
+    torch.cuda.synchronize()
+    assert torch.equal(dec.reshape(-1), frames.reshape(-1))
 L.scpr_debug_profile(out)
-r, dec = c.DecompressBatch(pk, sizes, ft)
-torch.cuda.synchronize()
-assert torch.equal(dec.reshape(-1), frames.reshape(-1))
-L.scpr_debug_profile(out)
-ev = np.array(list(out)[8:], dtype=np.float64)
+ev = np.array(list(out)[8:16], dtype=np.float64)
+ex = np.array(list(out)[16:], dtype=np.float64)
 v = np.array(list(out)[:8], dtype=np.float64)
 names = ["P", "colour", "N", "fill", "rows/loop", "P-frame: plane copy, header, block types", "P-frame: rect border + write-back, motion copies", "P-frame: runs"]
 tot = v.sum()
@@ -41,5 +54,8 @@ print("ticks per frame: %.0f" % (tot / n))
 for nm, x in zip(names, v):
     if x:
         print("%-50s %5.1f %%   %.0f ticks/frame" % (nm, 100 * x / tot, x / n))
-for nm, x in zip(["colour symbols", "record cache misses", "dense-table symbols", "raw symbols", "small-table slow path", "runs", "literal runs", "run lengths above 63"], ev):
+for nm, x in zip(["colour symbols", "record cache misses", "dense-table symbols", "raw symbols", "small-table slow path", "runs", "literal runs", "dense-table cache misses"], ev):
     print("%-50s %.0f per frame" % (nm, x / n))
+print("dense fast-path hits per frame: %.0f" % (ex[0] / n))
+for nm, tt, cc in (("small-table", ex[1], ex[5] - 0), ("dense", ex[2], ex[6]), ("raw", ex[3], 0), ("record-miss", ex[4], ex[7])):
+    print("colour() ticks in %-12s symbols: %.0f per frame  (count %.0f)" % (nm, tt / n, cc / n))
