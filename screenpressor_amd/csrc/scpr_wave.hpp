@@ -1556,23 +1556,26 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
     if (njobs) flush_jobs();  // a copied block may be this rect's left/top context
     // pixel-coded rect (:1370-1421): context border from the plane, then runs inside the tile
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores to the plane have reached L2
+    u32 border = 0;
+    int border_at = 0;
     {
       // the 33 border pixels (row above: lanes 0..16, column to the left: lanes 17..32) in ONE round trip to L2 - a
       // loop over the 289 tile words with the loads inside waits for L2 five times per rect
+      // (The tile is not cleared: every cell is written - the 33 border cells below, the rect's cells by its runs - before
+      // anything that is kept reads it.)  The border is asked for here and put into the tile when the first run of the rect is
+      // about to be filled in: the symbols of that run (type, literal, length) are decoded while the L2 round trip is under way.
       const int ty = lane < 17 ? 0 : lane - 16, tx = lane < 17 ? lane : 0;
-      u32 v = 0;
       if (lane < 33 && ty <= h && tx <= w) {
         const int xq = x1 - 1 + tx, yq = y1 - 1 + ty;
-        if (xq >= 0 && yq >= 0) v = ld3_l2(cur + (size_t)yq * S + xq * 3);
+        if (xq >= 0 && yq >= 0) border = ld3_l2(cur + (size_t)yq * S + xq * 3);
       }
-      for (int i = lane; i < 17 * 17; i += 64) tile[i] = 0;
-      wave_fence();
-      if (lane < 33) tile[ty * 17 + tx] = v;
+      border_at = ty * 17 + tx;
     }
-    wave_fence();
+    bool border_due = true;
     D.template stamp<6>();
     int x = x1, y = y1, pt = 0;
     const int lc = min(lane, 15);
+    const int rcpw = (65536 + w - 1) / w;  // (li * rcpw) >> 16 == li / w for li <= 256, w <= 16
     // One run of the rect, in two instances like the key-frame loop: the careful one tests for the end of the coder
     // block after every symbol, the fast one is entered while the block cannot end within a run and counts the
     // run's symbols in one go.  A refused stream ends the rect (y = y2) instead of leaving the loops from inside.
@@ -1599,11 +1602,57 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
       D.template stamp<1>();
       int rem = D.template fixed_n<!FAST>(pt);
       D.template stamp<2>();
+      if constexpr (!FAST) {  // (a rect always starts in this instance)
+        if (border_due) {
+          wave_fence();
+          if (lane < 33) tile[border_at] = border;
+          wave_fence();
+          border_due = false;
+        }
+      }
       if (FAST) D.ndec += pt == 0 ? 5 : 2;
       if (SCPR_UNLIKELY(rem < 1)) {
         D.bad = true;
         rem = 0;
         y = y2;
+      }
+      // Literal (0), left (1), above (2) and previous frame (3): no pixel of the run depends on another pixel of the run that
+      // is not a plain copy of it, so the whole run is one pass - lane i takes the run's i-th pixel wherever the rect's rows
+      // wrap it to.  "Left" is the pixel left of the run's start on its first row and the column left of the rect on the rows
+      // below; "above" of a pixel further than a rect row into the run is another pixel of the run, and through it the pixel
+      // above run pixel i mod w.  (Above-left and the gradient go row by row in the loop below.)
+      if (SCPR_LIKELY(!((0x30 >> pt) & 1)) && rem > 0) {
+        const int li0 = (y - y1) * w + (x - x1);  // position in the rect, row-major
+        if (SCPR_UNLIKELY(li0 + rem > w * h)) {  // the run goes on below the rect
+          D.bad = true;
+          y = y2;
+        } else {
+          const int row0 = y - y1, col0 = x - x1;
+          u32 v = px;
+          for (int b = 0; b < rem; b += 64) {
+            const int i = min(b + lane, rem - 1);
+            const bool act = b + lane < rem;
+            const int li = li0 + i;
+            const int row = (li * rcpw) >> 16, col = li - row * w;
+            wave_fence();
+            if (pt == 1) {
+              v = tile[(row + 1) * 17 + (row == row0 ? col0 : 0)];
+            } else if (pt == 2) {
+              const int ls = li0 + (i - ((i * rcpw) >> 16) * w);
+              const int rs = (ls * rcpw) >> 16;
+              v = tile[rs * 17 + (ls - rs * w) + 1];
+            } else if (pt == 3) {
+              v = ld3(prv + (size_t)(y1 + row) * S + (x1 + col) * 3);
+            }
+            if (act) tile[(row + 1) * 17 + col + 1] = v;
+          }
+          wave_fence();
+          lastpix = rdl(v, (rem - 1) & 63) & 0xFFFFFFu;
+          const int le = li0 + rem, re = (le * rcpw) >> 16;
+          y = y1 + re;
+          x = x1 + (le - re * w);
+        }
+        rem = 0;
       }
       while (rem > 0) {
         if (SCPR_UNLIKELY(y >= y2)) {  // the run goes on below the rect
