@@ -131,6 +131,7 @@ struct ColHdr {
   int fmax;                             // kinds 4/5: the count of entry maxpos (derived: saves reading it back for every symbol)
   int dirty;                            // decoder: kind, fshift or d changed (the record word that holds them and maxpos is rewritten)
   u32 dense;
+  u32 top;                              // kinds 4/5: symbol | P << 8 of entry maxpos (small_top): what a hit on the top entry needs
 };
 // Small table (kinds 4/5): entry i in lane i, sorted by symbol, one packed word per lane:
 //   symbol | count << 8 | P << 20,   P = sum of the counts of the entries before it.
@@ -229,7 +230,43 @@ struct WaveModel {
     h.fmax = 0;  // see small_fmax()
     h.dirty = 0;
     h.dense = h2;
+    h.top = 0;
     return h;
+  }
+  // The top entry (the one the spare code space goes to) takes most of the symbols of a small table - 85 % on desktop
+  // content, and more than half of all colour symbols belong to contexts that have met ONE symbol.  Its symbol and the sum of
+  // the counts before it, kept beside the header, turn such a symbol into scalar arithmetic (top_hit): no search, no lane read.
+  // They change only when a symbol takes another path, and every such path ends with this refresh.
+  __device__ __forceinline__ u32 small_top(const ColHdr& h, u32 w) {
+    const u32 wt = rdl(w, h.maxpos);
+    return sm_sym(wt) | (sm_p(wt) << 8);
+  }
+  // A symbol that is the top entry of a small table, no rescale due after it.  DEC: `in` is the coder value, else the symbol.
+  // Returns a negative number and has applied the symbol (w, h.total, h.fmax updated; c, ofr, ocf set) - or a non-negative one
+  // with nothing touched.  Same arithmetic as small_hit() for p == maxpos.
+  template <bool DEC>
+  __device__ __forceinline__ int top_hit(ColHdr& h, u32& w, int in, int& c, u32& ofr, u32& ocf) {
+    const int tot = h.total, mp = h.maxpos;
+    const int sh = __builtin_clz((u32)(tot - 1)) - 20, bonus = (kProbScale >> sh) - tot;  // == (kProbScale - (tot << sh)) >> sh
+    const int ts = (int)(h.top & 255u);
+    const int ap = ts + (int)(h.top >> 8) - mp, width = h.fmax + bonus;
+    const int norescale = tot + 2 * kStepSmall - kProbScale - 1;  // negative: no rescale after this symbol
+    int t;
+    if (DEC) {
+      const int vv = in >> sh;
+      t = (vv - ap - width) & (ap - vv - 1) & norescale;  // each negative when fine: below the entry's end, not below its start
+    } else {
+      t = (ts == in ? -1 : 0) & norescale;
+    }
+    if (SCPR_LIKELY(t < 0)) {
+      ofr = (u32)width << sh;
+      ocf = (u32)ap << sh;
+      w += l15 == mp ? (u32)kStepSmall << 8 : ((u32)(l15 - mp - 1) < (u32)(h.d - mp - 1) ? (u32)kStepSmall << 20 : 0u);
+      h.total = tot + kStepSmall;
+      h.fmax += kStepSmall;
+      c = ts;
+    }
+    return t;
   }
   static __device__ __forceinline__ u32 pack0(const ColHdr& h) { return (u32)h.kind | ((u32)h.maxpos << 8) | ((u32)h.fshift << 16); }
   static __device__ __forceinline__ u32 pack1(const ColHdr& h) { return (u32)h.d | ((u32)h.total << 16); }
@@ -1063,11 +1100,22 @@ struct WaveDec : WaveModel {
     const u32 v = x & (kProbScale - 1);
     int small0 = (int)h0;  // sign bit: a small table (kind 4 or 5)
     if (SCPR_LIKELY(small0 < 0)) {
-      int t = small_hit(h, w, (int)v, c, fr, cf);
-      asm volatile("" : "+s"(t));  // (keeps the test inside small_hit and this one apart)
-      if (SCPR_UNLIKELY(t >= 0)) {
-        event<12>();
-        c = small_op<true>(r, h, w, (int)v, fr, cf);
+      h.top = rfl(hz);
+      int tt = top_hit<true>(h, w, (int)v, c, fr, cf);
+      asm volatile("" : "+s"(tt));  // (keeps the test inside top_hit and this one apart)
+      if (SCPR_UNLIKELY(tt >= 0)) {  // another entry, an unmet symbol, or a rescale is due
+        int t = small_hit(h, w, (int)v, c, fr, cf);
+        asm volatile("" : "+s"(t));
+        if (SCPR_UNLIKELY(t >= 0)) {
+          event<12>();
+          c = small_op<true>(r, h, w, (int)v, fr, cf);
+        }
+        if ((h.kind | 1) == 5) {  // still a small table: its top entry may have moved, or the counts before it have changed
+          const u32 nt = small_top(h, w);
+          asm volatile("ds_write_b32 %0, %1 offset:8" ::"v"(ra), "v"(nt) : "memory");
+        }
+      } else {
+        event<17>();
       }
       wave_fence();
       // the entries go back from every row of 16 lanes alike: no lane mask (a full table has just become a dense
@@ -1084,7 +1132,11 @@ struct WaveDec : WaveModel {
         c = (int)take_byte();
         note_raw(r, h, c, w);
         wave_fence();
-        if ((h.kind == 4 || h.kind == 5) && lane < 16) r[4 + lane] = w;  // promoted to a small table
+        if (h.kind == 4 || h.kind == 5) {  // promoted to a small table
+          if (lane < 16) r[4 + lane] = w;
+          const u32 nt = small_top(h, w);
+          if (lane == 0) r[2] = nt;
+        }
         wave_fence();
         scalar_hdr(h);
       } else {
@@ -1852,6 +1904,7 @@ __global__ __launch_bounds__(64) void k_colour_chain_w(const u32* __restrict__ s
         if (h.kind == 4 || h.kind == 5) {
           M.load_small(rec, h.d, T);
           h.fmax = M.small_fmax(h, T);
+          h.top = M.small_top(h, T);
         }
       }
     }
@@ -1868,12 +1921,20 @@ __global__ __launch_bounds__(64) void k_colour_chain_w(const u32* __restrict__ s
         wave_fence();
         // plain ifs, the common case first (see the decoder's colour())
         int small = ((h.kind | 1) == 5) ? -1 : 0;
-        if (SCPR_LIKELY(small < 0)) M.small_op<false>(rec, h, T, c, fr, cf);
+        if (SCPR_LIKELY(small < 0)) {
+          int cc, tt = M.top_hit<false>(h, T, c, cc, fr, cf);  // the symbol of the top entry: scalar arithmetic only
+          tt = (int)rfl((u32)tt);
+          if (SCPR_UNLIKELY(tt >= 0)) {
+            M.small_op<false>(rec, h, T, c, fr, cf);
+            if ((h.kind | 1) == 5) h.top = M.small_top(h, T);
+          }
+        }
         small = (int)rfl((u32)small);  // (keeps the two tests apart)
         if (SCPR_UNLIKELY(small >= 0)) {
           if (h.kind < 4) M.note_raw(rec, h, c, T);
           else M.dense_op<false>(rec, h, c, fr, cf);
           WaveModel::scalar_hdr(h);
+          if ((h.kind | 1) == 5) h.top = M.small_top(h, T);
         }
         if (lane == j) mine = (fr & 0xFFFFu) | (cf << 16);
       }
