@@ -241,15 +241,23 @@ struct WaveModel {
     const u32 wt = rdl(w, h.maxpos);
     return sm_sym(wt) | (sm_p(wt) << 8);
   }
+  // the table brought up to date with the top-entry hits that top_hit<DEC, true> only counted in the header
+  __device__ __forceinline__ void small_settle(const ColHdr& h, u32& w) {
+    const u32 delta = (u32)h.fmax - (h.top >> 20);
+    w += l15 == h.maxpos ? delta << 8 : ((u32)(l15 - h.maxpos - 1) < (u32)(h.d - h.maxpos - 1) ? delta << 20 : 0u);
+  }
   // A symbol that is the top entry of a small table, no rescale due after it.  DEC: `in` is the coder value, else the symbol.
   // Returns a negative number and has applied the symbol (w, h.total, h.fmax updated; c, ofr, ocf set) - or a non-negative one
   // with nothing touched.  Same arithmetic as small_hit() for p == maxpos.
-  template <bool DEC>
+  // LAZY (the decoder): the table itself is left alone - the count of the top entry is h.fmax, and what the entries above it
+  // have not been told yet is h.fmax minus the count the table holds for the top entry (kept in bits 20.. of h.top); the next
+  // symbol that takes another path brings the table up to date first (small_settle).
+  template <bool DEC, bool LAZY = false>
   __device__ __forceinline__ int top_hit(ColHdr& h, u32& w, int in, int& c, u32& ofr, u32& ocf) {
     const int tot = h.total, mp = h.maxpos;
     const int sh = __builtin_clz((u32)(tot - 1)) - 20, bonus = (kProbScale >> sh) - tot;  // == (kProbScale - (tot << sh)) >> sh
     const int ts = (int)(h.top & 255u);
-    const int ap = ts + (int)(h.top >> 8) - mp, width = h.fmax + bonus;
+    const int ap = ts + (int)((h.top >> 8) & 0xFFFu) - mp, width = h.fmax + bonus;
     const int norescale = tot + 2 * kStepSmall - kProbScale - 1;  // negative: no rescale after this symbol
     int t;
     if (DEC) {
@@ -261,7 +269,7 @@ struct WaveModel {
     if (SCPR_LIKELY(t < 0)) {
       ofr = (u32)width << sh;
       ocf = (u32)ap << sh;
-      w += l15 == mp ? (u32)kStepSmall << 8 : ((u32)(l15 - mp - 1) < (u32)(h.d - mp - 1) ? (u32)kStepSmall << 20 : 0u);
+      if (!LAZY) w += l15 == mp ? (u32)kStepSmall << 8 : ((u32)(l15 - mp - 1) < (u32)(h.d - mp - 1) ? (u32)kStepSmall << 20 : 0u);
       h.total = tot + kStepSmall;
       h.fmax += kStepSmall;
       c = ts;
@@ -1101,9 +1109,10 @@ struct WaveDec : WaveModel {
     int small0 = (int)h0;  // sign bit: a small table (kind 4 or 5)
     if (SCPR_LIKELY(small0 < 0)) {
       h.top = rfl(hz);
-      int tt = top_hit<true>(h, w, (int)v, c, fr, cf);
+      int tt = top_hit<true, true>(h, w, (int)v, c, fr, cf);  // (a hit changes the header only: nothing of the table is stored)
       asm volatile("" : "+s"(tt));  // (keeps the test inside top_hit and this one apart)
       if (SCPR_UNLIKELY(tt >= 0)) {  // another entry, an unmet symbol, or a rescale is due
+        small_settle(h, w);
         int t = small_hit(h, w, (int)v, c, fr, cf);
         asm volatile("" : "+s"(t));
         if (SCPR_UNLIKELY(t >= 0)) {
@@ -1111,16 +1120,17 @@ struct WaveDec : WaveModel {
           c = small_op<true>(r, h, w, (int)v, fr, cf);
         }
         if ((h.kind | 1) == 5) {  // still a small table: its top entry may have moved, or the counts before it have changed
-          const u32 nt = small_top(h, w);
+          const u32 nt = small_top(h, w) | ((u32)h.fmax << 20);
           asm volatile("ds_write_b32 %0, %1 offset:8" ::"v"(ra), "v"(nt) : "memory");
         }
+        wave_fence();
+        // the entries go back from every row of 16 lanes alike: no lane mask (a full table has just become a dense
+        // one: then w holds what is there already)
+        asm volatile("ds_write_b32 %0, %1" ::"v"(ea), "v"(w) : "memory");
       } else {
         event<17>();
       }
       wave_fence();
-      // the entries go back from every row of 16 lanes alike: no lane mask (a full table has just become a dense
-      // one: then w holds what is there already)
-      asm volatile("ds_write_b32 %0, %1" ::"v"(ea), "v"(w) : "memory");
     }
     asm volatile("" : "+s"(small0));  // keeps the two tests apart (merged, they come back as if/else)
     if (SCPR_UNLIKELY(small0 >= 0)) {
@@ -1134,7 +1144,7 @@ struct WaveDec : WaveModel {
         wave_fence();
         if (h.kind == 4 || h.kind == 5) {  // promoted to a small table
           if (lane < 16) r[4 + lane] = w;
-          const u32 nt = small_top(h, w);
+          const u32 nt = small_top(h, w) | ((u32)h.fmax << 20);
           if (lane == 0) r[2] = nt;
         }
         wave_fence();
