@@ -563,6 +563,28 @@ struct WaveModel {
     return c;
   }
 
+  // Encoder chains: one context per chain, so a dense context's table (24 bytes per lane) stays in registers for the chain - a
+  // symbol that has been met, with no rescale due after it, is two lane reads and a masked add; anything else goes through
+  // dense_op() on the table in the arena (the caller stores the registers first and loads them again afterwards).  A chain of
+  // 13000 symbols through a dense context was 13000 L2 round trips (the longest chain of a frame: it set the stage's time).
+  __device__ __forceinline__ int dense_enc_hit(ColHdr& h, int c, u32x2 fq, u32x2 cu, u32x2& cq, u32 bits, u32& ofr, u32& ocf) {
+    const int own = c >> 2, kk = c & 3;
+    const u32 fw = rdl(kk < 2 ? fq.x : fq.y, own), cw = rdl(kk < 2 ? cu.x : cu.y, own);
+    const u32 sh16 = (u32)(kk & 1) * 16u;
+    const int step = h.kind == 7 ? kStepDense : kStepHash << h.fshift;
+    const u32 met = (rdl(bits, own) >> kk) & 1u;  // (kind 7: every symbol counts as met)
+    const int tst = (met ? -1 : 0) & (h.total + 2 * step - kProbScale - 1);  // each negative when fine
+    if (SCPR_LIKELY(tst < 0)) {
+      ofr = (fw >> sh16) & 0xFFFFu;
+      ocf = (cw >> sh16) & 0xFFFFu;
+      const u32 inc = (u32)step << sh16;
+      const bool mine = lane == own;
+      cq.x += (mine && kk < 2) ? inc : 0u;
+      cq.y += (mine && kk >= 2) ? inc : 0u;
+      h.total += step;
+    }
+    return tst;
+  }
   // kinds 6/7: Cx6/Cx7 decode and encode (ans_contexts.h:640-740, :953-997), 4 symbols per lane
   template <bool DEC>
   __device__ __forceinline__ int dense_op(u32* r, ColHdr& h, int in, u32& ofr, u32& ocf) {
@@ -1903,6 +1925,9 @@ __global__ __launch_bounds__(64) void k_colour_chain_w(const u32* __restrict__ s
     const int gen = (int)(q / NCOLCTX), ctx = (int)(q - (u32)gen * NCOLCTX);
     ColHdr h = WaveModel::unpack(0, 0, 0);
     u32 T = kSmallNone;
+    bool tlive = false;  // the context's dense table is in tfq / tcu / tcq (dense_enc_hit), tbits = which of a lane's symbols have been met
+    u32x2 tfq = {0u, 0u}, tcu = {0u, 0u}, tcq = {0u, 0u};
+    u32 tbits = 0;
     wave_fence();
     if (gen == 0 && cp.load_first) {  // continue the model of this context from the previous call
       const u32* src = (const u32*)&cp.states_in[ctx];
@@ -1941,9 +1966,26 @@ __global__ __launch_bounds__(64) void k_colour_chain_w(const u32* __restrict__ s
         }
         small = (int)rfl((u32)small);  // (keeps the two tests apart)
         if (SCPR_UNLIKELY(small >= 0)) {
-          if (h.kind < 4) M.note_raw(rec, h, c, T);
-          else M.dense_op<false>(rec, h, c, fr, cf);
-          WaveModel::scalar_hdr(h);
+          if (h.kind < 4) {
+            M.note_raw(rec, h, c, T);
+            WaveModel::scalar_hdr(h);
+          } else {
+            DenseTab* tp = arena.tabs + h.dense;
+            if (!tlive) {
+              wave_fence();
+              tfq = tab_ld<false>(tp->freq, lane), tcu = tab_ld<false>(tp->cum, lane), tcq = tab_ld<false>(tp->cnt, lane);
+              tbits = h.kind == 6 ? M.set_bits4(rec) : 15u;
+              tlive = true;
+            }
+            int tt = M.dense_enc_hit(h, c, tfq, tcu, tcq, tbits, fr, cf);
+            tt = (int)rfl((u32)tt);
+            if (SCPR_UNLIKELY(tt >= 0)) {  // a symbol the context has not met, or a rescale: on the table in the arena
+              tab_st<false>(tp->cnt, lane, tcq);
+              M.dense_op<false>(rec, h, c, fr, cf);
+              WaveModel::scalar_hdr(h);
+              tlive = false;
+            }
+          }
           if ((h.kind | 1) == 5) h.top = M.small_top(h, T);
         }
         if (lane == j) mine = (fr & 0xFFFFu) | (cf << 16);
@@ -1952,6 +1994,7 @@ __global__ __launch_bounds__(64) void k_colour_chain_w(const u32* __restrict__ s
     }
     if (gen == cp.ngens - 1) {  // live generation: keep the state for the next call
       wave_fence();
+      if (tlive) tab_st<false>(arena.tabs[h.dense].cnt, lane, tcq);  // (only the counts change between rescales)
       if (h.kind == 4 || h.kind == 5) M.store_small(rec, h.d, T);
       M.store_header(rec, h);
       if (lane == 0) rec[3] = cp.stamp_out;
