@@ -91,7 +91,7 @@ struct scpr_codec {
   u32 last_flat_rgb = 0;
   int slots = 0;  // frames processed per chunk
   // per-slot worst-case buffers
-  DevBuf planes, exitmap, entry, runrec, tilecnt, tileoff, hdrrec, hdrcnt, frametot;
+  DevBuf planes, exitmap, entry, runrec, tilecnt, tileoff, hdrrec, hdrcnt, frametot, tnmap;
   // per-batch buffers
   DevBuf flags, slotlist, genlist, bases, totals, runs, runpos, keys[2], vals[2], cstart, sorttmp, entries, ranges;
   DevBuf rblocks, rscratch, rsize, packets, pktoff, blkdst, outsizes, total64, arena, arena_top, err, rcp;
@@ -185,13 +185,14 @@ static int ensure_codec(scpr_codec* c, int version) {  // CreateCodec + CScreenC
   g.workers = (int)p.workers;
   g.plane_stride = (u32)(((size_t)g.H * g.S + 16 + 255) & ~(size_t)255);
   // chunk size: keep the per-slot worst-case buffers within ~6 GiB
-  size_t per_slot = (size_t)g.plane_stride + (size_t)g.ntiles * (512 + 2 + TILE * 4 + 16) + (size_t)(g.W + 2) * 4;
+  size_t per_slot = (size_t)g.plane_stride + (size_t)g.ntiles * (512 + 2 + TILE * 6 + 16) + (size_t)(g.W + 2) * 4;
   size_t s = (12ull << 30) / per_slot;
   c->slots = (int)std::min<size_t>(std::max<size_t>(s, 1), 512);
   const size_t ns = (size_t)c->slots + 1;  // +1: slot `slots` holds the previous frame of the stream
   HIPCHK(c->planes.reserve(ns * g.plane_stride));
   HIPCHK(hipMemsetAsync(c->planes.p, 0, ns * g.plane_stride, c->stream));
   HIPCHK(c->exitmap.reserve(ns * g.ntiles * 512));
+  HIPCHK(c->tnmap.reserve(ns * g.ntiles * TILE * 2));
   HIPCHK(c->entry.reserve(ns * g.ntiles * 2));
   HIPCHK(c->runrec.reserve(ns * g.ntiles * TILE * 4));
   HIPCHK(c->tilecnt.reserve(ns * g.ntiles * 8));
@@ -303,9 +304,10 @@ static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int n
     HIPCHK(hipMemcpyAsync(c->genlist.p, igens.data(), ni * 4, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(c->fidx.p, ifidx.data(), ni * 4, hipMemcpyHostToDevice, st));
     stage_begin(c, ST_CLASSIFY);
-    hipLaunchKernelGGL(k_tiles<false>, dim3(g.ntiles, ni), dim3(256), 0, st, planes, g, d_slots, c->exitmap.as<u8>(), (const u8*)nullptr, (u32*)nullptr, (u32*)nullptr);
+    hipLaunchKernelGGL(k_tiles, dim3(g.ntiles, ni), dim3(256), 0, st, planes, g, d_slots, c->exitmap.as<u8>(), c->tnmap.as<u16>());
     hipLaunchKernelGGL(k_entries, dim3(ni), dim3(64), 0, st, c->exitmap.as<u8>(), c->entry.as<u8>(), g, d_slots);
-    hipLaunchKernelGGL(k_tiles<true>, dim3(g.ntiles, ni), dim3(256), 0, st, planes, g, d_slots, (u8*)nullptr, c->entry.as<u8>(), c->runrec.as<u32>(), c->tilecnt.as<u32>());
+    hipLaunchKernelGGL(k_runs, dim3((g.ntiles + 255) / 256, ni), dim3(256), 0, st, g, d_slots, c->entry.as<u8>(), c->tnmap.as<u16>(), c->runrec.as<u32>(),
+                       c->tilecnt.as<u32>());
     hipLaunchKernelGGL(k_header, dim3(ni), dim3(64), 0, st, planes, g, d_slots, c->hdrrec.as<u32>(), c->hdrcnt.as<u32>());
     stage_end(c, ST_CLASSIFY);
     stage_begin(c, ST_SCAN);
@@ -541,7 +543,7 @@ void scpr_destroy(scpr_codec* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   (void)hipStreamSynchronize(c->stream2);
-  DevBuf* all[] = {&c->planes, &c->exitmap, &c->entry, &c->runrec, &c->tilecnt, &c->tileoff, &c->hdrrec, &c->hdrcnt, &c->frametot, &c->flags, &c->slotlist, &c->genlist,
+  DevBuf* all[] = {&c->planes, &c->tnmap, &c->exitmap, &c->entry, &c->runrec, &c->tilecnt, &c->tileoff, &c->hdrrec, &c->hdrcnt, &c->frametot, &c->flags, &c->slotlist, &c->genlist,
                    &c->bases, &c->totals, &c->runs, &c->runpos, &c->keys[0], &c->keys[1], &c->vals[0], &c->vals[1], &c->cstart, &c->sorttmp,
                    &c->entries, &c->ranges, &c->rblocks, &c->rscratch, &c->rsize, &c->packets, &c->pktoff, &c->blkdst, &c->outsizes, &c->total64, &c->arena,
                    &c->arena_top, &c->err, &c->rcp, &c->decframes, &c->decstates, &c->hoststage_in, &c->hoststage_out, &c->chainlists, &c->chaincounts, &c->kinds, &c->pidx, &c->fidx, &c->pframes, &c->pflag, &c->binfo, &c->smv, &c->btype, &c->bmv, &c->bcnt, &c->boff, &c->bflag, &c->pinfo, &c->ptot, &c->pbase, &c->misc, &c->miscpos, &c->miscranges, &c->mvs, &c->fixed_persist, &c->misc_persist, &c->colour_persist, &c->decgops, &c->decfixed, &c->dec_fixed_persist, &c->dec_colour_persist, &c->dec_arena, &c->dec_arena_top, &c->mvdict, &c->mvpre, &c->gmask};

@@ -2,11 +2,11 @@
 //
 // Encoder pipeline for a batch of frames resident in HBM:
 //   k_pack*           RGB32/24/16 -> packed RGB24 planes, flat-frame detection     (screencap.cpp:1652-1678, :1436-1444)
-//   k_tiles<false>    per 1024-pixel tile: predictor type + "fits" bitmaps via
-//                     wave ballots, greedy-run successor of every pixel, pointer
-//                     doubling in LDS -> exit map for every possible entry       (ClassifyPixelsI, :876-919)
+//   k_tiles           per 1024-pixel tile: predictor type + "fits" bitmaps via
+//                     wave ballots, greedy-run successor of every pixel (kept: type | length of the run that would start
+//                     there), pointer doubling in LDS -> exit map for every possible entry       (ClassifyPixelsI, :876-919)
 //   k_entries         chase the tile entries through the exit maps (one wave/frame)
-//   k_tiles<true>     same tiles again, mark the run starts on the real path, emit run records
+//   k_runs            one lane per tile walks the real path from its entry and writes the run records
 //   k_header          runs of the first row + pixel (0,1)                           (CompressI, :344-362)
 //   k_scan_tiles / k_bases   prefix sums -> run / symbol / colour-symbol offsets
 //   k_symbols         unified run list + (context,value,position) of every colour symbol   (WritePixel/EncodeRGB, :609-643)
@@ -307,15 +307,10 @@ __device__ __forceinline__ int block_excl_scan(int v, int* tot, int* wsum /*shar
 // exit map row: for every entry offset e < 255: [2e] = offset at which the path
 // leaves into the next tile, [2e+1] = type of the run that crosses the border.
 // tilecnt: {runs, literal runs} per tile.   runrec: rel_start | type<<10 | n<<16
-template <bool MARK>
-__global__ __launch_bounds__(256) void k_tiles(const u8* __restrict__ planes, Geom g, const int* __restrict__ slots, u8* __restrict__ exitmap,
-                                               const u8* __restrict__ entry, u32* __restrict__ runrec, u32* __restrict__ tilecnt) {
+__global__ __launch_bounds__(256) void k_tiles(const u8* __restrict__ planes, Geom g, const int* __restrict__ slots, u8* __restrict__ exitmap, u16* __restrict__ tnmap) {
   __shared__ u64 fm[4][24];
   __shared__ u8 ty[TILE];
-  __shared__ u16 lv[MARK ? 10 : 1][TILE];
-  __shared__ u32 lp[MARK ? 1 : 2][MARK ? 1 : TILE];  // first pass: successor | last run start << 16, one word per doubling step
-  __shared__ u8 mk[MARK ? TILE : 1];
-  __shared__ int wsum[5];
+  __shared__ u32 lp[2][TILE];  // successor | last run start << 16, one word per doubling step
   const int slot = slots[blockIdx.y], tile = blockIdx.x, tid = threadIdx.x;
   const u8* plane = planes + (size_t)slot * g.plane_stride;
   const int tstart = g.p0 + tile * TILE;
@@ -350,81 +345,30 @@ __global__ __launch_bounds__(256) void k_tiles(const u8* __restrict__ planes, Ge
     if (p < g.NP) {
       int n = ones_from(fm[fit_bit_of_type(ty[r])], r + 1, HALO - 1);
       j = (p + 1 + n >= g.NP) ? EXITED : r + 1 + n;
+      // for k_runs: type and length of the run that would start here (it never looks at a pixel again)
+      tnmap[((size_t)slot * g.ntiles + tile) * TILE + r] = (u16)((u32)ty[r] | ((u32)n << 8));
     }
-    lv[0][r] = (u16)j;
-    if (!MARK) lp[0][r] = (u32)j | ((u32)r << 16);
+    lp[0][r] = (u32)j | ((u32)r << 16);
   }
   __syncthreads();
-  if (!MARK) {
-    int cur = 0;
-    for (int it = 0; it < 10; it++) {
-      for (int k = 0; k < 4; k++) {
-        const int r = k * 256 + tid;
-        u32 v = lp[cur][r];
-        const u32 j = v & 0xFFFFu;
-        if (j < TILE) v = lp[cur][j];  // jump: the successor's successor, and the start of the run it sits in
-        lp[cur ^ 1][r] = v;
-      }
-      __syncthreads();
-      cur ^= 1;
-    }
-    if (tid < HALO) {
-      const u32 v = lp[cur][tid];
-      const int j = (int)(v & 0xFFFFu);
-      u8* row = exitmap + ((size_t)slot * g.ntiles + tile) * 512;
-      row[2 * tid] = (u8)(j == EXITED ? 255 : j - TILE);  // 255: the path ended inside this tile (frame end)
-      row[2 * tid + 1] = ty[v >> 16];
-    }
-  } else {
-    for (int lvl = 0; lvl < 9; lvl++) {
-      for (int k = 0; k < 4; k++) {
-        const int r = k * 256 + tid;
-        int j = lv[lvl][r];
-        lv[lvl + 1][r] = (u16)(j < TILE ? lv[lvl][j] : EXITED);
-      }
-      __syncthreads();
-    }
-    const int e = entry[((size_t)slot * g.ntiles + tile) * 2];
-    for (int k = 0; k < 4; k++) mk[k * 256 + tid] = 0;
-    __syncthreads();
-    if (tid == 0 && e < HALO) mk[e] = 1;  // e == 255: a run from an earlier tile already reached the frame end
-    __syncthreads();
-    for (int lvl = 9; lvl >= 0; lvl--) {
-      for (int k = 0; k < 4; k++) {
-        const int r = k * 256 + tid;
-        if (mk[r]) {
-          int j = lv[lvl][r];
-          if (j < TILE) mk[j] = 1;
-        }
-      }
-      __syncthreads();
-    }
-    // emit: thread t owns pixels 4t..4t+3 so that records come out in raster order
-    int cnt = 0, lit = 0;
+  int cur = 0;
+  for (int it = 0; it < 10; it++) {
     for (int k = 0; k < 4; k++) {
-      const int r = tid * 4 + k;
-      if (mk[r] && tstart + r < g.NP) {
-        cnt++;
-        lit += ty[r] == 0;
-      }
+      const int r = k * 256 + tid;
+      u32 v = lp[cur][r];
+      const u32 j = v & 0xFFFFu;
+      if (j < TILE) v = lp[cur][j];  // jump: the successor's successor, and the start of the run it sits in
+      lp[cur ^ 1][r] = v;
     }
-    int tot = 0, totlit = 0;
-    int off = block_excl_scan(cnt, &tot, wsum);
     __syncthreads();
-    block_excl_scan(lit, &totlit, wsum);
-    u32* rec = runrec + ((size_t)slot * g.ntiles + tile) * TILE;
-    for (int k = 0; k < 4; k++) {
-      const int r = tid * 4 + k;
-      if (mk[r] && tstart + r < g.NP) {
-        int j = lv[0][r];
-        int n = (j == EXITED) ? g.NP - (tstart + r) : j - r;
-        rec[off++] = (u32)r | ((u32)ty[r] << 10) | ((u32)n << 16);
-      }
-    }
-    if (tid == 0) {
-      tilecnt[((size_t)slot * g.ntiles + tile) * 2] = (u32)tot;
-      tilecnt[((size_t)slot * g.ntiles + tile) * 2 + 1] = (u32)totlit;
-    }
+    cur ^= 1;
+  }
+  if (tid < HALO) {
+    const u32 v = lp[cur][tid];
+    const int j = (int)(v & 0xFFFFu);
+    u8* row = exitmap + ((size_t)slot * g.ntiles + tile) * 512;
+    row[2 * tid] = (u8)(j == EXITED ? 255 : j - TILE);  // 255: the path ended inside this tile (frame end)
+    row[2 * tid + 1] = ty[v >> 16];
   }
 }
 
@@ -454,6 +398,40 @@ __global__ __launch_bounds__(64) void k_entries(const u8* __restrict__ exitmap, 
     }
     __syncthreads();
   }
+}
+
+// The runs of every tile, from where k_entries says the frame's path enters it: one LANE per tile walks the path (the type and
+// the length of the run that would start at any pixel were written by the first pass: one 2-byte load per step),
+// ~110 steps on average, and writes the tile's run records in order.  The tiles of a frame are independent once their entry
+// points are known, and a frame has 2000 of them: the walk needs no pointer doubling (the second k_tiles pass it replaces
+// re-classified every pixel and squared the successor function nine times to mark the same path).
+// tilecnt: {runs, literal runs} per tile.   runrec: rel_start | type<<10 | n<<16
+__global__ __launch_bounds__(256) void k_runs(Geom g, const int* __restrict__ slots, const u8* __restrict__ entry, const u16* __restrict__ tnmap,
+                                              u32* __restrict__ runrec, u32* __restrict__ tilecnt) {
+  const int slot = slots[blockIdx.y], tile = blockIdx.x * 256 + threadIdx.x;
+  if (tile >= g.ntiles) return;
+  const size_t ti = (size_t)slot * g.ntiles + tile;
+  const u16* tn = tnmap + ti * TILE;
+  u32* rec = runrec + ti * TILE;
+  const int tstart = g.p0 + tile * TILE;
+  int r = entry[ti * 2], cnt = 0, lit = 0;  // 255: a run from an earlier tile already reached the frame end
+  if (r < HALO) {
+    while (r < TILE && tstart + r < g.NP) {
+      const u32 v = tn[r];
+      const int t = (int)(v & 7u);
+      int j = r + 1 + (int)(v >> 8);
+      int len = j - r;
+      if (tstart + j >= g.NP) {  // the run reaches the end of the frame
+        len = g.NP - (tstart + r);
+        j = TILE;
+      }
+      rec[cnt++] = (u32)r | ((u32)t << 10) | ((u32)len << 16);
+      lit += t == 0;
+      r = j;
+    }
+  }
+  tilecnt[ti * 2] = (u32)cnt;
+  tilecnt[ti * 2 + 1] = (u32)lit;
 }
 
 // runs of identical pixels over raster pixels 0..W (first row and pixel (0,1)):
