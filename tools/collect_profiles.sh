@@ -1,25 +1,28 @@
 #!/bin/bash
-# Runs ON THE GPU BOX (through gpurun): the profiles behind DESIGN.md §6 / bench.py's roofline block.
-#   1. rocprofv3 --kernel-trace --stats over the default bench command
-#   2. HBM traffic: --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (MI355X_MICROARCH.md, HBM section)
-#   3. instruction mix of the decoder: SQ_INSTS_* / SQ_WAVE_CYCLES over tools/decode_only.py
+# Runs ON THE GPU BOX (through gpurun): the profiles behind DESIGN.md / bench.py's roofline block.
+#   1. rocprofv3 --kernel-trace --stats over the headline bench command (configs[1]) and over the I+P (configs[2]) and
+#      4K (configs[3] share) workloads
+#   2. HBM traffic of the headline: --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (MI355X_MICROARCH.md, HBM section)
+#   3. the decoder's instruction mix and wait counters: tools/decoder_pmc2.sh
 # Output: gpurun_out/prof/<tag>/...; tools/summarize_profiles.py turns it into profiles/<tag>_*.
 set -e
-TAG=${1:-r1e}
+TAG=${1:-r2a}
 R=$PWD
 OUT=$R/gpurun_out/prof/$TAG
-mkdir -p $OUT
+rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/stats -o run --output-format csv -- python3 $R/bench.py --frames 300 --steps 3 --warmup 1 --cpu-frames 24 > $OUT/bench_stats.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/stats -o run --output-format csv -- python3 $R/bench.py --no-others --steps 3 --warmup 1 --cpu-frames 24 > $OUT/bench_stats.log 2>&1
 echo stats done
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/stats_ip -o run --output-format csv -- python3 $R/bench.py --workload ip --gop 50 --no-cpu --steps 2 --warmup 1 > $OUT/bench_stats_ip.log 2>&1
+echo ip stats done
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/stats_4k -o run --output-format csv -- python3 $R/bench.py --width 3840 --height 2160 --frames 150 --no-cpu --steps 2 --warmup 1 > $OUT/bench_stats_4k.log 2>&1
+echo 4k stats done
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c -d $OUT/pmc_$c -o run --output-format csv -- python3 $R/bench.py --frames 300 --steps 1 --warmup 0 --no-cpu > $OUT/bench_$c.log 2>&1
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c -d $OUT/pmc_$c -o run --output-format csv -- python3 $R/bench.py --no-others --steps 1 --warmup 0 --no-cpu > $OUT/bench_$c.log 2>&1
   echo $c done
 done
-for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH SQ_INSTS" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY"; do
-  n=$(echo $set | cut -d" " -f1)
-  timeout -k 10 200 rocprofv3 --kernel-trace --pmc $set -d $OUT/dec_$n -o run --output-format csv -- python3 $R/tools/decode_only.py 16 > $OUT/dec_$n.log 2>&1
-  echo $n done
-done
-tail -1 $OUT/bench_stats.log | head -c 600
+cd $R
+tools/decoder_pmc2.sh 16 prof/$TAG/dec > $OUT/decoder_pmc.log 2>&1
+echo decoder pmc done
+tail -1 $OUT/bench_stats.log | head -c 400

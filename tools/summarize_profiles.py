@@ -20,6 +20,19 @@ if st:
 line = [l for l in open(os.path.join(src, "bench_stats.log")).read().splitlines() if l.startswith("{")]
 if line:
     open(os.path.join(dst, f"{tag}_bench_line.json"), "w").write(line[-1] + "\n")
+for sub in ("ip", "4k"):  # the I+P (configs[2]) and 4K (configs[3] share) runs
+    st2 = find("stats_" + sub, "*kernel_stats.csv")
+    if st2:
+        rows = list(csv.DictReader(open(st2)))
+        with open(os.path.join(dst, f"{tag}_{sub}_kernel_stats.csv"), "w", newline="") as f:
+            w = csv.DictWriter(f, fieldnames=rows[0].keys(), quoting=csv.QUOTE_NONNUMERIC)
+            w.writeheader()
+            w.writerows(rows)
+    lg = os.path.join(src, f"bench_stats_{sub}.log")
+    if os.path.exists(lg):
+        line = [l for l in open(lg).read().splitlines() if l.startswith("{")]
+        if line:
+            open(os.path.join(dst, f"{tag}_{sub}_bench_line.json"), "w").write(line[-1] + "\n")
 
 # 2. HBM traffic per kernel launch
 def pmc(d):
@@ -40,21 +53,16 @@ for k in fa:
     n = max(len(fc[k]), 1)
     fkb, wkb = fa[k] / n, wa.get(k, 0.0) / max(len(wc.get(k, [1])), 1)
     ker.append({"kernel": k, "launches": n, "FETCH_SIZE_KB_per_launch": fkb, "WRITE_SIZE_KB_per_launch": wkb, "hbm_bytes_per_launch": (2 * fkb + wkb) * 1024})
-json.dump({"command": "bench.py --frames 300 --steps 1 --warmup 0 --no-cpu (1920x1080 key frames)",
+json.dump({"command": "bench.py --no-others --steps 1 --warmup 0 --no-cpu (configs[1]: 300 x 1920x1080 key frames)",
            "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and, in a separate run, --pmc WRITE_SIZE; counters are KB; FETCH_SIZE doubled (gfx950 reports half of a wide coalesced read, MI355X_MICROARCH.md HBM section); WRITE_SIZE taken as is",
            "kernels": ker}, open(os.path.join(dst, f"{tag}_pmc_hbm_traffic.json"), "w"), indent=1)
 
-# 3. decoder instruction mix
-tot = collections.defaultdict(float)
-for d in glob.glob(os.path.join(src, "dec_*")):
-    if os.path.isdir(d):
-        f = find(os.path.basename(d), "*counter_collection.csv")
-        if f:
-            for r in csv.DictReader(open(f)):
-                if "decode_gop" in r["Kernel_Name"]:
-                    tot[r["Counter_Name"]] += float(r["Counter_Value"])
-nsym = 16 * 700818  # tools/decode_only.py 16: coder entries of the 16 synthetic key frames (oracle tap)
-json.dump({"command": "tools/decode_only.py 16 (16 x 1080p key frames), kernel k_decode_gop_w<false>", "symbols": nsym,
-           "note": "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* count in units of 4 cycles",
-           "per_symbol": {k: v / nsym for k, v in sorted(tot.items())}}, open(os.path.join(dst, f"{tag}_pmc_decoder.json"), "w"), indent=1)
-print("written", sorted(os.listdir(dst))[-6:])
+# 3. decoder instruction mix and waits (tools/decoder_pmc2.sh)
+summ = os.path.join(src, "dec", "summary.json")
+if os.path.exists(summ):
+    d = json.load(open(summ))
+    d["note"] = ("SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* count in units of 4 cycles; ACTIVE_INST_ANY == INSTS: every instruction is 'active' for one unit, "
+                 "WAIT_ANY is everything else of the wave's life - for this lone wave mostly the second half of the ~8-cycle issue-to-issue time of DEPENDENT instructions "
+                 "(tools/lonewave_bench.hip), not memory: see DESIGN.md")
+    json.dump(d, open(os.path.join(dst, f"{tag}_pmc_decoder.json"), "w"), indent=1)
+print("written", sorted(f for f in os.listdir(dst) if f.startswith(tag)))
