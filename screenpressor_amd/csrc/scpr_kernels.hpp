@@ -415,6 +415,7 @@ __global__ __launch_bounds__(256) void k_runs(Geom g, const int* __restrict__ sl
   u32* rec = runrec + ti * TILE;
   const int tstart = g.p0 + tile * TILE;
   int r = entry[ti * 2], cnt = 0, lit = 0;  // 255: a run from an earlier tile already reached the frame end
+  u32 q0 = 0, q1 = 0, q2 = 0;  // records leave four at a time (16-byte stores: a quarter of the partial-line writes)
   if (r < HALO) {
     while (r < TILE && tstart + r < g.NP) {
       const u32 v = tn[r];
@@ -425,10 +426,22 @@ __global__ __launch_bounds__(256) void k_runs(Geom g, const int* __restrict__ sl
         len = g.NP - (tstart + r);
         j = TILE;
       }
-      rec[cnt++] = (u32)r | ((u32)t << 10) | ((u32)len << 16);
+      const u32 rv = (u32)r | ((u32)t << 10) | ((u32)len << 16);
+      const int k = cnt & 3;
+      if (k == 3) ((uint4*)rec)[cnt >> 2] = make_uint4(q0, q1, q2, rv);
+      q0 = k == 0 ? rv : q0;
+      q1 = k == 1 ? rv : q1;
+      q2 = k == 2 ? rv : q2;
+      cnt++;
       lit += t == 0;
       r = j;
     }
+  }
+  {  // the last, partial group of records
+    const int k = cnt & 3, base = cnt & ~3;
+    if (k > 0) rec[base] = q0;
+    if (k > 1) rec[base + 1] = q1;
+    if (k > 2) rec[base + 2] = q2;
   }
   tilecnt[ti * 2] = (u32)cnt;
   tilecnt[ti * 2 + 1] = (u32)lit;
