@@ -338,7 +338,12 @@ static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int n
     HIPCHK(c->mvpre.reserve(pb * 4));
     hipLaunchKernelGGL(k_mvdict, dim3(np), dim3(256), 0, st, g, c->binfo.as<u32>(), c->smv.as<u32>(), c->mvdict.as<u32>());
     hipLaunchKernelGGL(k_mvpretest, dim3((nblocks + 3) / 4, np), dim3(64), 0, st, planes, g, c->pframes.as<PFrame>(), c->binfo.as<u32>(), mp, c->mvdict.as<u32>(), c->mvpre.as<u32>());
-    {
+    if ((size_t)nblocks * 4 <= 150 * 1024 && nblocks + nbx < 0xFFFF) {  // frames pipelined over sixteen waves, the vector memory in LDS
+      const size_t lds = (size_t)nblocks * 4;
+      HIPCHK(hipFuncSetAttribute((const void*)k_mvresolve_pipe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(k_mvresolve_pipe, dim3(1), dim3(64 * MVP_WAVES), lds, st, planes, g, c->pframes.as<PFrame>(), np, c->binfo.as<u32>(), c->smv.as<u32>(), c->mvdict.as<u32>(),
+                         c->mvpre.as<u32>(), mp, c->mvs.as<u32>(), c->btype.as<u8>(), c->bmv.as<u32>(), c->pinfo.as<int>(), c->gmask.as<unsigned long long>(), c->err.as<u32>());
+    } else {
       const size_t lds = (size_t)nblocks * 16;  // the frame's block arrays + the vector memory in LDS when they fit
       const int use_lds = lds <= 150 * 1024 ? 1 : 0;
       if (use_lds) HIPCHK(hipFuncSetAttribute((const void*)k_mvresolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -737,6 +742,10 @@ int64_t scpr_compress_batch(scpr_codec* c, const void* d_frames, int nframes, in
     if (err & 2) return SCPR_E_CAPACITY;
     if (err & 1) {
       fprintf(stderr, "[scpr] dense-table arena overflow\n");
+      return SCPR_E_DEVICE;
+    }
+    if (err & 8) {
+      fprintf(stderr, "[scpr] motion-vector pipeline stalled\n");
       return SCPR_E_DEVICE;
     }
     written += (int64_t)chunk_total;

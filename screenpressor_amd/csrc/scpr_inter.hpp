@@ -476,6 +476,158 @@ __global__ __launch_bounds__(256) void k_mvresolve(const u8* __restrict__ planes
     for (int i = threadIdx.x; i < nblocks; i += 256) mvs[i] = l_mv[i];
 }
 
+// The same resolution as a PIPELINE OF WAVES.  The only thing one frame hands to the next is the vector memory mvs[] (the
+// vector of the block above, :726-735); a frame reads mvs[b - nbx] when it is at block b and writes mvs[b] there, so frame
+// i + 1 may work on a group of blocks as soon as frame i is one block row past it (then frame i has read what frame i + 1 is about
+// to overwrite, and has written what frame i + 1 is about to read).  One workgroup of sixteen waves: wave w takes frames w,
+// w + 16, ... in order; the vector memory lives in LDS for the whole launch; every wave publishes (frame << 16 | blocks done) in
+// an LDS word after each group, and waits on the word of the wave that has the frame before its own.  A chunk of 300 P-frames
+// was 65 ms of one wave; with the frames a block row apart up to ~40 of them are in flight, sixteen here.
+constexpr int MVP_WAVES = 16;
+__global__ __launch_bounds__(64 * MVP_WAVES) void k_mvresolve_pipe(const u8* __restrict__ planes, Geom g, const PFrame* __restrict__ pf, int npf, const u32* __restrict__ binfo,
+                                                                   const u32* __restrict__ smv, const u32* __restrict__ dict, const u32* __restrict__ pre, MvParams mp, u32* mvs,
+                                                                   u8* __restrict__ btype, u32* __restrict__ bmv, int* __restrict__ pinfo,
+                                                                   const unsigned long long* __restrict__ gmask, u32* __restrict__ err) {
+  extern __shared__ __align__(16) u32 stage[];  // the vector memory: nblocks words
+  __shared__ u32 prog[MVP_WAVES];               // per wave: frame << 16 | blocks of it that are done (0xFFFF: all)
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int nbx = (g.W + 15) >> 4, nby = (g.H + 15) >> 4, nblocks = nbx * nby;
+  const int G = min(64, nbx), NG = (nblocks + G - 1) / G;
+  u32* const l_mv = stage;
+  for (int i = threadIdx.x; i < nblocks; i += 64 * MVP_WAVES) l_mv[i] = mvs[i];
+  if (threadIdx.x < MVP_WAVES) prog[threadIdx.x] = 0;
+  __syncthreads();
+  const int prev_w = (wv + MVP_WAVES - 1) % MVP_WAVES;
+  u32 seen = 0;  // the last value read from the previous frame's wave
+  for (int pi = wv; pi < npf; pi += MVP_WAVES) {
+    const u8* cur = planes + (size_t)pf[pi].slot * g.plane_stride;
+    const u8* prv = planes + (size_t)pf[pi].prev_slot * g.plane_stride;
+    u32 dk[MVDICT];
+#pragma unroll
+    for (int k = 0; k < MVDICT; k++) dk[k] = dict[pi * MVDICT + k];
+    auto dict_index = [&](u32 mv) __attribute__((always_inline)) {
+      int idx = -1;
+#pragma unroll
+      for (int k = 0; k < MVDICT; k++)
+        if (dk[k] == mv && idx < 0) idx = k;
+      return idx;
+    };
+    // frame pi may touch blocks below `upto` once frame pi - 1 has finished every block below upto + nbx
+    auto wait_for = [&](int upto) __attribute__((always_inline)) {
+      if (pi == 0) return;
+      const u32 need = ((u32)(pi - 1) << 16) | (u32)min(upto + nbx, 0xFFFF);
+      int spins = 0;
+      while (seen < need) {
+        seen = __hip_atomic_load(&prog[prev_w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (seen < need) {
+          __builtin_amdgcn_s_sleep(2);
+          if (++spins > (1 << 22)) {  // (cannot happen: the frame before is always ahead; never spin for ever on a GPU)
+            if (lane == 0) atomicOr(err, 8u);
+            break;
+          }
+        }
+      }
+      asm volatile("" ::: "memory");  // (LDS operations of a wave execute in order: what follows reads after the word above)
+    };
+    auto publish = [&](int done) __attribute__((always_inline)) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the vectors stored above are in LDS before the word that says so (global stores are not waited for)
+      if (lane == 0) __hip_atomic_store(&prog[wv], ((u32)pi << 16) | (u32)min(done, 0xFFFF), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    u32 last = 0;  // last vector found by search (0,0), wave-uniform
+    int bx1 = nbx, bx2 = -1, by1 = nby, by2 = -1;
+    for (int g0 = 0; g0 < NG; g0 += 64) {
+      u64 active = __ballot(g0 + lane < NG && gmask[(size_t)pi * NG + g0 + lane] != 0ull);
+      while (active) {
+        const int gi = g0 + __builtin_ctzll(active);
+        const int base = gi * G;
+        active &= active - 1;
+        wait_for(base + G);
+        const int b = base + lane;
+        const bool vb = lane < G && b < nblocks;
+        const u32 info = vb ? binfo[(size_t)pi * nblocks + b] : 0;
+        const bool changed = info & 1u;
+        const int by = vb ? b / nbx : 0, bx = vb ? b - by * nbx : 0;
+        int type = changed ? (int)((info >> 20) & 7) : 0;
+        u32 my_mv = 0;
+        bool has_mv = false;
+        if (changed) {
+          bx1 = min(bx1, bx);
+          bx2 = max(bx2, bx);
+          by1 = min(by1, by);
+          by2 = max(by2, by);
+        }
+        u64 unresolved = __ballot(changed);
+        if (unresolved) {
+          const Rect r = binfo_rect(info, bx, by);
+          const Windows w = mv_windows(r, g, mp.far_x, mp.far_y, mp.near_x, mp.near_y);
+          const u32 s = changed ? smv[(size_t)pi * nblocks + b] : 0;
+          const u32 pbits = changed ? pre[(size_t)pi * nblocks + b] : 0;
+          const u32 umv = (changed && by > 0) ? __hip_atomic_load(&l_mv[b - nbx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0;
+          const int ui = dict_index(umv);
+          auto exact = [&](u32 mv) __attribute__((always_inline)) {  // window test + SameBlocks for a vector outside the dictionary
+            const int x = r.x1 + mv_x(mv), y = r.y1 + mv_y(mv);
+            return x >= w.fx1 && x < w.fx2 && y >= w.fy1 && y < w.fy2 && same_rect(cur, prv, g.S, r, x, y);
+          };
+          while (unresolved) {
+            const bool mine = changed && ((unresolved >> lane) & 1ull);
+            const int li = dict_index(last);
+            bool ta = false, tb = false;
+            if (mine) {
+              ta = li >= 0 ? ((pbits >> li) & 1u) : exact(last);
+              if (!ta && by > 0 && umv != last) tb = ui >= 0 ? ((pbits >> ui) & 1u) : exact(umv);
+            }
+            const u64 Sm = __ballot(mine && !ta && !tb && (s >> 31));
+            const int f = Sm ? __builtin_ctzll(Sm) : 64;
+            const u64 upto = f >= 63 ? ~0ull : ((2ull << f) - 1ull);
+            if (mine && ((upto >> lane) & 1ull)) {
+              if (ta) {
+                my_mv = last;
+                has_mv = true;
+              } else if (tb) {
+                my_mv = umv;
+                has_mv = true;
+              } else if (lane == f) {
+                my_mv = smv_to_mv(s);
+                has_mv = true;
+              }
+            }
+            if (f < 64) last = __shfl(my_mv, f);
+            unresolved &= ~upto;
+          }
+        }
+        if (vb) {
+          if (has_mv) {
+            type += 2;
+            __hip_atomic_store(&l_mv[b], my_mv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+          btype[(size_t)pi * nblocks + b] = (u8)type;
+          bmv[(size_t)pi * nblocks + b] = my_mv;
+        }
+        publish(base + G);
+      }
+      // the groups skipped in this stretch count as done - but a frame never claims more than the frame before it allows (the
+      // frame after reads through this claim what ALL earlier frames have written)
+      wait_for(min((g0 + 64) * G, nblocks));
+      publish(min((g0 + 64) * G, nblocks));
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      bx1 = min(bx1, __shfl_xor(bx1, d));
+      by1 = min(by1, __shfl_xor(by1, d));
+      bx2 = max(bx2, __shfl_xor(bx2, d));
+      by2 = max(by2, __shfl_xor(by2, d));
+    }
+    if (lane == 0) {
+      pinfo[pi * 2] = bx2 < 0 ? 0 : by1 * nbx + bx1;
+      pinfo[pi * 2 + 1] = bx2 < 0 ? -1 : by2 * nbx + bx2;
+    }
+    wait_for(nblocks);
+    publish(0xFFFF);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nblocks; i += 64 * MVP_WAVES) mvs[i] = l_mv[i];
+}
+
 // ---- inter predictors (GetPixelTypeP / PixelTypeFitsP and the edge forms, :525-604) ----
 __device__ __forceinline__ bool eq3p(const u8* a, const u8* b) { return a[0] == b[0] && a[1] == b[1] && a[2] == b[2]; }
 __device__ __forceinline__ bool grad3p(const u8* p, int off) {
