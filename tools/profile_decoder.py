@@ -57,5 +57,4 @@ for nm, x in zip(names, v):
 for nm, x in zip(["colour symbols", "record cache misses", "dense-table symbols", "raw symbols", "small-table slow path", "runs", "literal runs", "dense-table cache misses"], ev):
     print("%-50s %.0f per frame" % (nm, x / n))
 print("dense fast-path hits per frame: %.0f; small-table hits on the top entry: %.0f, in one-symbol tables: %.0f" % (ex[0] / n, ex[1] / n, ex[2] / n))
-for nm, tt, cc in (("small-table", ex[1], ex[5] - 0), ("dense", ex[2], ex[6]), ("raw", ex[3], 0), ("record-miss", ex[4], ex[7])):
-    print("colour() ticks in %-12s symbols: %.0f per frame  (count %.0f)" % (nm, tt / n, cc / n))
+print("P-frame runs by pixel type 1..5 per frame:", [round(x / n) for x in ex[3:8]])
