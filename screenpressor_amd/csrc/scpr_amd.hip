@@ -184,10 +184,10 @@ static int ensure_codec(scpr_codec* c, int version) {  // CreateCodec + CScreenC
   if (g.ntiles < 1) g.ntiles = 1;
   g.workers = (int)p.workers;
   g.plane_stride = (u32)(((size_t)g.H * g.S + 16 + 255) & ~(size_t)255);
-  // chunk size: keep the per-slot worst-case buffers within ~6 GiB
+  // chunk size: keep the per-slot worst-case buffers within ~24 GiB
   size_t per_slot = (size_t)g.plane_stride + (size_t)g.ntiles * (512 + 2 + TILE * 6 + 16) + (size_t)(g.W + 2) * 4;
-  size_t s = (12ull << 30) / per_slot;
-  c->slots = (int)std::min<size_t>(std::max<size_t>(s, 1), 512);
+  size_t s = (24ull << 30) / per_slot;
+  c->slots = (int)std::min<size_t>(std::max<size_t>(s, 1), 768);  // 768 = three decoder workgroups on each of the 256 CUs
   const size_t ns = (size_t)c->slots + 1;  // +1: slot `slots` holds the previous frame of the stream
   HIPCHK(c->planes.reserve(ns * g.plane_stride));
   HIPCHK(hipMemsetAsync(c->planes.p, 0, ns * g.plane_stride, c->stream));
@@ -870,8 +870,9 @@ int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* 
       int ndc = 0;
       const int dcache_off = dyn;
       if (!v2) {
-        const size_t lds_budget = (ng <= 256 ? 160 * 1024 : 80 * 1024) - sizeof(WaveLds) - 1024;
-        while (ndc < 32 && (size_t)dyn + (size_t)(ndc ? 2 * ndc : 1) * sizeof(DenseTab) <= lds_budget) ndc = ndc ? 2 * ndc : 1;
+        const size_t lds_static = has_p ? sizeof(WaveLds) : offsetof(WaveLds, fp);  // (a batch of key frames: without the P-frame tables)
+        const size_t lds_budget = (ng <= 256 ? 160 * 1024 : (has_p || ng <= 512) ? 80 * 1024 : 53 * 1024) - lds_static - 1024;  // one, two or three workgroups per CU
+        while (ndc < 32 && lds_budget > (size_t)dyn && (size_t)dyn + (size_t)(ndc ? 2 * ndc : 1) * sizeof(DenseTab) <= lds_budget) ndc = ndc ? 2 * ndc : 1;
         if (ndc < 16) ndc = 0;  // a handful of slots would only be evicted all the time (a miss moves two tables, an uncached symbol 32 bytes per lane)
         dyn += ndc * (int)sizeof(DenseTab);
       }

@@ -92,8 +92,11 @@ constexpr int DECREC_WORDS = 20;
 // words per run-length table: 256 entries (freq | cum << 16), the running total at 256, padding, and the 256 counts from
 // NTAB_CNT on (the lane that holds an entry reaches its count and lane 0 the total with a constant offset from one address)
 constexpr int NTAB_STRIDE = 640, NTAB_CNT = 320;
-struct FixedLds {
+struct FixedLds {       // what a key frame needs
   u32 ntab[6][NTAB_STRIDE];
+  int ftot[24];        // same numbering as FixedBlob::ftot; 0-11 are unused here
+};
+struct FixedLdsP {      // the tables only P-frames use
   u32 mfc[2][512];
   u32 mcnt[2][512];
   u32 xfc[2][256];
@@ -102,15 +105,17 @@ struct FixedLds {
   u32 scnt[4][16];
   u32 bfc[8];
   u32 bcnt[8];
-  int ftot[24];        // same numbering as FixedBlob::ftot; 0-11 are unused here
 };
+// (Everything from `fp` on is for P-frames: a batch of key frames - k_decode_gop_w<false> - allocates the struct up to there,
+// which lets three of its workgroups share a CU at 1080p: 768 key frames per round instead of 512.)
 struct __attribute__((aligned(16))) WaveLds {
   FixedLds fx;
   u32 crec[CACHE_N][DECREC_WORDS];
   u16 tmp[256];
+  u32 dtag[64];        // tags of the dense-table cache (WaveModel::tab_of)
+  FixedLdsP fp;
   u32 tile[17 * 17];   // P-frame block under reconstruction, with one row above and one column to the left
   uint2 jobs[256];     // deferred motion-block copies of the current P-frame
-  u32 dtag[64];        // tags of the dense-table cache (WaveModel::tab_of)
   // Helper waves (P-frame GOPs: the workgroup is the chain's wave + helpers, see helper_loop): commands go out by bumping
   // `seq` after the arguments are in place, every helper adds 1 to `done` when it has finished the command it saw.
   struct {
@@ -689,6 +694,7 @@ struct WaveDec : WaveModel {
   // models
   DecRec* gstates;
   bool bad = false;
+  bool has_p = true;  // false: the workgroup's LDS ends before the P-frame tables (WaveLds::fp on)
 
   __device__ __forceinline__ WaveDec(WaveLds& l, const u8* s, const u8* e, DecRec* gs, Arena a, int f0_) : WaveModel(l.tmp, a, f0_), L(l), src(s), src_end(e), gstates(gs) {}
 
@@ -788,6 +794,7 @@ struct WaveDec : WaveModel {
   // renew() of every table (RenewI, screencap.cpp:178-198)
   __device__ __forceinline__ void fixed_init() {
     FixedLds& F = L.fx;
+    FixedLdsP& FP = L.fp;
     auto fill = [&](u32* fc, u32* cnt, int nsym, int cap, int ti) __attribute__((always_inline)) {
       const int fr = kProbScale / nsym, c0 = fr - (fr >> 1);
       for (int j = lane; j < cap; j += 64) {
@@ -806,17 +813,38 @@ struct WaveDec : WaveModel {
       pfc = (lane < 48 && j < 6) ? ((u32)fr | ((u32)(fr * j) << 16)) : 0xFFFFFFFFu;
       pcnt = lane < 48 ? (j < 6 ? (u32)c0 : j == 7 ? (u32)(c0 * 6) : 0u) : 0u;
     }
-    for (int t = 0; t < 2; t++) {
-      fill(F.mfc[t], F.mcnt[t], 512, 512, 12 + t);
-      fill(F.xfc[t], F.xcnt[t], 256, 256, 14 + t);
+    if (has_p) {
+      for (int t = 0; t < 2; t++) {
+        fill(FP.mfc[t], FP.mcnt[t], 512, 512, 12 + t);
+        fill(FP.xfc[t], FP.xcnt[t], 256, 256, 14 + t);
+      }
+      for (int t = 0; t < 4; t++) fill(FP.sfc[t], FP.scnt[t], 16, 16, 16 + t);
+      fill(FP.bfc, FP.bcnt, 5, 8, 20);
     }
-    for (int t = 0; t < 4; t++) fill(F.sfc[t], F.scnt[t], 16, 16, 16 + t);
-    fill(F.bfc, F.bcnt, 5, 8, 20);
     wave_fence();
+  }
+  // the renewed P-frame tables written straight into a models' image in HBM: a batch of key frames has no room for them in
+  // LDS (WaveLds), but the P-frames of a later call continue from this image
+  __device__ __forceinline__ void fixed_store_renewed_p(FixedBlob* __restrict__ B) {
+    auto fill = [&](u32* fc, u32* cnt, int nsym, int cap, int ti) __attribute__((always_inline)) {
+      const int fr = kProbScale / nsym, c0 = fr - (fr >> 1);
+      for (int j = lane; j < cap; j += 64) {
+        fc[j] = j < nsym ? ((u32)fr | ((u32)(fr * j) << 16)) : 0xFFFFFFFFu;
+        cnt[j] = j < nsym ? (u32)c0 : 0u;
+      }
+      if (lane == 0) B->ftot[ti] = c0 * nsym;
+    };
+    for (int t = 0; t < 2; t++) {
+      fill(B->mfc[t], B->mcnt[t], 512, 512, 12 + t);
+      fill(B->xfc[t], B->xcnt[t], 256, 256, 14 + t);
+    }
+    for (int t = 0; t < 4; t++) fill(B->sfc[t], B->scnt[t], 16, 16, 16 + t);
+    fill(B->bfc, B->bcnt, 5, 8, 20);
   }
   // the models of an earlier call, from their image in HBM
   __device__ __forceinline__ void fixed_load(const FixedBlob* __restrict__ B) {
     FixedLds& F = L.fx;
+    FixedLdsP& FP = L.fp;
     wave_fence();
     for (int t = 0; t < 6; t++) {
       for (int j = lane; j < NTAB_CNT; j += 64) F.ntab[t][j] = j < 256 ? B->nfc[t][j] : j == 256 ? (u32)B->ftot[t] : 0u;
@@ -827,25 +855,28 @@ struct WaveDec : WaveModel {
       pfc = lane < 48 ? B->pfc[t][j] : 0xFFFFFFFFu;
       pcnt = lane < 48 ? (j == 7 ? (u32)B->ftot[6 + t] : B->pcnt[t][j]) : 0u;
     }
-    for (int i = lane; i < 1024; i += 64) {
-      (&F.mfc[0][0])[i] = (&B->mfc[0][0])[i];
-      (&F.mcnt[0][0])[i] = (&B->mcnt[0][0])[i];
-    }
-    for (int i = lane; i < 512; i += 64) {
-      (&F.xfc[0][0])[i] = (&B->xfc[0][0])[i];
-      (&F.xcnt[0][0])[i] = (&B->xcnt[0][0])[i];
-    }
-    (&F.sfc[0][0])[lane] = (&B->sfc[0][0])[lane];
-    (&F.scnt[0][0])[lane] = (&B->scnt[0][0])[lane];
-    if (lane < 8) {
-      F.bfc[lane] = B->bfc[lane];
-      F.bcnt[lane] = B->bcnt[lane];
+    if (has_p) {
+      for (int i = lane; i < 1024; i += 64) {
+        (&FP.mfc[0][0])[i] = (&B->mfc[0][0])[i];
+        (&FP.mcnt[0][0])[i] = (&B->mcnt[0][0])[i];
+      }
+      for (int i = lane; i < 512; i += 64) {
+        (&FP.xfc[0][0])[i] = (&B->xfc[0][0])[i];
+        (&FP.xcnt[0][0])[i] = (&B->xcnt[0][0])[i];
+      }
+      (&FP.sfc[0][0])[lane] = (&B->sfc[0][0])[lane];
+      (&FP.scnt[0][0])[lane] = (&B->scnt[0][0])[lane];
+      if (lane < 8) {
+        FP.bfc[lane] = B->bfc[lane];
+        FP.bcnt[lane] = B->bcnt[lane];
+      }
     }
     if (lane < 24) F.ftot[lane] = B->ftot[lane];
     wave_fence();
   }
   __device__ __forceinline__ void fixed_store(FixedBlob* __restrict__ B) {
     FixedLds& F = L.fx;
+    FixedLdsP& FP = L.fp;
     wave_fence();
     for (int t = 0; t < 6; t++) {
       for (int j = lane; j < 256; j += 64) {
@@ -854,19 +885,21 @@ struct WaveDec : WaveModel {
       }
       if (lane == 0) B->ftot[t] = (int)F.ntab[t][256];
     }
-    for (int i = lane; i < 1024; i += 64) {
-      (&B->mfc[0][0])[i] = (&F.mfc[0][0])[i];
-      (&B->mcnt[0][0])[i] = (&F.mcnt[0][0])[i];
-    }
-    for (int i = lane; i < 512; i += 64) {
-      (&B->xfc[0][0])[i] = (&F.xfc[0][0])[i];
-      (&B->xcnt[0][0])[i] = (&F.xcnt[0][0])[i];
-    }
-    (&B->sfc[0][0])[lane] = (&F.sfc[0][0])[lane];
-    (&B->scnt[0][0])[lane] = (&F.scnt[0][0])[lane];
-    if (lane < 8) {
-      B->bfc[lane] = F.bfc[lane];
-      B->bcnt[lane] = F.bcnt[lane];
+    if (has_p) {
+      for (int i = lane; i < 1024; i += 64) {
+        (&B->mfc[0][0])[i] = (&FP.mfc[0][0])[i];
+        (&B->mcnt[0][0])[i] = (&FP.mcnt[0][0])[i];
+      }
+      for (int i = lane; i < 512; i += 64) {
+        (&B->xfc[0][0])[i] = (&FP.xfc[0][0])[i];
+        (&B->xcnt[0][0])[i] = (&FP.xcnt[0][0])[i];
+      }
+      (&B->sfc[0][0])[lane] = (&FP.sfc[0][0])[lane];
+      (&B->scnt[0][0])[lane] = (&FP.scnt[0][0])[lane];
+      if (lane < 8) {
+        B->bfc[lane] = FP.bfc[lane];
+        B->bcnt[lane] = FP.bcnt[lane];
+      }
     }
     if (lane < 48) {
       const int t = lane >> 3, j = lane & 7;
@@ -874,7 +907,11 @@ struct WaveDec : WaveModel {
       B->pcnt[t][j] = j == 7 ? 0u : pcnt;
       if (j == 7) B->ftot[6 + t] = (int)pcnt;
     }
-    if (lane >= 12 && lane < 24) B->ftot[lane] = F.ftot[lane];
+    if (has_p) {
+      if (lane >= 12 && lane < 24) B->ftot[lane] = F.ftot[lane];
+    } else {
+      fixed_store_renewed_p(B);  // (a key frame renews them, screencap.cpp:178-198, and a batch of key frames never uses them)
+    }
   }
 
   // Run length after a pixel of type t (decode + incrCnt, ans_contexts.h:1093-1112, :1070-1091).
@@ -1019,10 +1056,10 @@ struct WaveDec : WaveModel {
     count();
     return sym;
   }
-  __device__ __forceinline__ int fixed_mv(int t) { return fixed_any<8>(L.fx.mfc[t], L.fx.mcnt[t], 512, 12 + t); }
-  __device__ __forceinline__ int fixed_x(int t) { return fixed_any<4>(L.fx.xfc[t], L.fx.xcnt[t], 256, 14 + t); }
-  __device__ __forceinline__ int fixed_sxy(int t) { return fixed_any<1>(L.fx.sfc[t], L.fx.scnt[t], 16, 16 + t); }
-  __device__ __forceinline__ int fixed_bt() { return fixed_any<1>(L.fx.bfc, L.fx.bcnt, 5, 20); }
+  __device__ __forceinline__ int fixed_mv(int t) { return fixed_any<8>(L.fp.mfc[t], L.fp.mcnt[t], 512, 12 + t); }
+  __device__ __forceinline__ int fixed_x(int t) { return fixed_any<4>(L.fp.xfc[t], L.fp.xcnt[t], 256, 14 + t); }
+  __device__ __forceinline__ int fixed_sxy(int t) { return fixed_any<1>(L.fp.sfc[t], L.fp.scnt[t], 16, 16 + t); }
+  __device__ __forceinline__ int fixed_bt() { return fixed_any<1>(L.fp.bfc, L.fp.bcnt, 5, 20); }
   __device__ __forceinline__ bool get_bool() {  // decodeBool, screencap.h:411-421
     const u32 v = x & (kProbScale - 1);
     const bool flag = v >= kProbScale / 2;
@@ -1812,7 +1849,8 @@ template <bool HAS_P>
 __global__ __launch_bounds__(HAS_P ? 512 : 64) void k_decode_gop_w(const u8* __restrict__ packets, const u8* packets_end, const DecFrame* __restrict__ frames, const DecGop* __restrict__ gops,
                                                      u8* __restrict__ planes, Geom g, DecRec* __restrict__ states, Arena arena, int f0, u32* __restrict__ status, int ring_bytes,
                                                      FixedBlob* __restrict__ fixedstore, int far_x, int far_y, int ndc, int dcache_off) {
-  __shared__ WaveLds L;
+  __shared__ __attribute__((aligned(16))) u8 Lraw[HAS_P ? sizeof(WaveLds) : offsetof(WaveLds, fp)];
+  WaveLds& L = *(WaveLds*)Lraw;
   // ring_bytes = 4 * (power of two >= W + 512) pixels, then (P-frames) one byte per 16x16 block, then (at dcache_off) ndc dense tables
   extern __shared__ __align__(16) u8 pix[];
   const DecGop gop = gops[blockIdx.x];
@@ -1828,6 +1866,7 @@ __global__ __launch_bounds__(HAS_P ? 512 : 64) void k_decode_gop_w(const u8* __r
     }
   }
   WaveDec D(L, packets, packets_end, states + (size_t)blockIdx.x * NCOLCTX, arena, f0);
+  D.has_p = HAS_P;
   if (ndc) {
     D.dcache = pix + dcache_off;
     D.dtag = L.dtag;
