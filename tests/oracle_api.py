@@ -76,12 +76,15 @@ class OracleCodec:
         self.nblocks = ((w + 15) // 16) * ((h + 15) // 16)
 
     def close(self):
-        if self.h_:
-            lib().spo_destroy(self.h_)
+        if self.h_ and _lib is not None:  # (at interpreter shutdown the module globals may be gone already)
+            _lib.spo_destroy(self.h_)
             self.h_ = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
 
     def compress(self, frame, key=False, loss=None):
         src = np.ascontiguousarray(frame, dtype=np.uint8).copy()  # the codec may write into src
