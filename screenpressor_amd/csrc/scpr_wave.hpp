@@ -691,6 +691,10 @@ struct WaveDec : WaveModel {
   int ndec = 0;
   // pixel-type tables (ptypetab) in registers: table t in lanes 8t..8t+5 (entries) and 8t+7 (the running total, in pcnt)
   u32 pfc = 0xFFFFFFFFu, pcnt = 0;
+  // the P-frame tables (fixed_any; lane = table - 12: motion x / y, block index bytes, block-type run lengths, rect x1 y1 x2 y2,
+  // block type): the widest symbol of each as start | (width - 1) << 12 and its number, and the table's running total.  Motion
+  // vectors repeat from block to block: the widest symbol takes almost every lookup, with one compare and nothing read.
+  u32 qtopA = 0, qtopB = 0, qtot = 0;
   // models
   DecRec* gstates;
   bool bad = false;
@@ -820,8 +824,32 @@ struct WaveDec : WaveModel {
       }
       for (int t = 0; t < 4; t++) fill(FP.sfc[t], FP.scnt[t], 16, 16, 16 + t);
       fill(FP.bfc, FP.bcnt, 5, 8, 20);
+      // every symbol of a renewed table is equally wide: its widest symbol is symbol 0
+      const int nsyms = lane < 2 ? 512 : lane < 4 ? 256 : lane < 8 ? 16 : 5, fr = kProbScale / nsyms;
+      qtopA = lane < 9 ? (u32)(fr - 1) << 12 : 0u;
+      qtopB = 0;
+      qtot = lane < 9 ? (u32)((fr - (fr >> 1)) * nsyms) : 0u;
     }
     wave_fence();
+  }
+  // qtopA / qtopB / qtot from the tables in LDS and their totals (after fixed_load)
+  __device__ __forceinline__ void fixed_tops(const int* ftot) {
+    FixedLdsP& FP = L.fp;
+    u32 a, b;
+    qtopA = qtopB = 0;
+    for (int t = 0; t < 2; t++) {
+      top_of_table<8>(FP.mfc[t], 512, a, b);
+      if (lane == t) qtopA = a, qtopB = b;
+      top_of_table<4>(FP.xfc[t], 256, a, b);
+      if (lane == 2 + t) qtopA = a, qtopB = b;
+    }
+    for (int t = 0; t < 4; t++) {
+      top_of_table<1>(FP.sfc[t], 16, a, b);
+      if (lane == 4 + t) qtopA = a, qtopB = b;
+    }
+    top_of_table<1>(FP.bfc, 5, a, b);
+    if (lane == 8) qtopA = a, qtopB = b;
+    qtot = lane < 9 ? (u32)ftot[12 + lane] : 0u;
   }
   // the renewed P-frame tables written straight into a models' image in HBM: a batch of key frames has no room for them in
   // LDS (WaveLds), but the P-frames of a later call continue from this image
@@ -873,6 +901,8 @@ struct WaveDec : WaveModel {
     }
     if (lane < 24) F.ftot[lane] = B->ftot[lane];
     wave_fence();
+    if (has_p) fixed_tops(B->ftot);
+    wave_fence();
   }
   __device__ __forceinline__ void fixed_store(FixedBlob* __restrict__ B) {
     FixedLds& F = L.fx;
@@ -908,7 +938,7 @@ struct WaveDec : WaveModel {
       if (j == 7) B->ftot[6 + t] = (int)pcnt;
     }
     if (has_p) {
-      if (lane >= 12 && lane < 24) B->ftot[lane] = F.ftot[lane];
+      if (lane < 9) B->ftot[12 + lane] = (int)qtot;
     } else {
       fixed_store_renewed_p(B);  // (a key frame renews them, screencap.cpp:178-198, and a batch of key frames never uses them)
     }
@@ -997,6 +1027,26 @@ struct WaveDec : WaveModel {
     return j;
   }
 
+  // the widest symbol of a table in LDS (PER entries per lane): { start | (width - 1) << 12, symbol }
+  template <int PER>
+  __device__ __forceinline__ void top_of_table(const u32* fc, int nsym, u32& ta, u32& tb) {
+    wave_fence();
+    u32 best = 0;  // width << 16 | 0xFFFF - symbol: the widest, the lowest of equals
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+      const int j = lane * PER + q;
+      const u32 e = j < nsym ? fc[j] : 0u;
+      const u32 key = j < nsym ? ((e & 0xFFFFu) << 16) | (0xFFFFu - (u32)j) : 0u;
+      best = max(best, key);
+    }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) best = max(best, (u32)__shfl_xor((int)best, d));
+    best = rfl(best);
+    const int sym = (int)(0xFFFFu - (best & 0xFFFFu));
+    const u32 e = rfl(fc[sym]);
+    ta = (e >> 16) | (((e & 0xFFFFu) - 1u) << 12);
+    tb = (u32)sym;
+  }
   template <int PER>
   __device__ __forceinline__ int fixed_rebuild(u32* fc, u32* cnt, int nsym) {  // incrCnt rebuild, ans_contexts.h:1075-1090
     wave_fence();
@@ -1024,35 +1074,51 @@ struct WaveDec : WaveModel {
     return wave_sum(ns);
   }
   // The P-frame tables (searched in LDS): symbol whose interval holds the coder value, then the
-  // table update.  PER entries per lane; entries past the alphabet hold ~0.
+  // table update.  PER entries per lane; entries past the alphabet hold ~0.  First the table's widest symbol (qtopA / qtopB).
   template <int PER>
   __device__ __forceinline__ int fixed_any(u32* fc, u32* cnt, int nsym, int ti) {
     wave_fence();
-    const u32 v = x & (kProbScale - 1), lim = (v + 1) << 16;
-    u32 e[PER];
+    const u32 v = x & (kProbScale - 1);
+    const int tl = ti - 12;
+    const u32 ta = rdl(qtopA, tl);
+    const int tot0 = (int)rdl(qtot, tl);
+    u32 cf = ta & 0xFFFu, fr = (ta >> 12) + 1u;
+    int sym = (int)rdl(qtopB, tl);
+    int miss = (v - cf) < fr ? 0 : -1;  // (unsigned: below the start wraps)
+    if (SCPR_UNLIKELY(miss < 0)) {
+      const u32 lim = (v + 1) << 16;
+      u32 e[PER];
 #pragma unroll
-    for (int q = 0; q < PER; q++) e[q] = (PER > 1 || lane < (nsym <= 8 ? 8 : 16)) ? fc[lane * PER + q] : 0xFFFFFFFFu;
-    const int tot0 = L.fx.ftot[ti];
-    const u64 m = __ballot(e[0] < lim);
-    const int own = 63 - __builtin_clzll(m);
-    int k = 0;
+      for (int q = 0; q < PER; q++) e[q] = (PER > 1 || lane < (nsym <= 8 ? 8 : 16)) ? fc[lane * PER + q] : 0xFFFFFFFFu;
+      const u64 m = __ballot(e[0] < lim);
+      const int own = 63 - __builtin_clzll(m);
+      int k = 0;
 #pragma unroll
-    for (int q = 1; q < PER; q++) k += e[q] < lim;
-    u32 sel = e[0];
+      for (int q = 1; q < PER; q++) k += e[q] < lim;
+      u32 sel = e[0];
 #pragma unroll
-    for (int q = 1; q < PER; q++) sel = (k == q) ? e[q] : sel;
-    const int kk = PER > 1 ? (int)rdl((u32)k, own) : 0;
-    const u32 s = rdl(sel, own);
-    const int sym = own * PER + kk;
-    if (lane == own) {
-      const u32 addr = (u32)(size_t)&cnt[sym];
-      asm volatile("ds_add_u32 %0, %1" ::"v"(addr), "v"((u32)kStepDense) : "memory");
+      for (int q = 1; q < PER; q++) sel = (k == q) ? e[q] : sel;
+      const int kk = PER > 1 ? (int)rdl((u32)k, own) : 0;
+      const u32 sv = rdl(sel, own);
+      sym = own * PER + kk;
+      cf = sv >> 16;
+      fr = sv & 0xFFFFu;
     }
-    wave_fence();
-    int tot = (int)rfl((u32)tot0) + kStepDense;
-    advance(s >> 16, s & 0xFFFF, v);
-    if (SCPR_UNLIKELY(tot + kStepDense > kProbScale)) tot = fixed_rebuild<PER>(fc, cnt, nsym);
-    if (lane == 0) L.fx.ftot[ti] = tot;
+    {
+      // no lane mask: lane 0 adds the step to the symbol's count, the others add 0 to words of the scratch area
+      const u32 addr = lane == 0 ? (u32)(size_t)&cnt[sym] : (u32)(size_t)tmp + 4u * (u32)lane;
+      const u32 dv = lane == 0 ? (u32)kStepDense : 0u;
+      asm volatile("ds_add_u32 %0, %1" ::"v"(addr), "v"(dv) : "memory");
+    }
+    int tot = tot0 + kStepDense;
+    advance(cf, fr, v);
+    if (SCPR_UNLIKELY(tot + kStepDense > kProbScale)) {
+      tot = fixed_rebuild<PER>(fc, cnt, nsym);
+      u32 na, nb;
+      top_of_table<PER>(fc, nsym, na, nb);
+      if (lane == tl) qtopA = na, qtopB = nb;
+    }
+    if (lane == tl) qtot = (u32)tot;
     count();
     return sym;
   }
