@@ -50,6 +50,8 @@ def parse_args(argv=None):
     ap.add_argument("--gop", type=int, default=None, help="key frame interval (ip: default 50; c4: default 150)")
     ap.add_argument("--cpu-frames", type=int, default=None, help="frames of the workload timed on the host CPU (default: the whole workload at 1080p keys, a bounded sample otherwise)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--c4-leg", action="store_true", help="run the configs[3] leg of an N > 1 run at N = 1 too (to rehearse it)")
+    ap.add_argument("--c4-frames", type=int, default=None, help="frames of the configs[3] leg's stream (default 1200)")
     ap.add_argument("--no-others", action="store_true", help="N = 1: do not measure the other single-GPU configs")
     ap.add_argument("--selftest-launcher", action="store_true", help="no codec, no GPU: ranks exchange synthetic packets over gloo (tests the launcher, the sharding and the gather)")
     return ap.parse_args(argv)
@@ -344,6 +346,52 @@ def run_rank(args):
     total_frames = wl.total_frames
     value = total_frames * W * H / 1e6 / (elapsed / args.steps)
 
+    # N > 1: configs[3] as well - ONE 3840x2160 stream of 1200 frames, key frame every 150, cut at key frames into `world`
+    # contiguous GOP ranges (strong scaling: 1200 / N frames per rank), compressed chunks gathered on rank 0 inside the timed
+    # step.  One warm-up and one timed pass; reported under config.others, never as `value`.
+    c4 = None
+    head_gathered = (int(gathered["s"].numel()), int(gathered["p"].numel())) if gathered.get("s") is not None else None
+    def all_reduce(t, op):
+        if world > 1:
+            dist.all_reduce(t, op=op)
+
+    if (world > 1 or args.c4_leg) and not args.no_others and args.workload == "keys" and (W, H, BPP) == (1920, 1080, 32) and not args.frames:
+        import copy
+        a4 = copy.copy(args)
+        a4.workload, a4.width, a4.height, a4.frames, a4.gop = "c4", None, None, args.c4_frames, None
+        wl4 = describe(a4, rank, world)
+        headline_out = m["out"].clone() if rank == 0 else None
+        del frames
+        runner.packets = runner.decoded = None
+        runner = None
+        m["out"] = headline_out
+        torch.cuda.empty_cache()
+        ready, f4, r4 = 1, None, None
+        try:
+            f4 = make_frames(wl4.w, wl4.h, wl4.seed, wl4.bpp, wl4.lo, wl4.hi, dev)
+            r4 = Runner(dev, local_rank, wl4.w, wl4.h, wl4.bpp, wl4.n)
+        except Exception as e:  # noqa: BLE001  (every rank still takes part in the collective below)
+            ready, c4 = 0, {"config": wl4.name, "error": repr(e)}
+        flag = torch.tensor([ready], device=dev, dtype=torch.int32)
+        all_reduce(flag, dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            m4 = measure(r4, wl4, f4, 1, 1, barrier, (wl4.lo, False, 0) if wl4.lo else None, exchange)
+            t4 = torch.tensor([m4["elapsed"]], device=dev, dtype=torch.float64)
+            all_reduce(t4, dist.ReduceOp.MAX)
+            pix4 = wl4.total_frames * wl4.w * wl4.h / 1e6
+            c4 = {"config": "configs[3]: ONE 3840x2160 stream, 1200 frames, key frame every 150, GOP-sharded over the ranks (strong scaling), packets gathered on rank 0 in the step",
+                  "workload": wl4.name, "scaling": "strong", "frames_total": wl4.total_frames, "frames_rank0": wl4.n, "gops_rank0": sum(1 for f in wl4.ftypes if f == 0),
+                  "value_MPix_s": round(pix4 / float(t4.item()), 2), "ms_per_step": round(float(t4.item()) * 1e3, 1),
+                  "enc_MPix_s_rank0": round(wl4.n * wl4.w * wl4.h / 1e6 / m4["t_enc"], 1), "dec_MPix_s_rank0": round(wl4.n * wl4.w * wl4.h / 1e6 / m4["t_dec"], 1),
+                  "lossless_roundtrip": True,
+                  "gathered_frames_rank0": int(gathered["s"].numel()) if gathered.get("s") is not None else None,
+                  "note": "a GOP is one serial chain (one wave): 8 GOPs run side by side on ONE GPU already, so this stream gains nothing from more GPUs - "
+                          "GPU count pays when the stream has more GOPs than one GPU has chain slots (768 at 1080p), see DESIGN.md 7"}
+        elif c4 is None:
+            c4 = {"config": wl4.name, "error": "another rank could not set the workload up"}
+        del f4, r4
+        frames = None
+
     if rank == 0:
         host = m["out"].cpu().numpy()
         comp_bytes = int(host.size)
@@ -384,7 +432,7 @@ def run_rank(args):
             except Exception as e:  # noqa: BLE001
                 parity["golden_fixture_ok"] = f"not checked: {e}"
         cpu = None
-        if not args.no_cpu and world == 1:  # the CPU baseline is a rank-0, one-GPU measurement
+        if not args.no_cpu and world == 1 and frames is not None:  # the CPU baseline is a rank-0, one-GPU measurement
             big = W * H > 1920 * 1080 or args.workload != "keys"
             nf = min(args.cpu_frames or (40 if big else N), N)
             try:
@@ -406,10 +454,9 @@ def run_rank(args):
                   "compressed_bytes_rank0": comp_bytes,
                   "enc_MPix_s_rank0": round(N * W * H / 1e6 / m["t_enc"], 2), "dec_MPix_s_rank0": round(N * W * H / 1e6 / m["t_dec"], 2),
                   "stage_ms_per_step": {k: round(v, 3) for k, v in per_step.items()}}
-        if world > 1 and gathered.get("s") is not None:
-            config["gathered_frames_rank0"] = int(gathered["s"].numel())
-            config["gathered_bytes_rank0"] = int(gathered["p"].numel())
-        if world == 1:
+        if world > 1 and head_gathered is not None:
+            config["gathered_frames_rank0"], config["gathered_bytes_rank0"] = head_gathered
+        if world == 1 and frames is not None:
             # the boundary hands over host buffers (ScreenCodec::CompressFrame takes host pointers, screencap.cpp:1632): the
             # same pass with the frames coming from and going back to pinned host memory, packets crossing both ways
             try:
@@ -427,7 +474,9 @@ def run_rank(args):
                 del h_in, h_out, d_in
             except Exception as e:  # noqa: BLE001
                 config["incl_host_transfer_MPix_s"] = f"not measured: {e}"
-        if world == 1 and not args.no_others and args.workload == "keys" and (W, H, BPP) == (1920, 1080, 32) and not args.frames:
+        if c4 is not None:
+            config["others"] = [c4]
+        if world == 1 and c4 is None and not args.no_others and args.workload == "keys" and (W, H, BPP) == (1920, 1080, 32) and not args.frames:
             others, cache = [], {(W, H, BPP): runner}
             cf = args.cpu_frames or 60
 

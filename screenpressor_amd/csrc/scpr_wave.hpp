@@ -115,16 +115,20 @@ struct __attribute__((aligned(16))) WaveLds {
   u32 dtag[64];        // tags of the dense-table cache (WaveModel::tab_of)
   FixedLdsP fp;
   u32 tile[17 * 17];   // P-frame block under reconstruction, with one row above and one column to the left
-  uint2 jobs[256];     // deferred motion-block copies of the current P-frame
+  uint2 jobs[256];     // motion-block copies on their way to the helper waves (a ring, see hc)
   // Helper waves (P-frame GOPs: the workgroup is the chain's wave + helpers, see helper_loop): commands go out by bumping
   // `seq` after the arguments are in place, every helper adds 1 to `done` when it has finished the command it saw.
+  // Motion-block copies do not go through commands: the chain appends a job to the ring `jobs` and publishes the new count
+  // in `jtail`; helper h takes the jobs whose number is h modulo the number of helpers, in order, as soon as they appear, and
+  // keeps the number of its next job in hprog[h] - every job below the smallest hprog is finished.
   struct {
     u32 seq, op, done, nhelp;
     u64 src, dst;
-    u32 bytes, pad;
+    u32 bytes, jtail;
+    u32 hprog[16];
   } hc;
 };
-enum : u32 { HOP_COPY = 1, HOP_JOBS = 2, HOP_EXIT = 3 };
+enum : u32 { HOP_COPY = 1, HOP_EXIT = 3 };
 
 // The colour model of one context, operated by a whole wave.  The header is
 // wave-uniform (scalar registers), a small table is one entry per lane (lanes
@@ -1548,26 +1552,61 @@ __device__ __forceinline__ void copy_plane_part(u8* __restrict__ cur, const u8* 
     for (size_t q = (bytes & ~(size_t)15) + lane; q < bytes; q += 64) cur[q] = prv[q];
   }
 }
-__device__ __forceinline__ void helper_loop(WaveLds& L, int S) {
-  const int lane = lane_id(), hw = (int)(threadIdx.x >> 6) - 1, nh = (int)(blockDim.x >> 6) - 1;
-  u32 seen = 0;
-  for (;;) {
-    u32 sq = lds_peek(&L.hc.seq);
-    while (sq == seen) {
-      __builtin_amdgcn_s_sleep(4);
-      sq = lds_peek(&L.hc.seq);
+// one motion block, by a whole wave: lane = row * 4 + quarter of the row (four pixels, three words)
+__device__ __forceinline__ void copy_motion_block(uint2 j, u8* __restrict__ cur, const u8* __restrict__ prv, int S, int lane) {
+  const int jx1 = (int)(j.x & 0x1FFF), jy1 = (int)((j.x >> 13) & 0x1FFF), jw = (int)((j.x >> 26) & 15) + 1;
+  const int jh = (int)(j.y & 15) + 1, jmx = (int)((j.y >> 4) & 0x3FF) - 512, jmy = (int)((j.y >> 14) & 0x3FF) - 512;
+  const int r = lane >> 2, o = (lane & 3) * 12, wb = jw * 3;
+  if (r < jh && o < wb) {
+    const u8* sp = prv + (size_t)(jy1 + r + jmy) * S + (jx1 + jmx) * 3 + o;
+    u8* dp = cur + (size_t)(jy1 + r) * S + jx1 * 3 + o;
+    if (wb - o >= 12) {
+      u32 v[3];
+#pragma unroll
+      for (int k = 0; k < 3; k++) __builtin_memcpy(&v[k], sp + k * 4, 4);
+#pragma unroll
+      for (int k = 0; k < 3; k++) __builtin_memcpy(dp + k * 4, &v[k], 4);
+    } else {
+      u8 v[9];
+#pragma unroll
+      for (int k = 0; k < 9; k++)
+        if (k < wb - o) v[k] = sp[k];
+#pragma unroll
+      for (int k = 0; k < 9; k++)
+        if (k < wb - o) dp[k] = v[k];
     }
-    seen = sq;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    const u32 op = lds_peek(&L.hc.op);
-    if (op == HOP_EXIT) break;
-    u8* cur = (u8*)(size_t)L.hc.dst;
-    const u8* prv = (const u8*)(size_t)L.hc.src;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the planes were written by other waves: nothing stale from this CU's L1
-    if (op == HOP_COPY) copy_plane_part(cur, prv, (size_t)L.hc.bytes, hw, nh, lane);
-    else copy_motion_jobs(L.jobs, 4 * hw, (int)L.hc.bytes, 4 * nh, cur, prv, S, lane);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores have reached L2
-    if (lane == 0) __hip_atomic_fetch_add(&L.hc.done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+}
+__device__ __forceinline__ void helper_loop(WaveLds& L, int S, int hw, int nh) {
+  const int lane = lane_id();
+  u32 seen = 0, next = (u32)hw;  // the command last seen; the number of this helper's next motion job
+  u8* cur = nullptr;
+  const u8* prv = nullptr;
+  for (;;) {
+    const u32 sq = lds_peek(&L.hc.seq);
+    if (sq != seen) {
+      seen = sq;
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      const u32 op = lds_peek(&L.hc.op);
+      if (op == HOP_EXIT) break;
+      cur = (u8*)(size_t)L.hc.dst;  // (the motion jobs that follow are for these planes too)
+      prv = (const u8*)(size_t)L.hc.src;
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the planes were written by other waves: nothing stale from this CU's L1
+      copy_plane_part(cur, prv, (size_t)L.hc.bytes, hw, nh, lane);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores have reached L2
+      if (lane == 0) __hip_atomic_fetch_add(&L.hc.done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      continue;
+    }
+    const u32 tail = __hip_atomic_load(&L.hc.jtail, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if ((int)(tail - next) > 0) {
+      const uint2 j = L.jobs[next & 255u];
+      copy_motion_block(j, cur, prv, S, lane);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      next += (u32)nh;
+      if (lane == 0) __hip_atomic_store(&L.hc.hprog[hw], next, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else {
+      __builtin_amdgcn_s_sleep(2);
+    }
   }
 }
 // the chain's side
@@ -1581,12 +1620,23 @@ __device__ __forceinline__ void help_post(WaveLds& L, u32 op, const u8* src, u8*
     __hip_atomic_fetch_add(&L.hc.seq, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
 }
+// every motion job below number `upto` has been copied (and its stores have reached L2)
+__device__ __forceinline__ void help_wait_jobs(WaveLds& L, u32 upto, int nhelp) {
+  const int lane = lane_id();
+  for (;;) {
+    const u32 v = lane < nhelp ? lds_peek(&L.hc.hprog[lane]) : upto;
+    if (!__ballot((int)(v - upto) < 0)) break;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 __device__ __forceinline__ void help_wait(WaveLds& L) {
   const u32 nh = L.hc.nhelp;
   while (lds_peek(&L.hc.done) < nh) __builtin_amdgcn_s_sleep(2);
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+__constant__ const u32 kRcp16[17] = {0, 65536, 32768, 21846, 16384, 13108, 10923, 9363, 8192, 7282, 6554, 5958, 5462, 5042, 4682, 4370, 4096};
 // P-frame (DecompressP, screencap.cpp:1275-1432).  The new plane starts as a copy of the previous
 // one; motion blocks are copied from the previous plane, pixel-coded rects are rebuilt in an LDS
 // tile (with the row above and the column to the left as predictor context) and written back.
@@ -1652,43 +1702,25 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
   D.template stamp<5>();
   u32 lastpix = 0;  // cx = cx1 = 0 (:1317)
   int lastmx = 0, lastmy = 0;
+  const u32 rcpn = (u32)((0x100000000ull + (u32)nbx - 1u) / (u32)nbx);
   u32* tile = D.L.tile;
   uint2* jobs = D.L.jobs;
-  int njobs = 0;
-  // motion-block copies are queued and executed four blocks at a time (one row per lane, a row's
-  // bytes in flight together); the source is the previous plane, which this frame never modifies
+  // Motion-block copies (the source is the previous plane, which this frame never modifies): with helper waves every block
+  // is handed over as soon as it is decoded and copied while the chain goes on (see WaveLds::hc); a rect waits for them
+  // only when one of the blocks its context border comes from is a motion block.  Without helpers the blocks are
+  // queued and copied by this wave, four at a time, before the next rect and at the end of the frame.
+  int njobs = 0;                            // without helpers: blocks waiting in `jobs`
+  u32 jt = 0;                               // with helpers: blocks handed over so far (the ring goes on from frame to frame)
+  if constexpr (DEC::kHelpers) jt = D.L.hc.jtail;
   auto flush_jobs = [&]() __attribute__((always_inline)) {
     wave_fence();
-    if (nhelp && njobs > 8) {  // enough blocks to be worth a hand-over: the helpers take four blocks per wave and trip
-      hpost(HOP_JOBS, (u32)njobs);
-      hwait();
-      njobs = 0;
-      wave_fence();
-      return;
-    }
-    for (int base = 0; base < njobs; base += 4) {
-      const int jb = base + (lane >> 4), r = lane & 15;
-      if (jb < njobs) {
-        const uint2 j = jobs[jb];
-        const int jx1 = (int)(j.x & 0x1FFF), jy1 = (int)((j.x >> 13) & 0x1FFF), jw = (int)((j.x >> 26) & 15) + 1;
-        const int jh = (int)(j.y & 15) + 1, jmx = (int)((j.y >> 4) & 0x3FF) - 512, jmy = (int)((j.y >> 14) & 0x3FF) - 512;
-        if (r < jh) {
-          const u8* sp = prv + (size_t)(jy1 + r + jmy) * S + (jx1 + jmx) * 3;
-          u8* dp = cur + (size_t)(jy1 + r) * S + jx1 * 3;
-          const int wb = jw * 3;
-          u32 v[12];
-#pragma unroll
-          for (int k = 0; k < 12; k++)
-            if (k * 4 < wb) __builtin_memcpy(&v[k], sp + k * 4, 4);
-#pragma unroll
-          for (int k = 0; k < 12; k++) {
-            if (k * 4 + 4 <= wb) __builtin_memcpy(dp + k * 4, &v[k], 4);
-            else if (k * 4 < wb)
-              for (int q = 0; q < wb - k * 4; q++) dp[k * 4 + q] = (u8)(v[k] >> (8 * q));
-          }
-        }
+    if constexpr (DEC::kHelpers) {
+      if (nhelp) {
+        help_wait_jobs(D.L, jt, nhelp);
+        return;
       }
     }
+    copy_motion_jobs(jobs, 0, njobs, 4, cur, prv, S, lane);
     njobs = 0;
     wave_fence();
   };
@@ -1700,7 +1732,7 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
     bm &= bm - 1;
     const int b = gbase + bj;
     const int t = (int)rdl(tb, bj);
-    const int by = b / nbx, bx = b - by * nbx;
+    const int by = (int)__umulhi((u32)b, rcpn), bx = b - by * nbx;  // == b / nbx (b < 2^18, nbx <= 512: the rounding error stays below one)
     int x1 = bx * 16, y1 = by * 16, x2 = min(x1 + 16, W), y2 = min(y1 + 16, H);
     if ((t - 1) & 1) {  // changed rect inside the block (:1333-1346)
       D.tick();
@@ -1736,13 +1768,33 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
         D.bad = true;
         break;
       }
-      if (lane == 0) jobs[njobs] = make_uint2((u32)x1 | ((u32)y1 << 13) | ((u32)(w - 1) << 26), (u32)(h - 1) | ((u32)(mx + 512) << 4) | ((u32)(my + 512) << 14));
-      if (SCPR_UNLIKELY(++njobs == 256)) flush_jobs();
+      const uint2 job = make_uint2((u32)x1 | ((u32)y1 << 13) | ((u32)(w - 1) << 26), (u32)(h - 1) | ((u32)(mx + 512) << 4) | ((u32)(my + 512) << 14));
+      if (nhelp) {
+        if constexpr (DEC::kHelpers) {
+          // (the ring slots written from here to the next test held the jobs 193..256 back)
+          if (SCPR_UNLIKELY((jt & 63u) == 0)) help_wait_jobs(D.L, jt - 192u, nhelp);
+          jobs[jt & 255u] = job;
+          jt++;
+          __hip_atomic_store(&D.L.hc.jtail, jt, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      } else {
+        if (lane == 0) jobs[njobs] = job;
+        if (SCPR_UNLIKELY(++njobs == 256)) flush_jobs();
+      }
+      D.template stamp<20>();
       continue;
     }
-    if (njobs) flush_jobs();  // a copied block may be this rect's left/top context
+    D.template stamp<6>();
+    if (nhelp) {  // a copied block may be this rect's left/top context: is one of the three blocks the border lies in a motion block?
+      const int nq = lane == 0 ? (bx > 0 ? b - 1 : -1) : lane == 1 ? (by > 0 ? b - nbx : -1) : lane == 2 ? (bx > 0 && by > 0 ? b - nbx - 1 : -1) : -1;
+      const u32 nt = nq >= 0 ? (u32)bts[nq] : 0u;
+      if (__ballot(nt >= 3u)) flush_jobs();
+    } else if (njobs) {
+      flush_jobs();
+    }
     // pixel-coded rect (:1370-1421): context border from the plane, then runs inside the tile
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores to the plane have reached L2
+    D.template stamp<3>();
     u32 border = 0;
     int border_at = 0;
     {
@@ -1762,7 +1814,7 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
     D.template stamp<6>();
     int x = x1, y = y1, pt = 0;
     const int lc = min(lane, 15);
-    const int rcpw = (65536 + w - 1) / w;  // (li * rcpw) >> 16 == li / w for li <= 256, w <= 16
+    const int rcpw = (int)kRcp16[w];  // ceil(65536 / w): (li * rcpw) >> 16 == li / w for li <= 256, w <= 16
     // One run of the rect, in two instances like the key-frame loop: the careful one tests for the end of the coder
     // block after every symbol, the fast one is entered while the block cannot end within a run and counts the
     // run's symbols in one go.  A refused stream ends the rect (y = y2) instead of leaving the loops from inside.
@@ -1899,16 +1951,17 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
     D.template stamp<7>();
     wave_fence();
     for (int i = lane; i < w * h; i += 64) {  // the finished rect goes to the plane
-      const int yy = i / w, xq = i - yy * w;
+      const int yy = (i * rcpw) >> 16, xq = i - yy * w;
       const u32 v = tile[(yy + 1) * 17 + xq + 1];
       u8* dp = cur + (size_t)(y1 + yy) * S + (x1 + xq) * 3;
       dp[0] = (u8)v;
       dp[1] = (u8)(v >> 8);
       dp[2] = (u8)(v >> 16);
     }
+    D.template stamp<19>();
    }
   }
-  if (njobs) flush_jobs();
+  flush_jobs();  // the frame is complete (and the next one reads it) when every block is in place
 }
 
 template <bool HAS_P>
@@ -1924,10 +1977,15 @@ __global__ __launch_bounds__(HAS_P ? 512 : 64) void k_decode_gop_w(const u8* __r
   for (int i = lane; i < CACHE_N; i += 64) L.crec[i][3] = kNoCtx;  // empty cache
   if (threadIdx.x < 64) L.dtag[lane] = 0;
   if (HAS_P) {
-    if (threadIdx.x == 0) L.hc.seq = 0, L.hc.op = 0, L.hc.done = 0, L.hc.nhelp = (blockDim.x >> 6) - 1;
+    // Helper waves: bulk copies for the chain (wave 0), until it says stop.  A workgroup's waves go round the CU's four SIMDs:
+    // wave 4 would sit on the chain's SIMD and take issue slots from it with its polling, so it leaves at once.
+    const int nwaves = (int)(blockDim.x >> 6), wv = (int)(threadIdx.x >> 6);
+    const int nh = nwaves > 4 ? nwaves - 2 : nwaves - 1;
+    if (threadIdx.x == 0) L.hc.seq = 0, L.hc.op = 0, L.hc.done = 0, L.hc.nhelp = (u32)nh, L.hc.jtail = 0;
+    if (threadIdx.x < 16) L.hc.hprog[threadIdx.x] = threadIdx.x;
     __syncthreads();
-    if (threadIdx.x >= 64) {  // helper waves: bulk copies for the chain (wave 0), until it says stop
-      helper_loop(L, g.S);
+    if (wv > 0) {
+      if (wv != 4) helper_loop(L, g.S, wv < 4 ? wv - 1 : wv - 2, nh);
       return;
     }
   }

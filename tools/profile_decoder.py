@@ -48,7 +48,7 @@ L.scpr_debug_profile(out)
 ev = np.array(list(out)[8:16], dtype=np.float64)
 ex = np.array(list(out)[16:], dtype=np.float64)
 v = np.array(list(out)[:8], dtype=np.float64)
-names = ["P", "colour", "N", "fill", "rows/loop", "P-frame: plane copy, header, block types", "P-frame: rect border + write-back, motion copies", "P-frame: runs"]
+names = ["P", "colour", "N", "fill (key frames) / wait for motion copies and own stores (P-frames)", "rows/loop", "P-frame: plane copy, header, block types", "P-frame: rect header symbols", "P-frame: runs"]
 tot = v.sum()
 print("ticks per frame: %.0f" % (tot / n))
 for nm, x in zip(names, v):
@@ -57,4 +57,4 @@ for nm, x in zip(names, v):
 for nm, x in zip(["colour symbols", "record cache misses", "dense-table symbols", "raw symbols", "small-table slow path", "runs", "literal runs", "dense-table cache misses"], ev):
     print("%-50s %.0f per frame" % (nm, x / n))
 print("dense fast-path hits per frame: %.0f; small-table hits on the top entry: %.0f, in one-symbol tables: %.0f" % (ex[0] / n, ex[1] / n, ex[2] / n))
-print("P-frame runs by pixel type 1..5 per frame:", [round(x / n) for x in ex[3:8]])
+print("P-frame, more sections (ticks/frame): rect write-back %.0f, motion blocks (symbols, hand-over) %.0f" % (ex[3] / n, ex[4] / n))
