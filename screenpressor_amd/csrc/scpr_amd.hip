@@ -92,6 +92,7 @@ struct scpr_codec {
   int slots = 0;  // frames processed per chunk
   // per-slot worst-case buffers
   DevBuf planes, exitmap, entry, runrec, tilecnt, tileoff, hdrrec, hdrcnt, frametot, tnmap;
+  size_t tn_half = 0;
   // per-batch buffers
   DevBuf flags, slotlist, genlist, bases, totals, runs, runpos, keys[2], vals[2], cstart, sorttmp, entries, ranges;
   DevBuf rblocks, rscratch, rsize, packets, pktoff, blkdst, outsizes, total64, arena, arena_top, err, rcp;
@@ -192,7 +193,8 @@ static int ensure_codec(scpr_codec* c, int version) {  // CreateCodec + CScreenC
   HIPCHK(c->planes.reserve(ns * g.plane_stride));
   HIPCHK(hipMemsetAsync(c->planes.p, 0, ns * g.plane_stride, c->stream));
   HIPCHK(c->exitmap.reserve(ns * g.ntiles * 512));
-  HIPCHK(c->tnmap.reserve(ns * g.ntiles * TILE * 2));
+  c->tn_half = ns * g.ntiles * TILE;  // type | short length per pixel, then (same size, written only where needed) the long lengths
+  HIPCHK(c->tnmap.reserve(c->tn_half * 2));
   HIPCHK(c->entry.reserve(ns * g.ntiles * 2));
   HIPCHK(c->runrec.reserve(ns * g.ntiles * TILE * 4));
   HIPCHK(c->tilecnt.reserve(ns * g.ntiles * 8));
@@ -304,9 +306,13 @@ static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int n
     HIPCHK(hipMemcpyAsync(c->genlist.p, igens.data(), ni * 4, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(c->fidx.p, ifidx.data(), ni * 4, hipMemcpyHostToDevice, st));
     stage_begin(c, ST_CLASSIFY);
-    hipLaunchKernelGGL(k_tiles, dim3(g.ntiles, ni), dim3(256), 0, st, planes, g, d_slots, c->exitmap.as<u8>(), c->tnmap.as<u16>());
+    hipLaunchKernelGGL(k_tiles, dim3(g.ntiles, ni), dim3(256), 0, st, planes, g, d_slots, c->exitmap.as<u8>(), c->tnmap.as<u8>(), c->tnmap.as<u8>() + (size_t)c->tn_half);
     hipLaunchKernelGGL(k_entries, dim3(ni), dim3(64), 0, st, c->exitmap.as<u8>(), c->entry.as<u8>(), g, d_slots);
-    hipLaunchKernelGGL(k_runs, dim3((g.ntiles + 255) / 256, ni), dim3(256), 0, st, g, d_slots, c->entry.as<u8>(), c->tnmap.as<u16>(), c->runrec.as<u32>(),
+    // k_runs walks one tile per lane, a cache line of the type/length map at a time: with every CU full of its waves the lines
+    // in use (8 MB per XCD) do not fit the XCD's 4 MB L2 and are fetched three times over.  Unused dynamic LDS keeps it to two
+    // workgroups per CU - each line comes in once (profiles/: FETCH_SIZE 1.98 GB -> 0.40 GB per launch, +0.2 ms).
+    static const int runs_lds = getenv("SCPR_RUNS_LDS") ? atoi(getenv("SCPR_RUNS_LDS")) : 65000;
+    hipLaunchKernelGGL(k_runs, dim3((g.ntiles + 255) / 256, ni), dim3(256), runs_lds, st, g, d_slots, c->entry.as<u8>(), c->tnmap.as<u8>(), c->tnmap.as<u8>() + (size_t)c->tn_half, c->runrec.as<u32>(),
                        c->tilecnt.as<u32>());
     hipLaunchKernelGGL(k_header, dim3(ni), dim3(64), 0, st, planes, g, d_slots, c->hdrrec.as<u32>(), c->hdrcnt.as<u32>());
     stage_end(c, ST_CLASSIFY);

@@ -313,11 +313,20 @@ __device__ __forceinline__ int block_excl_scan(int v, int* tot, int* wsum /*shar
 // exit map row: for every entry offset e < 255: [2e] = offset at which the path
 // leaves into the next tile, [2e+1] = type of the run that crosses the border.
 // tilecnt: {runs, literal runs} per tile.   runrec: rel_start | type<<10 | n<<16
-__global__ __launch_bounds__(256) void k_tiles(const u8* __restrict__ planes, Geom g, const int* __restrict__ slots, u8* __restrict__ exitmap, u16* __restrict__ tnmap) {
+__global__ __launch_bounds__(256) void k_tiles(const u8* __restrict__ planes, Geom g, const int* __restrict__ slots, u8* __restrict__ exitmap, u8* __restrict__ tnmap, u8* __restrict__ nlong) {
   __shared__ u64 fm[4][24];
   __shared__ u8 ty[TILE];
   __shared__ u32 lp[2][TILE];  // successor | last run start << 16, one word per doubling step
-  const int slot = slots[blockIdx.y], tile = blockIdx.x, tid = threadIdx.x;
+  __shared__ u32 more[2][4];
+  // Workgroups go round the eight XCDs in launch order, and every XCD has its own L2: tile t reads the row above its pixels,
+  // which tile t - W / 1024 (the one before the last, at 1080p) has just read.  The launch order is therefore remapped so
+  // that each XCD gets one contiguous eighth of the (frame, tile) space - neighbouring tiles meet in the same L2 instead
+  // of being fetched from memory once per XCD.
+  const u32 nwg = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+  const u32 xq = nwg >> 3, xr = nwg & 7u, xcd = lin & 7u, xk = lin >> 3;
+  const u32 ord = xcd < xr ? xcd * (xq + 1u) + xk : xr * (xq + 1u) + (xcd - xr) * xq + xk;
+  const int fidx = (int)(ord / gridDim.x);
+  const int slot = slots[fidx], tile = (int)(ord - (u32)fidx * gridDim.x), tid = threadIdx.x;
   const u8* plane = planes + (size_t)slot * g.plane_stride;
   const int tstart = g.p0 + tile * TILE;
   // row and column of the tile's first pixel, once per workgroup; a pixel's own come from there by stepping over
@@ -351,23 +360,33 @@ __global__ __launch_bounds__(256) void k_tiles(const u8* __restrict__ planes, Ge
     if (p < g.NP) {
       int n = ones_from(fm[fit_bit_of_type(ty[r])], r + 1, HALO - 1);
       j = (p + 1 + n >= g.NP) ? EXITED : r + 1 + n;
-      // for k_runs: type and length of the run that would start here (it never looks at a pixel again)
-      tnmap[((size_t)slot * g.ntiles + tile) * TILE + r] = (u16)((u32)ty[r] | ((u32)n << 8));
+      // for k_runs: type and length of the run that would start here (it never looks at a pixel again) - one byte,
+      // type | min(n, 31) << 3; the few lengths from 31 up are in a second array that is written (and read) only there
+      const size_t at = ((size_t)slot * g.ntiles + tile) * TILE + r;
+      tnmap[at] = (u8)((u32)ty[r] | ((u32)min(n, 31) << 3));
+      if (n >= 31) nlong[at] = (u8)n;
     }
     lp[0][r] = (u32)j | ((u32)r << 16);
   }
   __syncthreads();
   int cur = 0;
-  for (int it = 0; it < 10; it++) {
+  for (int it = 0; it < 10; it++) {  // (2^10 steps: every path has left the tile)
+    u32 v0 = 0;
     for (int k = 0; k < 4; k++) {
       const int r = k * 256 + tid;
       u32 v = lp[cur][r];
       const u32 j = v & 0xFFFFu;
       if (j < TILE) v = lp[cur][j];  // jump: the successor's successor, and the start of the run it sits in
       lp[cur ^ 1][r] = v;
+      if (k == 0) v0 = v;
     }
+    // only the paths from the HALO possible entry points are asked for: ~110 runs per tile, seven steps as a rule
+    // (the verdict rides on the iteration's own barrier: one flag per wave, two sets in turn)
+    const u64 live = __ballot(tid < HALO && (v0 & 0xFFFFu) < (u32)TILE);
+    if (lane_id() == 0) more[it & 1][tid >> 6] = live != 0;
     __syncthreads();
     cur ^= 1;
+    if (!(more[it & 1][0] | more[it & 1][1] | more[it & 1][2] | more[it & 1][3])) break;
   }
   if (tid < HALO) {
     const u32 v = lp[cur][tid];
@@ -407,17 +426,18 @@ __global__ __launch_bounds__(64) void k_entries(const u8* __restrict__ exitmap, 
 }
 
 // The runs of every tile, from where k_entries says the frame's path enters it: one LANE per tile walks the path (the type and
-// the length of the run that would start at any pixel were written by the first pass: one 2-byte load per step),
+// the length of the run that would start at any pixel were written by the first pass: one byte load per step),
 // ~110 steps on average, and writes the tile's run records in order.  The tiles of a frame are independent once their entry
 // points are known, and a frame has 2000 of them: the walk needs no pointer doubling (the second k_tiles pass it replaces
 // re-classified every pixel and squared the successor function nine times to mark the same path).
 // tilecnt: {runs, literal runs} per tile.   runrec: rel_start | type<<10 | n<<16
-__global__ __launch_bounds__(256) void k_runs(Geom g, const int* __restrict__ slots, const u8* __restrict__ entry, const u16* __restrict__ tnmap,
+__global__ __launch_bounds__(256) void k_runs(Geom g, const int* __restrict__ slots, const u8* __restrict__ entry, const u8* __restrict__ tnmap, const u8* __restrict__ nlong,
                                               u32* __restrict__ runrec, u32* __restrict__ tilecnt) {
   const int slot = slots[blockIdx.y], tile = blockIdx.x * 256 + threadIdx.x;
   if (tile >= g.ntiles) return;
   const size_t ti = (size_t)slot * g.ntiles + tile;
-  const u16* tn = tnmap + ti * TILE;
+  const u8* tn = tnmap + ti * TILE;
+  const u8* nl = nlong + ti * TILE;
   u32* rec = runrec + ti * TILE;
   const int tstart = g.p0 + tile * TILE;
   int r = entry[ti * 2], cnt = 0, lit = 0;  // 255: a run from an earlier tile already reached the frame end
@@ -426,7 +446,9 @@ __global__ __launch_bounds__(256) void k_runs(Geom g, const int* __restrict__ sl
     while (r < TILE && tstart + r < g.NP) {
       const u32 v = tn[r];
       const int t = (int)(v & 7u);
-      int j = r + 1 + (int)(v >> 8);
+      int n = (int)(v >> 3);
+      if (n == 31) n = nl[r];
+      int j = r + 1 + n;
       int len = j - r;
       if (tstart + j >= g.NP) {  // the run reaches the end of the frame
         len = g.NP - (tstart + r);
