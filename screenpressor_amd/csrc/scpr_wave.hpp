@@ -101,11 +101,9 @@ struct FixedLdsP {      // the tables only P-frames use
   u32 mcnt[2][512];
   u32 xfc[2][256];
   u32 xcnt[2][256];
-  u32 sfc[4][16];
-  u32 scnt[4][16];
   u32 bfc[8];
   u32 bcnt[8];
-};
+};                      // (the four 16-symbol tables of the rect coordinates live in registers: WaveDec::sxfc / sxcnt)
 // (Everything from `fp` on is for P-frames: a batch of key frames - k_decode_gop_w<false> - allocates the struct up to there,
 // which lets three of its workgroups share a CU at 1080p: 768 key frames per round instead of 512.)
 struct __attribute__((aligned(16))) WaveLds {
@@ -695,6 +693,8 @@ struct WaveDec : WaveModel {
   int ndec = 0;
   // pixel-type tables (ptypetab) in registers: table t in lanes 8t..8t+5 (entries) and 8t+7 (the running total, in pcnt)
   u32 pfc = 0xFFFFFFFFu, pcnt = 0;
+  // the changed-rect coordinate tables (sxytab) likewise: table t in lanes 16t..16t+15 (their totals are qtot lanes 4..7)
+  u32 sxfc = 0xFFFFFFFFu, sxcnt = 0;
   // the P-frame tables (fixed_any; lane = table - 12: motion x / y, block index bytes, block-type run lengths, rect x1 y1 x2 y2,
   // block type): the widest symbol of each as start | (width - 1) << 12 and its number, and the table's running total.  Motion
   // vectors repeat from block to block: the widest symbol takes almost every lookup, with one compare and nothing read.
@@ -826,7 +826,9 @@ struct WaveDec : WaveModel {
         fill(FP.mfc[t], FP.mcnt[t], 512, 512, 12 + t);
         fill(FP.xfc[t], FP.xcnt[t], 256, 256, 14 + t);
       }
-      for (int t = 0; t < 4; t++) fill(FP.sfc[t], FP.scnt[t], 16, 16, 16 + t);
+      sxfc = 256u | ((u32)(256 * (lane & 15)) << 16);
+      sxcnt = 128u;
+      if (lane >= 16 && lane < 20) F.ftot[lane] = 128 * 16;
       fill(FP.bfc, FP.bcnt, 5, 8, 20);
       // every symbol of a renewed table is equally wide: its widest symbol is symbol 0
       const int nsyms = lane < 2 ? 512 : lane < 4 ? 256 : lane < 8 ? 16 : 5, fr = kProbScale / nsyms;
@@ -846,10 +848,6 @@ struct WaveDec : WaveModel {
       if (lane == t) qtopA = a, qtopB = b;
       top_of_table<4>(FP.xfc[t], 256, a, b);
       if (lane == 2 + t) qtopA = a, qtopB = b;
-    }
-    for (int t = 0; t < 4; t++) {
-      top_of_table<1>(FP.sfc[t], 16, a, b);
-      if (lane == 4 + t) qtopA = a, qtopB = b;
     }
     top_of_table<1>(FP.bfc, 5, a, b);
     if (lane == 8) qtopA = a, qtopB = b;
@@ -896,8 +894,8 @@ struct WaveDec : WaveModel {
         (&FP.xfc[0][0])[i] = (&B->xfc[0][0])[i];
         (&FP.xcnt[0][0])[i] = (&B->xcnt[0][0])[i];
       }
-      (&FP.sfc[0][0])[lane] = (&B->sfc[0][0])[lane];
-      (&FP.scnt[0][0])[lane] = (&B->scnt[0][0])[lane];
+      sxfc = (&B->sfc[0][0])[lane];
+      sxcnt = (&B->scnt[0][0])[lane];
       if (lane < 8) {
         FP.bfc[lane] = B->bfc[lane];
         FP.bcnt[lane] = B->bcnt[lane];
@@ -928,8 +926,8 @@ struct WaveDec : WaveModel {
         (&B->xfc[0][0])[i] = (&FP.xfc[0][0])[i];
         (&B->xcnt[0][0])[i] = (&FP.xcnt[0][0])[i];
       }
-      (&B->sfc[0][0])[lane] = (&FP.sfc[0][0])[lane];
-      (&B->scnt[0][0])[lane] = (&FP.scnt[0][0])[lane];
+      (&B->sfc[0][0])[lane] = sxfc;
+      (&B->scnt[0][0])[lane] = sxcnt;
       if (lane < 8) {
         B->bfc[lane] = FP.bfc[lane];
         B->bcnt[lane] = FP.bcnt[lane];
@@ -1128,7 +1126,32 @@ struct WaveDec : WaveModel {
   }
   __device__ __forceinline__ int fixed_mv(int t) { return fixed_any<8>(L.fp.mfc[t], L.fp.mcnt[t], 512, 12 + t); }
   __device__ __forceinline__ int fixed_x(int t) { return fixed_any<4>(L.fp.xfc[t], L.fp.xcnt[t], 256, 14 + t); }
-  __device__ __forceinline__ int fixed_sxy(int t) { return fixed_any<1>(L.fp.sfc[t], L.fp.scnt[t], 16, 16 + t); }
+  // a coordinate of a changed rect: the tables are in registers, searched like the pixel types (fixed_p)
+  __device__ __forceinline__ int fixed_sxy(int t) {
+    const u32 v = x & (kProbScale - 1), lim = (v + 1) << 16;
+    const u64 m = __ballot(sxfc < lim);
+    const u32 mt = (u32)(m >> (16 * t)) & 0xFFFFu;  // never 0: the first cum is 0
+    const int j = 31 - __builtin_clz(mt);
+    const int own = 16 * t + j, tl = 4 + t;
+    const u32 s = rdl(sxfc, own);
+    int tot = (int)rdl(qtot, tl) + kStepDense;
+    sxcnt += lane == own ? (u32)kStepDense : 0u;
+    advance(s >> 16, s & 0xFFFF, v);
+    if (SCPR_UNLIKELY(tot + kStepDense > kProbScale)) {  // incrCnt rebuild, ans_contexts.h:1075-1090
+      const bool in = (lane >> 4) == t;
+      const int c = in ? (int)sxcnt : 0;
+      const int inc = wave_incl_scan(c);
+      const int h = c - (c >> 1);
+      tot = wave_sum(h);
+      if (in) {
+        sxfc = (u32)c | ((u32)(inc - c) << 16);
+        sxcnt = (u32)h;
+      }
+    }
+    if (lane == tl) qtot = (u32)tot;
+    count();
+    return j;
+  }
   __device__ __forceinline__ int fixed_bt() { return fixed_any<1>(L.fp.bfc, L.fp.bcnt, 5, 20); }
   __device__ __forceinline__ bool get_bool() {  // decodeBool, screencap.h:411-421
     const u32 v = x & (kProbScale - 1);
