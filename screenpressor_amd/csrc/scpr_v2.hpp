@@ -29,6 +29,7 @@ struct V2Fixed {       // count tables of UseRC; rows are zero past the alphabet
 struct __attribute__((aligned(16))) V2Lds {
   V2Fixed fx;
   u32 tile[17 * 17];
+  u32 ptile[256];
   uint2 jobs[256];
 };
 constexpr int V2_COLTAB = 256;          // words per colour table in HBM

@@ -113,6 +113,7 @@ struct __attribute__((aligned(16))) WaveLds {
   u32 dtag[64];        // tags of the dense-table cache (WaveModel::tab_of)
   FixedLdsP fp;
   u32 tile[17 * 17];   // P-frame block under reconstruction, with one row above and one column to the left
+  u32 ptile[256];      // the same rect in the previous frame (row-major, w * h pixels): what "previous frame" runs copy
   uint2 jobs[256];     // motion-block copies on their way to the helper waves (a ring, see hc)
   // Helper waves (P-frame GOPs: the workgroup is the chain's wave + helpers, see helper_loop): commands go out by bumping
   // `seq` after the arguments are in place, every helper adds 1 to `done` when it has finished the command it saw.
@@ -1727,6 +1728,7 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
   int lastmx = 0, lastmy = 0;
   const u32 rcpn = (u32)((0x100000000ull + (u32)nbx - 1u) / (u32)nbx);
   u32* tile = D.L.tile;
+  u32* ptile = D.L.ptile;
   uint2* jobs = D.L.jobs;
   // Motion-block copies (the source is the previous plane, which this frame never modifies): with helper waves every block
   // is handed over as soon as it is decoded and copied while the chain goes on (see WaveLds::hc); a rect waits for them
@@ -1833,6 +1835,18 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
       }
       border_at = ty * 17 + tx;
     }
+    // The rect's pixels in the previous frame come with the same round trip: a third of the runs of a P-frame copy from
+    // there (type 3), and a load inside each of those runs was an L1/L2 round trip on the chain, a dozen per rect.
+    u32 pv[4];  // (lane = row * 4 + quarter: pixels 4 * quarter .. + 3 of the row)
+    const int prow = lane >> 2, pcol = (lane & 3) * 4;
+    {
+      const u8* pp = prv + (size_t)(y1 + prow) * S + (x1 + pcol) * 3;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        pv[k] = 0;
+        if (prow < h && pcol + k < w) pv[k] = ld3(pp + 3 * k);
+      }
+    }
     bool border_due = true;
     D.template stamp<6>();
     int x = x1, y = y1, pt = 0;
@@ -1868,6 +1882,9 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
         if (border_due) {
           wave_fence();
           if (lane < 33) tile[border_at] = border;
+#pragma unroll
+          for (int k = 0; k < 4; k++)
+            if (prow < h && pcol + k < w) ptile[prow * w + pcol + k] = pv[k];
           wave_fence();
           border_due = false;
         }
@@ -1904,7 +1921,7 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
               const int rs = (ls * rcpw) >> 16;
               v = tile[rs * 17 + (ls - rs * w) + 1];
             } else if (pt == 3) {
-              v = ld3(prv + (size_t)(y1 + row) * S + (x1 + col) * 3);
+              v = ptile[li];
             }
             if (act) tile[(row + 1) * 17 + col + 1] = v;
           }
@@ -1938,7 +1955,7 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
         if (SCPR_UNLIKELY((0x18u >> pt) & 1u)) {
           if (pt == 3) {
             v = px;
-            if (act) v = ld3(prv + (size_t)y * S + (x + lane) * 3);
+            if (act) v = ptile[(y - y1) * w + (x - x1) + lane];
           } else {
             u32 tp = 0, tl = 0;
             if (act) {
