@@ -893,8 +893,8 @@ int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* 
         auto kern = has_p ? k_decode_gop_w<true> : k_decode_gop_w<false>;  // key-frame-only GOPs: smaller kernel (instruction cache)
         HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
         // P-frame GOPs run as a workgroup: the chain's wave + helper waves for the bulk copies (scpr_wave.hpp, helper_loop) -
-        // seven when every GOP has a CU to itself, three when CUs are shared (two waves per SIMD at most: the chain keeps its
-        // 256 registers)
+        // eight waves when every GOP has a CU to itself (six helpers: the wave that would share the chain's SIMD leaves at
+        // once), four when CUs are shared (three helpers; two waves per SIMD at most: the chain keeps its 256 registers)
         const unsigned threads = has_p ? (ng <= 256 ? 512u : 256u) : 64u;
         hipLaunchKernelGGL(kern, dim3((unsigned)ng), dim3(threads), dyn, st, pk, pk_end, c->decframes.as<DecFrame>(), c->decgops.as<DecGop>(), c->planes.as<u8>(), g,
                            c->decstates.as<DecRec>(), ar, c->f0, c->err.as<u32>(), ring, c->decfixed.as<FixedBlob>(), (int)std::min<u32>(c->prm.high_range_x, 256),
