@@ -89,7 +89,10 @@ struct scpr_codec {
   u32 frames_done = 0;  // fn
   bool last_flat = false;
   u32 last_flat_rgb = 0;
-  int slots = 0;  // frames processed per chunk
+  int slots = 0;   // frames per encode chunk (bounded by the per-frame scratch the encoder needs)
+  int dslots = 0;  // frames per decode chunk (the decoder needs planes only: a long stream keeps all its GOPs in flight)
+  size_t plane_slots = 0;  // planes allocated for frames; the previous frame of the stream lives in slot `pslot` == plane_slots
+  int pslot = 0;
   // per-slot worst-case buffers
   DevBuf planes, exitmap, entry, runrec, tilecnt, tileoff, hdrrec, hdrcnt, frametot, tnmap;
   size_t tn_half = 0;
@@ -166,6 +169,57 @@ static void setup_loss(scpr_codec* c, int loss) {  // SetupLossMask, screencap.c
   c->last_loss = loss;
 }
 
+// Planes for the frames of a chunk (slots 0..n-1) and, behind them, the previous frame of the stream (slot pslot): grown when a
+// call needs more, the previous frame carried over - a codec used one frame at a time holds two planes, not a batch's worth.
+static int ensure_planes(scpr_codec* c, size_t n) {
+  if (n <= c->plane_slots && c->planes.p) return SCPR_OK;
+  const Geom& g = c->g;
+  const size_t most = (size_t)std::max(c->slots, c->dslots);
+  const size_t want = std::max(n, std::min(most, 2 * c->plane_slots));
+  void* np = nullptr;
+  HIPCHK(hipMalloc(&np, (want + 1) * (size_t)g.plane_stride));
+  HIPCHK(hipMemsetAsync(np, 0, (want + 1) * (size_t)g.plane_stride, c->stream));  // (row padding stays zero: RGB24 output copies whole rows)
+  if (c->planes.p)
+    HIPCHK(hipMemcpyAsync((u8*)np + want * (size_t)g.plane_stride, c->planes.as<u8>() + c->plane_slots * (size_t)g.plane_stride, g.plane_stride, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->planes.release();
+  c->planes.p = np;
+  c->planes.cap = (want + 1) * (size_t)g.plane_stride;
+  c->plane_slots = want;
+  c->pslot = (int)want;
+  return SCPR_OK;
+}
+// the encoder's per-frame scratch for a chunk of n frames (grow-only; a codec that only decodes never allocates it)
+static int ensure_enc_scratch(scpr_codec* c, size_t n) {
+  const Geom& g = c->g;
+  const size_t ns = n + 1;
+  HIPCHK(c->exitmap.reserve(ns * g.ntiles * 512));
+  c->tn_half = ns * g.ntiles * TILE;  // type | short length per pixel, then (same size, written only where needed) the long lengths
+  HIPCHK(c->tnmap.reserve(c->tn_half * 2));
+  HIPCHK(c->entry.reserve(ns * g.ntiles * 2));
+  HIPCHK(c->runrec.reserve(ns * g.ntiles * TILE * 4));
+  HIPCHK(c->tilecnt.reserve(ns * g.ntiles * 8));
+  HIPCHK(c->tileoff.reserve(ns * g.ntiles * 8));
+  HIPCHK(c->hdrrec.reserve(ns * (g.W + 2) * 4));
+  HIPCHK(c->hdrcnt.reserve(ns * 4));
+  HIPCHK(c->frametot.reserve(ns * 8));
+  HIPCHK(c->flags.reserve(ns * 8));
+  HIPCHK(c->slotlist.reserve(ns * 4));
+  HIPCHK(c->genlist.reserve(ns * 4));
+  HIPCHK(c->bases.reserve(ns * sizeof(FrameBase)));
+  HIPCHK(c->ranges.reserve(ns * sizeof(GenRange)));
+  HIPCHK(c->kinds.reserve(ns * 4));
+  HIPCHK(c->pidx.reserve(ns * 4));
+  HIPCHK(c->fidx.reserve(ns * 4));
+  HIPCHK(c->pframes.reserve(ns * sizeof(PFrame)));
+  HIPCHK(c->pflag.reserve(ns * 4));
+  HIPCHK(c->pinfo.reserve(ns * 8));
+  HIPCHK(c->ptot.reserve(ns * 32));
+  HIPCHK(c->pbase.reserve(ns * sizeof(PBase)));
+  HIPCHK(c->miscranges.reserve(ns * sizeof(MiscRange)));
+  return SCPR_OK;
+}
+
 static int ensure_codec(scpr_codec* c, int version) {  // CreateCodec + CScreenCapt::Init, screencap.cpp:1587-1617, :69-124
   if (c->have_codec) return SCPR_OK;
   if (version < 2 || version > 4) return SCPR_E_BAD_VERSION;  // BadVersionException (:1589-1590); version 2 is decode-only here
@@ -185,40 +239,26 @@ static int ensure_codec(scpr_codec* c, int version) {  // CreateCodec + CScreenC
   if (g.ntiles < 1) g.ntiles = 1;
   g.workers = (int)p.workers;
   g.plane_stride = (u32)(((size_t)g.H * g.S + 16 + 255) & ~(size_t)255);
-  // chunk size: keep the per-slot worst-case buffers within ~24 GiB
+  // encode chunk size: keep the per-slot worst-case buffers within ~24 GiB (they are allocated for the chunks that come: ensure_enc_scratch)
   size_t per_slot = (size_t)g.plane_stride + (size_t)g.ntiles * (512 + 2 + TILE * 6 + 16) + (size_t)(g.W + 2) * 4;
   size_t s = (24ull << 30) / per_slot;
   c->slots = (int)std::min<size_t>(std::max<size_t>(s, 1), 768);  // 768 = three decoder workgroups on each of the 256 CUs
-  const size_t ns = (size_t)c->slots + 1;  // +1: slot `slots` holds the previous frame of the stream
-  HIPCHK(c->planes.reserve(ns * g.plane_stride));
-  HIPCHK(hipMemsetAsync(c->planes.p, 0, ns * g.plane_stride, c->stream));
-  HIPCHK(c->exitmap.reserve(ns * g.ntiles * 512));
-  c->tn_half = ns * g.ntiles * TILE;  // type | short length per pixel, then (same size, written only where needed) the long lengths
-  HIPCHK(c->tnmap.reserve(c->tn_half * 2));
-  HIPCHK(c->entry.reserve(ns * g.ntiles * 2));
-  HIPCHK(c->runrec.reserve(ns * g.ntiles * TILE * 4));
-  HIPCHK(c->tilecnt.reserve(ns * g.ntiles * 8));
-  HIPCHK(c->tileoff.reserve(ns * g.ntiles * 8));
-  HIPCHK(c->hdrrec.reserve(ns * (g.W + 2) * 4));
-  HIPCHK(c->hdrcnt.reserve(ns * 4));
-  HIPCHK(c->frametot.reserve(ns * 8));
-  HIPCHK(c->flags.reserve(ns * 8));
-  HIPCHK(c->slotlist.reserve(ns * 4));
-  HIPCHK(c->genlist.reserve(ns * 4));
-  HIPCHK(c->bases.reserve(ns * sizeof(FrameBase)));
+  // decode chunk size: planes only, up to ~32 GiB of them - what a chunk holds is what runs side by side, and a GOP is one chain
+  c->dslots = (int)std::min<size_t>(std::max<size_t>((32ull << 30) / g.plane_stride, 1), 4096);
+  if (c->planes.p && c->planes.cap >= 2 * (size_t)g.plane_stride) {  // the planes of an earlier Init are kept (Deinit / Init per stream is cheap)
+    c->plane_slots = std::min<size_t>(c->planes.cap / g.plane_stride - 1, (size_t)std::max(c->slots, c->dslots));
+    c->pslot = (int)c->plane_slots;
+    HIPCHK(hipMemsetAsync(c->planes.p, 0, (c->plane_slots + 1) * (size_t)g.plane_stride, c->stream));
+  } else {
+    c->planes.release();
+    c->plane_slots = 0;
+    c->pslot = 0;
+    int rc = ensure_planes(c, 1);
+    if (rc != SCPR_OK) return rc;
+  }
   HIPCHK(c->totals.reserve(64));
-  HIPCHK(c->ranges.reserve(ns * sizeof(GenRange)));
   {
     const size_t nblk = (size_t)((g.W + 15) / 16) * ((g.H + 15) / 16);
-    HIPCHK(c->kinds.reserve(ns * 4));
-    HIPCHK(c->pidx.reserve(ns * 4));
-    HIPCHK(c->fidx.reserve(ns * 4));
-    HIPCHK(c->pframes.reserve(ns * sizeof(PFrame)));
-    HIPCHK(c->pflag.reserve(ns * 4));
-    HIPCHK(c->pinfo.reserve(ns * 8));
-    HIPCHK(c->ptot.reserve(ns * 32));
-    HIPCHK(c->pbase.reserve(ns * sizeof(PBase)));
-    HIPCHK(c->miscranges.reserve(ns * sizeof(MiscRange)));
     HIPCHK(c->mvs.reserve(nblk * 4));
     HIPCHK(hipMemsetAsync(c->mvs.p, 0, nblk * 4, c->stream));  // calloc'd in the reference (screencap.cpp:96-97), never reset
     // two copies of everything the chains keep between calls (see k_fixed_chain: a call with several generations reads one, writes the other)
@@ -282,7 +322,7 @@ static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int n
       lossslots.push_back(i);
     } else if (cf[i].kind == 2) {
       pidx[i] = (int)pfr.size();
-      pfr.push_back({i, i > 0 ? i - 1 : c->slots});
+      pfr.push_back({i, i > 0 ? i - 1 : c->pslot});
       pgen.push_back(cf[i].gen);
       pfidx.push_back(i);
       lossslots.push_back(i);
@@ -585,7 +625,7 @@ int scpr_seed_shard(scpr_codec* c, uint32_t frames_before, int last_was_flat, ui
   if (last_was_flat) {
     c->last_flat_rgb = last_flat_rgb & 0xFFFFFFu;
     const Geom& g = c->g;
-    hipLaunchKernelGGL(k_fill_flat, dim3((g.H * g.S + 255) / 256), dim3(256), 0, c->stream, c->planes.as<u8>(), g, c->slots, c->last_flat_rgb);
+    hipLaunchKernelGGL(k_fill_flat, dim3((g.H * g.S + 255) / 256), dim3(256), 0, c->stream, c->planes.as<u8>(), g, c->pslot, c->last_flat_rgb);
     HIPCHK(hipStreamSynchronize(c->stream));
     c->live_valid = true;       // that flat frame renewed the models ...
     c->live_has_state = false;  // ... and nothing has been coded with them
@@ -610,6 +650,8 @@ int64_t scpr_compress_batch(scpr_codec* c, const void* d_frames, int nframes, in
   HIPCHK(hipMemsetAsync(c->err.p, 0, 32, st));
   for (int f0 = 0; f0 < nframes; f0 += c->slots) {
     const int n = std::min(c->slots, nframes - f0);
+    if ((rc = ensure_planes(c, (size_t)n)) != SCPR_OK) return rc;
+    if ((rc = ensure_enc_scratch(c, (size_t)n)) != SCPR_OK) return rc;
     const u8* src = (const u8*)d_frames + (size_t)f0 * frame_bytes;
     u32* d_nonflat = c->flags.as<u32>();
     u32* d_first = d_nonflat + n;
@@ -688,7 +730,7 @@ int64_t scpr_compress_batch(scpr_codec* c, const void* d_frames, int nframes, in
     rc = encode_chunk(c, n, cf, ngens, load_first, hb, pchanged);
     if (rc != SCPR_OK) return rc;
     // the last plane of the chunk is the "previous frame" of the next call
-    HIPCHK(hipMemcpyAsync(c->planes.as<u8>() + (size_t)c->slots * g.plane_stride, c->planes.as<u8>() + (size_t)(n - 1) * g.plane_stride, g.plane_stride, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(c->planes.as<u8>() + (size_t)c->pslot * g.plane_stride, c->planes.as<u8>() + (size_t)(n - 1) * g.plane_stride, g.plane_stride, hipMemcpyDeviceToDevice, st));
 
     // rANS blocks and packets
     std::vector<RansBlock> blocks;
@@ -786,7 +828,14 @@ int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* 
       if (rc != SCPR_OK) return rc;
     }
     const Geom& g = c->g;
-    const int n = std::min(c->slots, nframes - f0);
+    // a chunk: as many frames as there are planes for, and no more GOPs than the GPU runs side by side (768 chains)
+    int n = 0;
+    for (int keys = 0; f0 + n < nframes && n < c->dslots; n++)
+      if (ftypes[f0 + n] == 0 && ++keys > 768) break;
+    {
+      int rc = ensure_planes(c, (size_t)n);
+      if (rc != SCPR_OK) return rc;
+    }
     // A chunk is decoded with a dense-table arena sized for what streams need in practice; the device reports an
     // overflow (nothing is lost: the run scribbles on table 0, which is never a real table) and the chunk is then
     // decoded again with the worst case (every context of every GOP dense, 12288 tables per GOP).
@@ -805,7 +854,7 @@ int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* 
       if (c->crashed && ftypes[fi] > 0) return done;  // (:1697)
       c->crashed = false;
       c->frames_done++;
-      DecFrame d{offs[fi], sizes[fi], i, 0, i > 0 ? i - 1 : c->slots};
+      DecFrame d{offs[fi], sizes[fi], i, 0, i > 0 ? i - 1 : c->pslot};
       bool new_gop = false;
       if (ftypes[fi]) {  // DecompressP
         d.kind = 2;
@@ -923,7 +972,7 @@ int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* 
     }
     break;
     }
-    HIPCHK(hipMemcpyAsync(c->planes.as<u8>() + (size_t)c->slots * g.plane_stride, c->planes.as<u8>() + (size_t)(n - 1) * g.plane_stride, g.plane_stride, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(c->planes.as<u8>() + (size_t)c->pslot * g.plane_stride, c->planes.as<u8>() + (size_t)(n - 1) * g.plane_stride, g.plane_stride, hipMemcpyDeviceToDevice, st));
     stage_begin(c, ST_UNPACK);
     u8* out = (u8*)d_frames_out + (size_t)f0 * pitch * g.H;
     if (c->bpp == 4) {
