@@ -303,6 +303,7 @@ struct ChunkFrame {
   u32 hdr, hdr_len;
 };
 
+constexpr int kMaxChunkGens = 512;  // generations per encode chunk (see scpr_compress_batch)
 static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int ngens, bool load_first, std::vector<FrameBase>& hb, std::vector<u32>& pchanged) {
   const Geom& g = c->g;
   hipStream_t st = c->stream;
@@ -454,6 +455,19 @@ static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int n
   }
   stage_end(c, ST_SYMBOLS);
 
+  if (getenv("SCPR_DEBUG_KEYS") && Ctot) {  // design aid: every colour key must name a generation of this chunk and a context below NCOLCTX
+    std::vector<u32> hk(Ctot);
+    HIPCHK(hipMemcpyAsync(hk.data(), c->keys[0].p, Ctot * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    size_t bad = 0, first = 0;
+    for (size_t i = 0; i < Ctot; i++)
+      if ((hk[i] >> 22) >= (u32)ngens || ((hk[i] >> 8) & 0x3FFFu) >= (u32)NCOLCTX) {
+        if (!bad) first = i;
+        bad++;
+      }
+    fprintf(stderr, "[scpr debug] chunk n=%d ngens=%d ni=%d np=%d Ctot=%zu bad keys=%zu first=%zu key=%08x\n", n, ngens, ni, np, (size_t)Ctot, bad, first, bad ? hk[first] : 0u);
+    if (bad) return SCPR_E_DEVICE;
+  }
   stage_begin(c, ST_SORT);
   {
     int genbits = 1;
@@ -467,6 +481,26 @@ static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int n
     hipLaunchKernelGGL(k_chain_starts, dim3((unsigned)((Ctot + 256) / 256)), dim3(256), 0, st, c->keys[1].as<u32>(), (u32)Ctot, (u32)nchains, c->cstart.as<u32>());
   }
   stage_end(c, ST_SORT);
+  if (getenv("SCPR_DEBUG_KEYS") && Ctot) {
+    std::vector<u32> hk(Ctot), hc(nchains + 1);
+    HIPCHK(hipMemcpyAsync(hk.data(), c->keys[1].p, Ctot * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(hc.data(), c->cstart.p, (nchains + 1) * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    size_t unsorted = 0, firstu = 0, badc = 0, firstc = 0;
+    for (size_t i = 1; i < Ctot; i++)
+      if ((hk[i] >> 8) < (hk[i - 1] >> 8)) {
+        if (!unsorted) firstu = i;
+        unsorted++;
+      }
+    for (size_t q = 0; q < nchains; q++)
+      if (hc[q + 1] < hc[q] || hc[q + 1] > Ctot) {
+        if (!badc) firstc = q;
+        badc++;
+      }
+    fprintf(stderr, "[scpr debug] sorted: out-of-order keys=%zu (first %zu: %08x after %08x), bad chain starts=%zu (first q=%zu: %u then %u), last=%u\n", unsorted, firstu,
+            unsorted ? hk[firstu] : 0u, unsorted ? hk[firstu - 1] : 0u, badc, firstc, badc ? hc[firstc] : 0u, badc ? hc[firstc + 1] : 0u, hc[nchains]);
+    if (unsorted || badc) return SCPR_E_DEVICE;
+  }
 
   // per-generation ranges of the run list and of the misc list (frames of a generation are consecutive)
   std::vector<GenRange>& rg = c->h_ranges;
@@ -648,8 +682,9 @@ int64_t scpr_compress_batch(scpr_codec* c, const void* d_frames, int nframes, in
   const size_t frame_bytes = (size_t)c->pitch_in * g.H;
   int64_t written = 0;
   HIPCHK(hipMemsetAsync(c->err.p, 0, 32, st));
-  for (int f0 = 0; f0 < nframes; f0 += c->slots) {
-    const int n = std::min(c->slots, nframes - f0);
+  for (int f0 = 0, used = 0; f0 < nframes; f0 += used) {
+    int n = std::min(c->slots, nframes - f0);  // (may shrink below: at most kMaxChunkGens generations per chunk)
+    const int npacked = n;
     if ((rc = ensure_planes(c, (size_t)n)) != SCPR_OK) return rc;
     if ((rc = ensure_enc_scratch(c, (size_t)n)) != SCPR_OK) return rc;
     const u8* src = (const u8*)d_frames + (size_t)f0 * frame_bytes;
@@ -680,7 +715,16 @@ int64_t scpr_compress_batch(scpr_codec* c, const void* d_frames, int nframes, in
     for (int i = 0; i < n; i++) {
       ChunkFrame& fr = cf[i];
       const bool flat = hflags[i] == 0;
-      const u32 rgb = hflags[n + i] & 0xFFFFFFu;
+      const u32 rgb = hflags[npacked + i] & 0xFFFFFFu;
+      // The colour symbols are partitioned by a radix sort over (generation, context): bits 8 .. 22 + log2(generations).
+      // rocPRIM 4.2 (ROCm 7.2) returns UNSORTED output for a bit range that ends at bit 32 when the input has ~10^5 elements
+      // (its merge-sort path: tools/rocprim_sort_check.hip; 10^3 and 2*10^6 elements are fine), so a chunk stops before its
+      // 513th generation and the sort never sees bit 31.
+      const bool starts_gen = flat ? !(c->last_flat && c->last_flat_rgb == rgb) : !(c->frames_done && ftypes[f0 + i]);
+      if (starts_gen && ngens == kMaxChunkGens) {
+        n = i;
+        break;
+      }
       if (flat) {
         fr.kind = 1;
         fr.hdr_len = 4;
@@ -717,6 +761,8 @@ int64_t scpr_compress_batch(scpr_codec* c, const void* d_frames, int nframes, in
       }
       c->frames_done++;
     }
+    cf.resize(n);
+    used = n;
     // a flat frame that renews the models starts a generation of its own; if it is first in the chunk nothing is loaded
     const bool any_gen = ngens > 0;
     if (ngens == 0) ngens = 1, load_first = c->live_valid && c->live_has_state;

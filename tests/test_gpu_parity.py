@@ -456,6 +456,30 @@ def test_batch_longer_than_the_slot_pool():
     assert r == n and torch.equal(out.reshape(n, -1), dev)
 
 
+def test_decode_chunks_cut_inside_a_gop_and_after_768_gops():
+    """The decoder takes up to 4096 frames and up to 768 GOPs per chunk (a chunk's GOPs are what runs side by side).  A stream
+    longer than that is cut wherever the count says - one frame into a GOP here - and the GOP goes on in the next chunk from
+    the state the first left; a stream of 800 key frames is cut after the 768th."""
+    import torch
+    w, h, n, k = 48, 32, 4300, 7
+    seq = DesktopSequence(w, h, seed=77, sparkles=6)
+    frames = np.stack([seq.frame(t % 97) for t in range(n)])
+    keys = [t % k == 0 for t in range(n)]
+    ora = O.OracleCodec(w, h, 32)
+    ref = [ora.compress(f, key=kk) for f, kk in zip(frames, keys)]
+    dev = torch.from_numpy(frames).cuda().reshape(n, -1)
+    pk, sizes, fts = _codec(w, h).CompressBatch(dev, [0 if kk else 1 for kk in keys])
+    assert pk.cpu().numpy().tobytes() == b"".join(p for p, _ in ref) and list(fts) == [ft for _, ft in ref]
+    assert 4096 % k == 1  # the first chunk ends one frame into a GOP
+    r, out = _codec(w, h).DecompressBatch(pk, sizes, fts)
+    assert r == n and torch.equal(out.reshape(n, -1), dev)
+    m = 800
+    pk, sizes, fts = _codec(w, h).CompressBatch(dev[:m], [0] * m)
+    assert pk.cpu().numpy().tobytes() == b"".join(O.OracleCodec(w, h, 32).compress(f, key=True)[0] for f in frames[:m])
+    r, out = _codec(w, h).DecompressBatch(pk, sizes, fts)
+    assert r == m and torch.equal(out.reshape(m, -1), dev[:m])
+
+
 @pytest.mark.parametrize("bpp,w,h,seed", [(24, 100, 37, 1), (24, 96, 64, 2), (16, 100, 37, 3), (16, 98, 50, 4), (24, 33, 50, 5), (16, 34, 40, 6)])
 def test_random_streams_rgb24_and_rgb16(bpp, w, h, seed):
     """The other two input formats (rows padded to 4 bytes) through random key / P / repeated / flat frames and
