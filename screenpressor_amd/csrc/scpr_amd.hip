@@ -98,7 +98,7 @@ struct scpr_codec {
   size_t tn_half = 0;
   // per-batch buffers
   DevBuf flags, slotlist, genlist, bases, totals, runs, runpos, keys[2], vals[2], cstart, sorttmp, entries, ranges;
-  DevBuf rblocks, rscratch, rsize, packets, pktoff, blkdst, outsizes, total64, arena, arena_top, err, rcp;
+  DevBuf rblocks, rscratch, rsize, packets, pktoff, blkdst, outsizes, total64, arena, arena2, arena_top, err, rcp;  // (arena2: where compact_tables moves the live tables)
   DevBuf decframes, decstates, hoststage_in, hoststage_out, chainlists, chaincounts;
   // P-frame buffers
   DevBuf mvdict, mvpre, gmask;
@@ -112,7 +112,7 @@ struct scpr_codec {
   size_t arena_used_bound = 0;  // dense tables held by the live generation (the arena top read back after every call)
   size_t live_symbols = 0;      // colour symbols coded so far in the live generation (a bound on the tables it can own)
   // decoder side of the same
-  DevBuf decgops, decfixed, dec_fixed_persist, dec_colour_persist, dec_arena, dec_arena_top;  // (its own dense-table arena: one codec may compress and decompress)
+  DevBuf decgops, decfixed, dec_fixed_persist, dec_colour_persist, dec_arena, dec_arena2, dec_arena_top;  // (its own dense-table arena: one codec may compress and decompress)
   bool dec_live = false;
   u32 h_dec_top0 = 1;
   size_t dec_arena_used = 1;  // tables held by the live GOP of the decoder (table 0 is the sink of an overflowing run, never a real table)
@@ -303,6 +303,20 @@ struct ChunkFrame {
   u32 hdr, hdr_len;
 };
 
+// The tables of the records in `recs` to the bottom of the other arena (k_compact_tables); `first` = the index the first
+// one gets (the decoder keeps table 0 out of use).  Returns the new top through *top.
+static int compact_tables(scpr_codec* c, DevBuf& arena, DevBuf& other, DevBuf& topbuf, void* recs, int words, int stamp_word, u32 stamp, u32 first, size_t old_top, u32* top) {
+  hipStream_t st = c->stream;
+  const size_t most = std::min<size_t>(old_top, (size_t)NCOLCTX + first) + 64;
+  HIPCHK(other.reserve(most * sizeof(DenseTab)));
+  HIPCHK(hipMemcpyAsync(topbuf.p, &first, 4, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_compact_tables, dim3(NCOLCTX), dim3(64), 0, st, (u32*)recs, words, (int)NCOLCTX, stamp_word, stamp, arena.as<DenseTab>(), other.as<DenseTab>(), topbuf.as<u32>());
+  HIPCHK(hipMemcpyAsync(top, topbuf.p, 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));  // (`first` and `top` are the caller's)
+  std::swap(arena.p, other.p);
+  std::swap(arena.cap, other.cap);
+  return SCPR_OK;
+}
 constexpr int kMaxChunkGens = 512;  // generations per encode chunk (see scpr_compress_batch)
 static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int ngens, bool load_first, std::vector<FrameBase>& hb, std::vector<u32>& pchanged) {
   const Geom& g = c->g;
@@ -431,7 +445,8 @@ static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int n
   // generation, not over this call: a context may meet its 16th symbol here after 15 in earlier calls.  So the tables
   // alive at the end of this call are at most (symbols of the live generation so far + this call's) / 16, and 12288 per generation.
   c->live_symbols += Ctot;
-  const size_t arena_cap = std::max(c->arena_used_bound, std::min<size_t>((size_t)ngens * NCOLCTX, c->live_symbols / 16 + (size_t)ngens)) + 64;
+  // (the arena holds the live generation's tables and nothing else when a call starts: compact_tables after every call with several)
+  const size_t arena_cap = std::min<size_t>((size_t)ngens * NCOLCTX, c->arena_used_bound + c->live_symbols / 16 + (size_t)ngens) + 64;
   HIPCHK(c->arena.reserve_keep(arena_cap * sizeof(DenseTab), c->arena_used_bound * sizeof(DenseTab), st));
   if (ngens > 1) c->live_symbols = Ctot;  // (an upper bound for the generation that is live after this call)
   c->dbg_entries = (int64_t)Ttot;
@@ -631,7 +646,7 @@ void scpr_destroy(scpr_codec* c) {
   DevBuf* all[] = {&c->planes, &c->tnmap, &c->exitmap, &c->entry, &c->runrec, &c->tilecnt, &c->tileoff, &c->hdrrec, &c->hdrcnt, &c->frametot, &c->flags, &c->slotlist, &c->genlist,
                    &c->bases, &c->totals, &c->runs, &c->runpos, &c->keys[0], &c->keys[1], &c->vals[0], &c->vals[1], &c->cstart, &c->sorttmp,
                    &c->entries, &c->ranges, &c->rblocks, &c->rscratch, &c->rsize, &c->packets, &c->pktoff, &c->blkdst, &c->outsizes, &c->total64, &c->arena,
-                   &c->arena_top, &c->err, &c->rcp, &c->decframes, &c->decstates, &c->hoststage_in, &c->hoststage_out, &c->chainlists, &c->chaincounts, &c->kinds, &c->pidx, &c->fidx, &c->pframes, &c->pflag, &c->binfo, &c->smv, &c->btype, &c->bmv, &c->bcnt, &c->boff, &c->bflag, &c->pinfo, &c->ptot, &c->pbase, &c->misc, &c->miscpos, &c->miscranges, &c->mvs, &c->fixed_persist, &c->misc_persist, &c->colour_persist, &c->decgops, &c->decfixed, &c->dec_fixed_persist, &c->dec_colour_persist, &c->dec_arena, &c->dec_arena_top, &c->mvdict, &c->mvpre, &c->gmask};
+                   &c->arena_top, &c->err, &c->rcp, &c->decframes, &c->decstates, &c->hoststage_in, &c->hoststage_out, &c->chainlists, &c->chaincounts, &c->kinds, &c->pidx, &c->fidx, &c->pframes, &c->pflag, &c->binfo, &c->smv, &c->btype, &c->bmv, &c->bcnt, &c->boff, &c->bflag, &c->pinfo, &c->ptot, &c->pbase, &c->misc, &c->miscpos, &c->miscranges, &c->mvs, &c->fixed_persist, &c->misc_persist, &c->colour_persist, &c->decgops, &c->decfixed, &c->dec_fixed_persist, &c->dec_colour_persist, &c->dec_arena, &c->dec_arena2, &c->arena2, &c->dec_arena_top, &c->mvdict, &c->mvpre, &c->gmask};
   for (DevBuf* b : all) b->release();
   for (int s = 0; s < ST_COUNT + 1; s++)
     for (int k = 0; k < 2; k++) (void)hipEventDestroy(c->ev[s][k]);
@@ -842,6 +857,13 @@ int64_t scpr_compress_batch(scpr_codec* c, const void* d_frames, int nframes, in
       fprintf(stderr, "[scpr] motion-vector pipeline stalled\n");
       return SCPR_E_DEVICE;
     }
+    if (ngens > 1 && atop > 0) {  // only the last generation's tables are needed again: to the bottom, the rest is dropped
+      u32 ntop = 0;
+      rc = compact_tables(c, c->arena, c->arena2, c->arena_top, c->colour_persist.as<ColState>() + (size_t)c->live_buf * NCOLCTX, (int)(sizeof(ColState) / 4), 3, c->live_stamp, 0u, atop,
+                          &ntop);
+      if (rc != SCPR_OK) return rc;
+      c->arena_used_bound = ntop;
+    }
     written += (int64_t)chunk_total;
   }
   return written;
@@ -950,7 +972,8 @@ int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* 
       const size_t worst = v2 ? 0 : std::min<size_t>(ng * (size_t)NCOLCTX, (size_t)((c->dec_live_bytes + gop_bytes) / 12) + 8 * ng);
       // (a chunk that continues a GOP is not decoded twice: its run changes the tables that GOP already owns)
       const size_t budget = (attempt || cont) ? worst : std::min<size_t>(worst, ng * 1024);
-      const size_t arena_cap = std::max<size_t>(c->dec_arena_used, 1 + budget) + 64;
+      // (the arena holds table 0 and the live GOP's tables when a chunk starts: compact_tables after every chunk with several GOPs)
+      const size_t arena_cap = std::min<size_t>(1 + ng * (size_t)NCOLCTX, c->dec_arena_used + budget) + 64;
       HIPCHK(c->dec_arena.reserve_keep(arena_cap * sizeof(DenseTab), c->dec_arena_used * sizeof(DenseTab), st));
       c->h_dec_top0 = (u32)c->dec_arena_used;  // (a member: the source of an asynchronous copy must outlive the call)
       HIPCHK(hipMemcpyAsync(c->dec_arena_top.p, &c->h_dec_top0, 4, hipMemcpyHostToDevice, st));
@@ -1015,6 +1038,12 @@ int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* 
       c->dec_arena_used = std::max<size_t>(atop, 1);
       c->dec_live_bytes = ng > 1 ? gop_bytes : c->dec_live_bytes + gop_bytes;  // (an upper bound for the GOP that is live after this chunk)
       c->dec_live = true;
+      if (ng > 1 && !v2 && atop > 1) {  // only the last GOP's tables are needed again: to the bottom (behind table 0), the rest is dropped
+        u32 ntop = 1;
+        int rc = compact_tables(c, c->dec_arena, c->dec_arena2, c->dec_arena_top, c->dec_colour_persist.p, DECREC_WORDS, -1, 0u, 1u, atop, &ntop);
+        if (rc != SCPR_OK) return rc;
+        c->dec_arena_used = std::max<size_t>(ntop, 1);
+      }
     }
     break;
     }

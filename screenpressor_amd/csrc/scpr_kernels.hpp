@@ -808,6 +808,29 @@ struct Arena {
   u32* err;
 };
 // (the chains themselves are in scpr_wave.hpp: one wave per chain, WaveModel)
+// After a call that ran several generations only the last one's tables are needed again, and they sit anywhere below the
+// arena's top among the tables of the generations that ended: the live records' tables move to the bottom of a second
+// arena, in record order, and the records get the new indices.  One wave per record (word 0: kind in the low byte - 6 and 7
+// are the kinds with a table -, word 2: table index; stamp_word >= 0: only records that carry `stamp` there are live).
+__global__ __launch_bounds__(64) void k_compact_tables(u32* __restrict__ recs, int words, int nrec, int stamp_word, u32 stamp, const DenseTab* __restrict__ src, DenseTab* __restrict__ dst,
+                                                       u32* __restrict__ counter) {
+  const int r = blockIdx.x, lane = threadIdx.x;
+  if (r >= nrec) return;
+  u32* rec = recs + (size_t)r * words;
+  const u32 kind = rec[0] & 255u;
+  if (kind != 6u && kind != 7u) return;
+  if (stamp_word >= 0 && rec[stamp_word] != stamp) return;
+  u32 idx = 0;
+  if (lane == 0) idx = atomicAdd(counter, 1u);
+  idx = (u32)__builtin_amdgcn_readfirstlane((int)idx);
+  const u32* s = (const u32*)&src[rec[2]];
+  u32* d = (u32*)&dst[idx];
+  static_assert(sizeof(DenseTab) == 64 * 6 * 4, "one table is six words per lane");
+#pragma unroll
+  for (int k = 0; k < 6; k++) d[k * 64 + lane] = s[k * 64 + lane];
+  __builtin_amdgcn_s_waitcnt(0);
+  if (lane == 0) rec[2] = idx;
+}
 
 // ------------------------------------------------------------------ rANS ---
 struct RansBlock {

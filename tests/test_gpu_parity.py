@@ -456,6 +456,32 @@ def test_batch_longer_than_the_slot_pool():
     assert r == n and torch.equal(out.reshape(n, -1), dev)
 
 
+def test_batches_that_never_start_on_a_key_frame_with_contexts_that_go_dense():
+    """Streaming use of the batch API: ten frames per call, a key frame every thirty - never the first of a call - and
+    noise in all three channels, so that thousands of contexts get a dense table in every GOP.  After a call with two
+    generations only the second one's tables are needed again; they used to stay wherever they were among the first one's,
+    the arena's top crept up by a GOP's worth per key frame, and the fourth call ended in "dense-table arena overflow" (both
+    directions).  The live tables are now moved to the bottom after such a call (compact_tables)."""
+    import torch
+    w, h, k, nb, bs = 96, 64, 30, 16, 10
+    rng = np.random.default_rng(3)
+    enc, dec = _codec(w, h), _codec(w, h)
+    ora = O.OracleCodec(w, h, 32)
+    t = 0
+    for b in range(nb):
+        frames = np.full((bs, h, w, 4), 255, np.uint8)
+        frames[..., :3] = rng.integers(0, 256, (bs, h, w, 3))
+        keys = [(t + i) % k == 5 or (t + i) == 0 for i in range(bs)]
+        dev = torch.from_numpy(frames).cuda().reshape(bs, -1)
+        pk, sizes, fts = enc.CompressBatch(dev, [0 if kk else 1 for kk in keys])
+        assert pk.cpu().numpy().tobytes() == b"".join(ora.compress(f, key=kk)[0] for f, kk in zip(frames, keys)), b
+        r, out = dec.DecompressBatch(pk, sizes, fts)
+        assert r == bs and torch.equal(out.reshape(bs, -1), dev), b
+        t += bs
+    ea, da = enc.debug_arena()[0], dec.debug_arena()[1]
+    assert ea < 3 * 12288 * 1536 * 1.6 and da < 3 * 12288 * 1536 * 1.6, (ea, da)  # two generations' worth (and the allocator's slack), whatever the number of calls
+
+
 def test_decode_chunks_cut_inside_a_gop_and_after_768_gops():
     """The decoder takes up to 4096 frames and up to 768 GOPs per chunk (a chunk's GOPs are what runs side by side).  A stream
     longer than that is cut wherever the count says - one frame into a GOP here - and the GOP goes on in the next chunk from
