@@ -456,6 +456,35 @@ def test_batch_longer_than_the_slot_pool():
     assert r == n and torch.equal(out.reshape(n, -1), dev)
 
 
+def test_one_codec_object_through_deinit_and_init_with_other_geometries():
+    """ScreenCodec::Deinit / Init on the same object (screencap.cpp:1565-1629): the device buffers of the earlier geometry
+    are kept and reused (planes, scratch), the stream state is not - every stream equals the oracle's from its first frame."""
+    import torch
+    from screenpressor_amd.codec import ScreenCodec
+    enc, dec = ScreenCodec(0), ScreenCodec(0)
+    for w, h, n, seed in [(320, 240, 12, 1), (64, 48, 30, 2), (640, 360, 6, 3), (33, 21, 9, 4), (320, 240, 5, 5)]:
+        enc.Init(w, h, 32)
+        dec.Init(w, h, 32)
+        seq = DesktopSequence(w, h, seed=seed, sparkles=15)
+        frames = np.stack([seq.frame(t) for t in range(n)])
+        keys = [t == 0 or t == n // 2 for t in range(n)]
+        ora = O.OracleCodec(w, h, 32)
+        ref = [ora.compress(f, key=k) for f, k in zip(frames, keys)]
+        dev = torch.from_numpy(frames).cuda().reshape(n, -1)
+        pk, sizes, fts = enc.CompressBatch(dev[:n - 2], [0 if k else 1 for k in keys[:n - 2]])
+        got = pk.cpu().numpy().tobytes()
+        for t in (n - 2, n - 1):  # and the per-frame entry points on the same stream
+            d, ft = enc.CompressFrame(frames[t], 0 if keys[t] else 1)
+            got += d
+            assert ft == ref[t][1]
+        assert got == b"".join(p for p, _ in ref), (w, h)
+        allpk = torch.from_numpy(np.frombuffer(got, np.uint8).copy()).cuda()
+        r, out = dec.DecompressBatch(allpk, [len(p) for p, _ in ref], [ft for _, ft in ref])
+        assert r == n and torch.equal(out.reshape(n, -1), dev), (w, h)
+        enc.Deinit()
+        dec.Deinit()
+
+
 def test_batches_that_never_start_on_a_key_frame_with_contexts_that_go_dense():
     """Streaming use of the batch API: ten frames per call, a key frame every thirty - never the first of a call - and
     noise in all three channels, so that thousands of contexts get a dense table in every GOP.  After a call with two

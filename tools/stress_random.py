@@ -1,0 +1,65 @@
+"""Design tool (GPU box): random geometry, content, key-frame positions and call sizes through the batch entry points -
+packets against the oracle per call, decode of every call by a second codec.  `python tools/stress_random.py [cases] [seed0]`."""
+import sys, os, time
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import numpy as np, torch
+import oracle_api as O
+from screenpressor_amd.codec import ScreenCodec
+from screenpressor_amd.synth import DesktopSequence
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+bad = 0
+t0 = time.time()
+for case in range(seed0, seed0 + cases):
+    rng = np.random.default_rng(1000 + case)
+    w, h = int(rng.integers(17, 200)), int(rng.integers(9, 120))
+    n = int(rng.integers(40, 260))
+    kprob = float(rng.choice([0.0, 0.01, 0.05, 0.2, 0.6]))
+    style = int(rng.integers(0, 5))
+    seq = DesktopSequence(w, h, seed=case, sparkles=int(rng.integers(0, 60)))
+    frames = np.empty((n, h, w, 4), np.uint8)
+    for t in range(n):
+        if style == 0: f = seq.frame(t)
+        elif style == 1: f = seq.frame(t // 3)                                   # repeated frames
+        elif style == 2:                                                        # noise in all channels (contexts go dense)
+            f = np.full((h, w, 4), 255, np.uint8); f[..., :3] = rng.integers(0, 256, (h, w, 3))
+        elif style == 3:                                                        # desktop with noisy patches and flat frames
+            f = seq.frame(t).copy()
+            if rng.random() < 0.3:
+                y0, x0 = int(rng.integers(0, max(1, h - 8))), int(rng.integers(0, max(1, w - 8)))
+                f[y0:y0 + 24, x0:x0 + 40, :3] = rng.integers(0, 256, f[y0:y0 + 24, x0:x0 + 40, :3].shape)
+            if rng.random() < 0.1: f[..., :3] = rng.integers(0, 256, 3) if rng.random() < 0.5 else f[0, 0, :3]
+        else:                                                                   # scrolling texture
+            if t == 0: tex = rng.integers(0, 256, (h + 3 * n + 8, w, 3), dtype=np.uint8)
+            f = np.full((h, w, 4), 255, np.uint8); f[..., :3] = tex[3 * t:3 * t + h]
+        frames[t] = f
+    keys = [t == 0 or rng.random() < kprob for t in range(n)]
+    workers = int(rng.choice([1, 1, 2, 3])) if h >= 12 else 1
+    loss = int(rng.choice([0, 0, 0, 1, 2, 3]))
+    enc, dec, ora = ScreenCodec(0).Init(w, h, 32, loss=loss, workers=workers), ScreenCodec(0).Init(w, h, 32, loss=loss), O.OracleCodec(w, h, 32, loss=loss, workers=workers)
+    lossy = loss != 0
+    t = 0
+    ok = True
+    while t < n and ok:
+        m = int(min(n - t, rng.choice([1, 2, 5, 10, 33, 100])))
+        dev = torch.from_numpy(frames[t:t + m]).cuda().reshape(m, -1)
+        try:
+            pk, sizes, fts = enc.CompressBatch(dev, [0 if k else 1 for k in keys[t:t + m]])
+            ref = [ora.compress(f, key=k) for f, k in zip(frames[t:t + m], keys[t:t + m])]
+            if pk.cpu().numpy().tobytes() != b"".join(p for p, _ in ref) or list(fts) != [ft for _, ft in ref]:
+                print("case", case, (w, h, n, style, kprob, workers, loss), "ENCODE differs in call at frame", t, "size", m, flush=True); ok = False; break
+            r, out = dec.DecompressBatch(pk, sizes, fts)
+            if lossy:  # the decoded frames are what the oracle's decoder gives for the same packets
+                if not hasattr(ora, "_d"): ora._d = O.OracleCodec(w, h, 32, loss=loss)
+                want = np.stack([ora._d.decompress(p, ft)[1].reshape(h, w, 4) for p, ft in ref])
+                same = r == m and np.array_equal(out.cpu().numpy().reshape(m, h, w, 4)[..., :3], want[..., :3])
+            else:
+                same = r == m and torch.equal(out.reshape(m, -1), dev)
+            if not same:
+                print("case", case, (w, h, n, style, kprob, workers, loss), "DECODE differs in call at frame", t, "size", m, flush=True); ok = False; break
+        except Exception as e:  # noqa: BLE001
+            print("case", case, (w, h, n, style, kprob, workers, loss), "ERROR at frame", t, "size", m, repr(e), flush=True); ok = False; break
+        t += m
+    bad += not ok
+    if case % 5 == 4: print("...", case + 1 - seed0, "cases,", bad, "bad, %.0f s" % (time.time() - t0), flush=True)
+print("BAD %d" % bad if bad else "ALL OK (%d cases)" % cases)
