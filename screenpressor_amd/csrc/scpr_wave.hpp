@@ -1757,7 +1757,7 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
     bm &= bm - 1;
     const int b = gbase + bj;
     const int t = (int)rdl(tb, bj);
-    const int by = (int)__umulhi((u32)b, rcpn), bx = b - by * nbx;  // == b / nbx (b < 2^18, nbx <= 512: the rounding error stays below one)
+    const int by = nbx == 1 ? b : (int)__umulhi((u32)b, rcpn), bx = b - by * nbx;  // == b / nbx (b < 2^18, 2 <= nbx <= 512: the rounding error stays below one; the reciprocal of 1 does not fit 32 bits)
     int x1 = bx * 16, y1 = by * 16, x2 = min(x1 + 16, W), y2 = min(y1 + 16, H);
     if ((t - 1) & 1) {  // changed rect inside the block (:1333-1346)
       D.tick();

@@ -456,6 +456,33 @@ def test_batch_longer_than_the_slot_pool():
     assert r == n and torch.equal(out.reshape(n, -1), dev)
 
 
+@pytest.mark.parametrize("w,h,n", [(8000, 6, 5), (4099, 33, 4), (3, 2, 12), (3, 80, 8), (5, 701, 5), (16, 40, 8), (17, 17, 8), (1023, 2, 6), (1025, 4, 6)])
+def test_extreme_frame_shapes(w, h, n):
+    """The documented limits (W >= 3, H >= 2, W <= 8000) and the shapes in between that change the structure of the work: one
+    column of 16x16 blocks (a block's row is its number), one row of blocks, a 1024-pixel tile that spans hundreds of rows, a
+    row that spans several tiles.  Key and P-frames, batch and per-frame calls, against the oracle; its packets decoded."""
+    import torch
+    rng = np.random.default_rng(w * 31 + h)
+    seq = DesktopSequence(w, h, seed=w + h, sparkles=min(40, w * h // 50))
+    frames = np.stack([seq.frame(t) for t in range(n)])
+    for t in range(1, n, 2):  # some noise: every predictor type, literal runs, changed rects inside blocks
+        m = rng.random((h, w)) < 0.15
+        frames[t][m, :3] = rng.integers(0, 256, (int(m.sum()), 3))
+    keys = [t == 0 or t == n - 2 for t in range(n)]
+    enc, dec, ora = _codec(w, h), _codec(w, h), O.OracleCodec(w, h, 32)
+    ref = [ora.compress(f, key=k) for f, k in zip(frames, keys)]
+    half = n // 2
+    dev = torch.from_numpy(frames).cuda().reshape(n, -1)
+    pk, sizes, fts = enc.CompressBatch(dev[:half], [0 if k else 1 for k in keys[:half]])
+    got = pk.cpu().numpy().tobytes()
+    for t in range(half, n):
+        got += enc.CompressFrame(frames[t], 0 if keys[t] else 1)[0]
+    assert got == b"".join(p for p, _ in ref)
+    allpk = torch.from_numpy(np.frombuffer(got, np.uint8).copy()).cuda()
+    r, out = dec.DecompressBatch(allpk, [len(p) for p, _ in ref], [ft for _, ft in ref])
+    assert r == n and torch.equal(out.reshape(n, -1), dev)
+
+
 def test_one_codec_object_through_deinit_and_init_with_other_geometries():
     """ScreenCodec::Deinit / Init on the same object (screencap.cpp:1565-1629): the device buffers of the earlier geometry
     are kept and reused (planes, scratch), the stream state is not - every stream equals the oracle's from its first frame."""
