@@ -412,7 +412,7 @@ static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int n
                          c->mvpre.as<u32>(), mp, c->mvs.as<u32>(), c->btype.as<u8>(), c->bmv.as<u32>(), c->pinfo.as<int>(), c->gmask.as<unsigned long long>(), use_lds);
     }
     hipLaunchKernelGGL(k_pcount, dim3((nblocks + 63) / 64, np), dim3(64), 0, st, planes, g, c->pframes.as<PFrame>(), c->binfo.as<u32>(), c->btype.as<u8>(), c->bcnt.as<u32>());
-    hipLaunchKernelGGL(k_pscan, dim3((np + 63) / 64), dim3(64), 0, st, g, np, c->btype.as<u8>(), c->bmv.as<u32>(), c->bcnt.as<u32>(), c->pinfo.as<int>(), c->boff.as<BOff>(),
+    hipLaunchKernelGGL(k_pscan, dim3(np), dim3(64), 0, st, g, np, c->btype.as<u8>(), c->bmv.as<u32>(), c->bcnt.as<u32>(), c->pinfo.as<int>(), c->boff.as<BOff>(),
                        c->bflag.as<u32>(), c->ptot.as<u32>());
     stage_end(c, ST_INTER);
   }
