@@ -32,11 +32,16 @@ using namespace scpr;
 
 namespace {
 
+static bool debug_alloc() {  // SCPR_DEBUG_ALLOC=1: every device allocation is reported (design aid: a steady state must have none)
+  static const bool on = getenv("SCPR_DEBUG_ALLOC") != nullptr;
+  return on;
+}
 struct DevBuf {  // grow-only device allocation
   void* p = nullptr;
   size_t cap = 0;
   hipError_t reserve(size_t bytes) {
     if (bytes <= cap) return hipSuccess;
+    if (debug_alloc()) fprintf(stderr, "[scpr alloc] reserve %zu (had %zu)\n", bytes, cap);
     if (p) (void)hipFree(p);
     p = nullptr;
     cap = 0;
@@ -47,6 +52,7 @@ struct DevBuf {  // grow-only device allocation
   }
   hipError_t reserve_keep(size_t bytes, size_t keep, hipStream_t st) {  // grow, preserving the first `keep` bytes
     if (bytes <= cap) return hipSuccess;
+    if (debug_alloc()) fprintf(stderr, "[scpr alloc] reserve_keep %zu (had %zu, keeps %zu)\n", bytes, cap, keep);
     void* np = nullptr;
     size_t want = bytes + bytes / 2 + 4096;
     hipError_t e = hipMalloc(&np, want);
@@ -303,8 +309,8 @@ struct ChunkFrame {
   u32 hdr, hdr_len;
 };
 
-// The tables of the records in `recs` to the bottom of the other arena (k_compact_tables); `first` = the index the first
-// one gets (the decoder keeps table 0 out of use).  Returns the new top through *top.
+// The tables of the records in `recs` to the bottom of the arena, by way of a second buffer (k_compact_tables); `first` = the
+// index the first one gets (the decoder keeps table 0 out of use).  Returns the new top through *top.
 static int compact_tables(scpr_codec* c, DevBuf& arena, DevBuf& other, DevBuf& topbuf, void* recs, int words, int stamp_word, u32 stamp, u32 first, size_t old_top, u32* top) {
   hipStream_t st = c->stream;
   const size_t most = std::min<size_t>(old_top, (size_t)NCOLCTX + first) + 64;
@@ -313,8 +319,9 @@ static int compact_tables(scpr_codec* c, DevBuf& arena, DevBuf& other, DevBuf& t
   hipLaunchKernelGGL(k_compact_tables, dim3(NCOLCTX), dim3(64), 0, st, (u32*)recs, words, (int)NCOLCTX, stamp_word, stamp, arena.as<DenseTab>(), other.as<DenseTab>(), topbuf.as<u32>());
   HIPCHK(hipMemcpyAsync(top, topbuf.p, 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));  // (`first` and `top` are the caller's)
-  std::swap(arena.p, other.p);
-  std::swap(arena.cap, other.cap);
+  // ... and back to the bottom of the arena itself (at most 19 MB; swapping the buffers instead would leave the small one as
+  // the arena and make the next call allocate gigabytes again)
+  if (*top > first) HIPCHK(hipMemcpyAsync(arena.as<DenseTab>() + first, other.as<DenseTab>() + first, (size_t)(*top - first) * sizeof(DenseTab), hipMemcpyDeviceToDevice, st));
   return SCPR_OK;
 }
 constexpr int kMaxChunkGens = 512;  // generations per encode chunk (see scpr_compress_batch)
