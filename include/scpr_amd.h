@@ -30,7 +30,7 @@ typedef struct scpr_params {
     uint32_t bits_per_pixel;              /* 16, 24 or 32 */
     uint32_t red_mask, green_mask, blue_mask; /* RGB16 only, e.g. 0x7C00,0x3E0,0x1F */
     uint32_t high_range_x, high_range_y;  /* motion search, far window (256,256) */
-    uint32_t low_range_x, low_range_y;    /* near window (8,8) */
+    uint32_t low_range_x, low_range_y;    /* near window (8,8); at most min(high_range, 256): beyond that the reference writes motion symbols below zero */
     uint32_t loss;                        /* 0..5 bits dropped per channel */
     uint32_t workers;                     /* >= 1 */
 } scpr_params;

@@ -232,6 +232,9 @@ static int ensure_codec(scpr_codec* c, int version) {  // CreateCodec + CScreenC
   const scpr_params& p = c->prm;
   if (p.bits_per_pixel != 16 && p.bits_per_pixel != 24 && p.bits_per_pixel != 32) return SCPR_E_BAD_VERSION;
   if (p.width < 3 || p.height < 2 || p.width > 8000 || p.workers < 1 || p.height < 2 * p.workers) return SCPR_E_PARAM;
+  // a near window wider than the far one makes the reference code motion symbols below zero (mv + msr_x with |mv| up to msrlow_x,
+  // screencap.cpp:691-704, :1206): outside the format
+  if (p.low_range_x > std::min<u32>(p.high_range_x, 256) || p.low_range_y > std::min<u32>(p.high_range_y, 256)) return SCPR_E_PARAM;
   if (version == 2 && (p.high_range_x > 256 || p.high_range_y > 256 || !p.high_range_x || !p.high_range_y)) return SCPR_E_PARAM;  // its motion tables hold 2 * range symbols (LDS: 512)
   c->version = version;
   c->f0 = version == 3 ? 64 : 32;

@@ -16,8 +16,8 @@ class SpoParams(C.Structure):
         "high_range_x", "high_range_y", "low_range_x", "low_range_y", "loss", "workers", "version")]
 
 
-def make_params(w, h, bpp=32, loss=0, workers=1, version=4, masks=(0x7C00, 0x3E0, 0x1F)):
-    return SpoParams(w, h, bpp, masks[0], masks[1], masks[2], 256, 256, 8, 8, loss, workers, version)
+def make_params(w, h, bpp=32, loss=0, workers=1, version=4, masks=(0x7C00, 0x3E0, 0x1F), high_range=(256, 256), low_range=(8, 8)):
+    return SpoParams(w, h, bpp, masks[0], masks[1], masks[2], high_range[0], high_range[1], low_range[0], low_range[1], loss, workers, version)
 
 
 _lib = None
@@ -65,9 +65,9 @@ def _ptr(a):
 class OracleCodec:
     """Mirror of ScreenCodec (screencap.h:519-541) over the CPU restatement."""
 
-    def __init__(self, w, h, bpp=32, loss=0, workers=1, version=4):
+    def __init__(self, w, h, bpp=32, loss=0, workers=1, version=4, high_range=(256, 256), low_range=(8, 8)):
         self.w, self.h, self.bpp, self.loss = w, h, bpp, loss
-        self.params = make_params(w, h, bpp, loss, workers, version)
+        self.params = make_params(w, h, bpp, loss, workers, version, high_range=high_range, low_range=low_range)
         self.h_ = lib().spo_create(C.byref(self.params))
         self.cap = w * h * 6 + 64
         self.pitch = w * 4 if bpp == 32 else ((w * (bpp // 8) + 3) & ~3)

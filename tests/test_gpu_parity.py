@@ -483,6 +483,34 @@ def test_extreme_frame_shapes(w, h, n):
     assert r == n and torch.equal(out.reshape(n, -1), dev)
 
 
+@pytest.mark.parametrize("hr,lr", [((64, 40), (8, 8)), ((17, 9), (3, 5)), ((300, 1000), (20, 16)), ((256, 256), (0, 0))])
+def test_motion_search_ranges_other_than_the_drivers(hr, lr):
+    """CodecParameters carries the motion search windows (screencap.cpp:76-81; the VfW driver always passes 256 / 8).  The far
+    window sets the offset of the motion symbols, the near one is searched first: scrolling content against the oracle."""
+    import torch
+    w, h, n = 160, 96, 10
+    rng = np.random.default_rng(hr[0] + lr[0])
+    tex = rng.integers(0, 256, (h + 40 * n, w + 40 * n, 3), dtype=np.uint8)
+    frames = np.full((n, h, w, 4), 255, np.uint8)
+    for t in range(n):
+        dx, dy = (3 * t) % 37, (11 * t) % 29  # small and large steps
+        frames[t, ..., :3] = tex[dy:dy + h, dx:dx + w]
+    ora = O.OracleCodec(w, h, 32, high_range=hr, low_range=lr)
+    ref = [ora.compress(f, key=(t == 0)) for t, f in enumerate(frames)]
+    enc = _codec(w, h, high_range=hr, low_range=lr)
+    dev = torch.from_numpy(frames).cuda().reshape(n, -1)
+    pk, sizes, fts = enc.CompressBatch(dev, [0] + [1] * (n - 1))
+    assert pk.cpu().numpy().tobytes() == b"".join(p for p, _ in ref)
+    r, out = _codec(w, h, high_range=hr, low_range=lr).DecompressBatch(pk, sizes, fts)
+    assert r == n and torch.equal(out.reshape(n, -1), dev)
+
+
+def test_a_near_window_wider_than_the_far_one_is_refused():
+    enc = _codec(64, 48, high_range=(17, 256), low_range=(20, 8))
+    with pytest.raises(RuntimeError):
+        enc.CompressFrame(np.zeros((48, 64, 4), np.uint8), 0)
+
+
 def test_one_codec_object_through_deinit_and_init_with_other_geometries():
     """ScreenCodec::Deinit / Init on the same object (screencap.cpp:1565-1629): the device buffers of the earlier geometry
     are kept and reused (planes, scratch), the stream state is not - every stream equals the oracle's from its first frame."""

@@ -36,7 +36,11 @@ for case in range(seed0, seed0 + cases):
     keys = [t == 0 or rng.random() < kprob for t in range(n)]
     workers = int(rng.choice([1, 1, 2, 3])) if h >= 12 else 1
     loss = int(rng.choice([0, 0, 0, 1, 2, 3]))
-    enc, dec, ora = ScreenCodec(0).Init(w, h, 32, loss=loss, workers=workers), ScreenCodec(0).Init(w, h, 32, loss=loss), O.OracleCodec(w, h, 32, loss=loss, workers=workers)
+    hr = (int(rng.choice([256, 256, 64, 17, 300])), int(rng.choice([256, 256, 40, 9, 1000])))  # motion search ranges (screencap.cpp:76-81)
+    lr = (int(rng.choice([8, 8, 0, 3, 20])), int(rng.choice([8, 8, 0, 5, 16])))
+    lr = (min(lr[0], hr[0], 256), min(lr[1], hr[1], 256))  # (a near window wider than the far one is outside the format)
+    enc, dec = ScreenCodec(0).Init(w, h, 32, loss=loss, workers=workers, high_range=hr, low_range=lr), ScreenCodec(0).Init(w, h, 32, loss=loss, high_range=hr, low_range=lr)
+    ora = O.OracleCodec(w, h, 32, loss=loss, workers=workers, high_range=hr, low_range=lr)
     lossy = loss != 0
     t = 0
     ok = True
@@ -47,18 +51,18 @@ for case in range(seed0, seed0 + cases):
             pk, sizes, fts = enc.CompressBatch(dev, [0 if k else 1 for k in keys[t:t + m]])
             ref = [ora.compress(f, key=k) for f, k in zip(frames[t:t + m], keys[t:t + m])]
             if pk.cpu().numpy().tobytes() != b"".join(p for p, _ in ref) or list(fts) != [ft for _, ft in ref]:
-                print("case", case, (w, h, n, style, kprob, workers, loss), "ENCODE differs in call at frame", t, "size", m, flush=True); ok = False; break
+                print("case", case, (w, h, n, style, kprob, workers, loss, hr, lr), "ENCODE differs in call at frame", t, "size", m, flush=True); ok = False; break
             r, out = dec.DecompressBatch(pk, sizes, fts)
             if lossy:  # the decoded frames are what the oracle's decoder gives for the same packets
-                if not hasattr(ora, "_d"): ora._d = O.OracleCodec(w, h, 32, loss=loss)
+                if not hasattr(ora, "_d"): ora._d = O.OracleCodec(w, h, 32, loss=loss, high_range=hr, low_range=lr)
                 want = np.stack([ora._d.decompress(p, ft)[1].reshape(h, w, 4) for p, ft in ref])
                 same = r == m and np.array_equal(out.cpu().numpy().reshape(m, h, w, 4)[..., :3], want[..., :3])
             else:
                 same = r == m and torch.equal(out.reshape(m, -1), dev)
             if not same:
-                print("case", case, (w, h, n, style, kprob, workers, loss), "DECODE differs in call at frame", t, "size", m, flush=True); ok = False; break
+                print("case", case, (w, h, n, style, kprob, workers, loss, hr, lr), "DECODE differs in call at frame", t, "size", m, flush=True); ok = False; break
         except Exception as e:  # noqa: BLE001
-            print("case", case, (w, h, n, style, kprob, workers, loss), "ERROR at frame", t, "size", m, repr(e), flush=True); ok = False; break
+            print("case", case, (w, h, n, style, kprob, workers, loss, hr, lr), "ERROR at frame", t, "size", m, repr(e), flush=True); ok = False; break
         t += m
     bad += not ok
     if case % 5 == 4: print("...", case + 1 - seed0, "cases,", bad, "bad, %.0f s" % (time.time() - t0), flush=True)
