@@ -1849,12 +1849,13 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
     }
     bool border_due = true;
     D.template stamp<6>();
-    int x = x1, y = y1, pt = 0;
+    int li = 0, pt = 0;  // position in the rect, row-major (the rect is w * h <= 256 pixels)
+    const int lend = w * h;
     const int lc = min(lane, 15);
     const int rcpw = (int)kRcp16[w];  // ceil(65536 / w): (li * rcpw) >> 16 == li / w for li <= 256, w <= 16
     // One run of the rect, in two instances like the key-frame loop: the careful one tests for the end of the coder
     // block after every symbol, the fast one is entered while the block cannot end within a run and counts the
-    // run's symbols in one go.  A refused stream ends the rect (y = y2) instead of leaving the loops from inside.
+    // run's symbols in one go.  A refused stream ends the rect (li = lend) instead of leaving the loops from inside.
     auto prun = [&](auto fast_tag) __attribute__((always_inline)) {
       constexpr bool FAST = decltype(fast_tag)::value;
       const int last_t = pt;
@@ -1893,7 +1894,7 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
       if (SCPR_UNLIKELY(rem < 1)) {
         D.bad = true;
         rem = 0;
-        y = y2;
+        li = lend;
       }
       // Literal (0), left (1), above (2) and previous frame (3): no pixel of the run depends on another pixel of the run that
       // is not a plain copy of it, so the whole run is one pass - lane i takes the run's i-th pixel wherever the rect's rows
@@ -1901,12 +1902,12 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
       // below; "above" of a pixel further than a rect row into the run is another pixel of the run, and through it the pixel
       // above run pixel i mod w.  (Above-left and the gradient go row by row in the loop below.)
       if (SCPR_LIKELY(!((0x30 >> pt) & 1)) && rem > 0) {
-        const int li0 = (y - y1) * w + (x - x1);  // position in the rect, row-major
-        if (SCPR_UNLIKELY(li0 + rem > w * h)) {  // the run goes on below the rect
+        const int li0 = li;
+        if (SCPR_UNLIKELY(li0 + rem > lend)) {  // the run goes on below the rect
           D.bad = true;
-          y = y2;
+          li = lend;
         } else {
-          const int row0 = y - y1, col0 = x - x1;
+          const int row0 = (li0 * rcpw) >> 16, col0 = li0 - row0 * w;
           u32 v = px;
           for (int b = 0; b < rem; b += 64) {
             const int i = min(b + lane, rem - 1);
@@ -1927,19 +1928,18 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
           }
           wave_fence();
           lastpix = rdl(v, (rem - 1) & 63) & 0xFFFFFFu;
-          const int le = li0 + rem, re = (le * rcpw) >> 16;
-          y = y1 + re;
-          x = x1 + (le - re * w);
+          li = li0 + rem;
         }
         rem = 0;
       }
       while (rem > 0) {
-        if (SCPR_UNLIKELY(y >= y2)) {  // the run goes on below the rect
+        if (SCPR_UNLIKELY(li >= lend)) {  // the run goes on below the rect
           D.bad = true;
           break;
         }
-        const int seg = min(rem, x2 - x);  // pixels of this run on the current rect row (<= 16)
-        const int ty = y - y1 + 1, tx0 = x - x1 + 1;
+        const int rrow = (li * rcpw) >> 16, rcol = li - rrow * w;
+        const int seg = min(rem, w - rcol);  // pixels of this run on the current rect row (<= 16)
+        const int ty = rrow + 1, tx0 = rcol + 1;
         const bool act = lane < seg;
         const int tx = tx0 + lane;
         wave_fence();
@@ -1955,7 +1955,7 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
         if (SCPR_UNLIKELY((0x18u >> pt) & 1u)) {
           if (pt == 3) {
             v = px;
-            if (act) v = ptile[(y - y1) * w + (x - x1) + lane];
+            if (act) v = ptile[li + lane];
           } else {
             u32 tp = 0, tl = 0;
             if (act) {
@@ -1975,18 +1975,14 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
         wave_fence();
         lastpix = rdl(v, seg - 1) & 0xFFFFFFu;
         rem -= seg;
-        x += seg;
-        if (x == x2) {
-          x = x1;
-          y++;
-        }
+        li += seg;
       }
-      if (SCPR_UNLIKELY(D.bad)) y = y2;
+      if (SCPR_UNLIKELY(D.bad)) li = lend;
     };
-    while (y < y2) {
+    while (li < lend) {
       D.tick();
       prun(std::false_type{});
-      while (SCPR_LIKELY((int)((u32)(y - y2) & (u32)(D.ndec - (kBlockEntries - 5))) < 0)) prun(std::true_type{});
+      while (SCPR_LIKELY((int)((u32)(li - lend) & (u32)(D.ndec - (kBlockEntries - 5))) < 0)) prun(std::true_type{});
     }
     D.template stamp<7>();
     wave_fence();
