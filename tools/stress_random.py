@@ -12,8 +12,12 @@ bad = 0
 t0 = time.time()
 for case in range(seed0, seed0 + cases):
     rng = np.random.default_rng(1000 + case)
-    w, h = int(rng.integers(17, 200)), int(rng.integers(9, 120))
-    n = int(rng.integers(40, 260))
+    if os.environ.get("BIG"):  # desktop-sized frames, shorter streams
+        w, h = int(rng.integers(300, 2100)), int(rng.integers(200, 1200))
+        n = int(rng.integers(6, 30))
+    else:
+        w, h = int(rng.integers(17, 200)), int(rng.integers(9, 120))
+        n = int(rng.integers(40, 260))
     kprob = float(rng.choice([0.0, 0.01, 0.05, 0.2, 0.6]))
     style = int(rng.integers(0, 5))
     seq = DesktopSequence(w, h, seed=case, sparkles=int(rng.integers(0, 60)))
