@@ -969,6 +969,25 @@ int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* 
       HIPCHK(c->dec_colour_persist.reserve(state_bytes));
       if (!v2) HIPCHK(hipMemsetAsync(c->decstates.p, 0, ng * state_bytes, st));  // kind 0 everywhere (RenewI)
       const bool cont = gops[0].load != 0;
+      if (cont && !v2 && getenv("SCPR_DEBUG_KEYS")) {  // design aid: every table index of the kept records lies inside the kept part of the arena
+        std::vector<u32> hr((size_t)NCOLCTX * DECREC_WORDS);
+        HIPCHK(hipMemcpyAsync(hr.data(), c->dec_colour_persist.p, hr.size() * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        size_t bad = 0, dense = 0, firstbad = 0;
+        for (size_t r = 0; r < (size_t)NCOLCTX; r++) {
+          const u32 kind = hr[r * DECREC_WORDS] & 255u;
+          if (kind == 6 || kind == 7) {
+            dense++;
+            if (hr[r * DECREC_WORDS + 2] == 0 || hr[r * DECREC_WORDS + 2] >= c->dec_arena_used) {
+              if (!bad) firstbad = r;
+              bad++;
+            }
+          }
+        }
+        fprintf(stderr, "[scpr debug] continuing GOP: %zu dense records, arena used %zu, bad indices %zu (first record %zu: kind %u index %u)\n", dense, c->dec_arena_used, bad, firstbad,
+                bad ? hr[firstbad * DECREC_WORDS] & 255u : 0u, bad ? hr[firstbad * DECREC_WORDS + 2] : 0u);
+        if (bad) return SCPR_E_DEVICE;
+      }
       if (cont) {  // the first GOP continues the state kept from the previous call
         HIPCHK(hipMemcpyAsync(c->decstates.p, c->dec_colour_persist.p, state_bytes, hipMemcpyDeviceToDevice, st));
         HIPCHK(hipMemcpyAsync(c->decfixed.p, c->dec_fixed_persist.p, blob_bytes, hipMemcpyDeviceToDevice, st));
@@ -1035,6 +1054,8 @@ int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* 
     if (ng) HIPCHK(hipMemcpyAsync(&atop, c->dec_arena_top.p, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));  // also covers fr / gops (host memory)
     HIPCHK(hipGetLastError());         // a kernel that could not be launched
+    if (errv[0] & 16) fprintf(stderr, "[scpr] decoder: a colour record named a dense table outside the arena (flags %u, attempt %d, %zu GOPs, continued %d)\n", errv[0], attempt, ng,
+                              ng ? gops[0].load : 0);
     if ((errv[0] & 1) && attempt == 0 && !(ng && gops[0].load)) continue;  // the arena was too small for this stream: once more with the worst case
     if (ng && !(errv[0] & 5)) {
       // keep the state of the last GOP for the next call; with one GOP in the chunk its tables stay where they are
@@ -1075,8 +1096,8 @@ int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* 
     HIPCHK(hipGetLastError());
     timing_collect(c);
     const u32 err = errv[0];
+    if (err & (1 | 16)) return SCPR_E_DEVICE;  // (an overflow of the arena in a chunk that could not be decoded again also sets 4)
     if (err & 4) return SCPR_E_STREAM;
-    if (err & 1) return SCPR_E_DEVICE;
     done += n;
     f0 += n;
   }

@@ -56,6 +56,7 @@ struct WaveDecV2 {
   u32* gtabs;                // [NCOLCTX][V2_COLTAB] colour counts of this GOP
   int mx2, my2;              // alphabets of the two motion tables
   bool bad = false;
+  static constexpr bool oom = false;  // (no dense-table arena in the version 2 models)
 
   __device__ __forceinline__ WaveDecV2(V2Lds& l, const u8* e, u32* tabs, int mx2_, int my2_) : lane(lane_id()), L(l), src_end(e), gtabs(tabs), mx2(mx2_), my2(my2_) {}
   __device__ __forceinline__ void tick() {}

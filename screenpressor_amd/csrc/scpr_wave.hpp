@@ -171,6 +171,7 @@ __device__ __forceinline__ void tab_st(u16* arr, int lane, u32x2 v) {
 }
 
 struct WaveModel {
+  bool oom = false;  // the dense-table arena has overflowed (alloc_dense)
   const int lane;
   const int l15;  // lane & 15: a small table is kept in every row of 16 lanes alike (so that it can be stored without a lane mask)
   u16* tmp;  // 256 x u16 LDS scratch
@@ -204,6 +205,11 @@ struct WaveModel {
 #ifdef SCPR_PROFILE
       dmiss++;
 #endif
+      if (SCPR_UNLIKELY(idx >= arena.cap)) {  // never a real table (a record that is not what it says): reported, not followed
+        if (lane == 0) atomicOr(arena.err, 16u);
+        oom = true;
+        return c;
+      }
       if (tag) copy_tab<false>(arena.tabs + (tag - 1u), c, lane);
       if (!fresh) copy_tab<true>(c, arena.tabs + idx, lane);
       if (lane == 0) dtag[slot] = idx + 1u;
@@ -317,10 +323,18 @@ struct WaveModel {
       idx = atomicAdd(arena.top, 1u);
       if (idx >= arena.cap) {
         atomicOr(arena.err, 1u);
-        idx = 0;
+        idx = 0x80000000u;
       }
     }
-    return rfl(idx);
+    idx = rfl(idx);
+    // From here on contexts share table 0 and overwrite each other's contents: whatever is decoded is thrown away (the host runs
+    // the chunk again with a larger arena), but it must stay harmless - a symbol looked up in such a table is kept inside 0..255
+    // (dense_hit / dense_impl), and the GOP's remaining frames are skipped.
+    if (SCPR_UNLIKELY(idx >> 31)) {
+      oom = true;
+      idx = 0;
+    }
+    return idx;
   }
   // this lane's 4 bits of the 256-bit set stored in r[4..11]
   __device__ __forceinline__ u32 set_bits4(const u32* r) { return (r[4 + (lane >> 3)] >> ((lane & 7) * 4)) & 15u; }
@@ -630,7 +644,7 @@ struct WaveModel {
             if (!((bits >> q) & 1u)) cn[q] = base;
           tab_st<LDS>(t->cnt, lane, u32x2{(u32)cn[0] | ((u32)cn[1] << 16), (u32)cn[2] | ((u32)cn[3] << 16)});
           h.kind = 7;
-          return j;
+          return DEC ? (j & 255) : j;
         }
         if (lane == own) {  // placeSymbol, :621-638
           nbits |= 1u << kk;
@@ -671,7 +685,7 @@ struct WaveModel {
     } else if (lane == own) {
       tab_st<LDS>(t->cnt, lane, u32x2{(u32)cn[0] | ((u32)cn[1] << 16), (u32)cn[2] | ((u32)cn[3] << 16)});
     }
-    return j;
+    return DEC ? (j & 255) : j;  // (a table that other contexts have scribbled on after an arena overflow may match no lane: own = -1)
   }
 };
 
@@ -1235,7 +1249,7 @@ struct WaveDec : WaveModel {
     if (SCPR_LIKELY(tst < 0)) {
       ocf = (cw >> sh16) & 0xFFFFu;
       ofr = (fw >> sh16) & 0xFFFFu;
-      c = j;
+      c = j & 255;  // (see dense_impl)
       const u32 inc = (u32)step << sh16;
       const bool mine = lane == own;
       cq.x += (mine && kk < 2) ? inc : 0u;
@@ -1421,6 +1435,7 @@ __device__ __forceinline__ void decode_intra_frame(DEC& D, const Geom& g, u8* __
         b = a;
         a = c >> 2;
       }
+      if (SCPR_UNLIKELY(D.oom)) lim = p;  // the arena is full (alloc_dense): this run ends the frame, nothing more is decoded
       D.template stamp<1>();
     }
     int n;
@@ -1875,6 +1890,7 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
           bb = a;
           a = c >> 2;
         }
+        if (SCPR_UNLIKELY(D.oom)) D.bad = true;  // the arena is full (alloc_dense): this run ends the frame, nothing more is decoded
       }
       D.template stamp<1>();
       int rem = D.template fixed_n<!FAST>(pt);
@@ -2034,7 +2050,7 @@ __global__ __launch_bounds__(HAS_P ? 512 : 64) void k_decode_gop_w(const u8* __r
   }
   if (gop.load) D.fixed_load(&fixedstore[blockIdx.x]);
   else D.fixed_init();
-  for (int fi = gop.first; fi < gop.first + gop.count && !D.bad; fi++) {
+  for (int fi = gop.first; fi < gop.first + gop.count && !D.bad && !D.oom; fi++) {
     const DecFrame fr = frames[fi];
     u8* dst = planes + (size_t)fr.slot * g.plane_stride;
     if (fr.kind == 0) {

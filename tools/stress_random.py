@@ -50,6 +50,7 @@ for case in range(seed0, seed0 + cases):
     ok = True
     while t < n and ok:
         m = int(min(n - t, rng.choice([1, 2, 5, 10, 33, 100])))
+        if os.environ.get("VERBOSE"): print("  case", case, "call at frame", t, "size", m, file=sys.stderr, flush=True)
         dev = torch.from_numpy(frames[t:t + m]).cuda().reshape(m, -1)
         try:
             pk, sizes, fts = enc.CompressBatch(dev, [0 if k else 1 for k in keys[t:t + m]])
