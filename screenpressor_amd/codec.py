@@ -154,7 +154,9 @@ class ScreenCodec:
         n = frames.shape[0]
         assert frames.is_cuda and frames.dtype == torch.uint8 and frames.is_contiguous() and frames.numel() == n * self.frame_bytes
         if out is None:
-            out = torch.empty(min(n * self.max_packet, max(64 << 20, n * self.frame_bytes // 2)), dtype=torch.uint8, device=frames.device)
+            # room for incompressible pictures (a literal pixel costs a little over three bytes): a batch that does not fit ends in
+            # SCPR_E_CAPACITY after the models have moved on, so the default is the safe size; pass `out` to reuse a smaller buffer
+            out = torch.empty(min(n * self.max_packet, max(64 << 20, n * (self.width * self.height * 4 + 1024))), dtype=torch.uint8, device=frames.device)
         ft = (C.c_int * n)(*[int(x) for x in ftypes])
         sizes = (C.c_uint32 * n)()
         torch.cuda.synchronize(frames.device)
