@@ -1435,7 +1435,6 @@ __device__ __forceinline__ void decode_intra_frame(DEC& D, const Geom& g, u8* __
         b = a;
         a = c >> 2;
       }
-      if (SCPR_UNLIKELY(D.oom)) lim = p;  // the arena is full (alloc_dense): this run ends the frame, nothing more is decoded
       D.template stamp<1>();
     }
     int n;
@@ -1444,6 +1443,9 @@ __device__ __forceinline__ void decode_intra_frame(DEC& D, const Geom& g, u8* __
       D.ndec += t == 0 ? 5 : 2;  // the symbols of this run (type, three colour bytes of a literal, length)
     } else {
       n = D.fixed_n(t);
+      // (the careful instance runs once per row: the place to notice that the arena is full - alloc_dense -, at most a row late:
+      // this run then ends the frame and nothing more is decoded; a test in the fast instance costs 2.5 % of the decoder)
+      if (SCPR_UNLIKELY(D.oom)) lim = p;
     }
     D.template stamp<2>();
     // an empty run, or one longer than what is left (of the header row), ends the frame like the type that does not exist
@@ -1890,12 +1892,12 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
           bb = a;
           a = c >> 2;
         }
-        if (SCPR_UNLIKELY(D.oom)) D.bad = true;  // the arena is full (alloc_dense): this run ends the frame, nothing more is decoded
       }
       D.template stamp<1>();
       int rem = D.template fixed_n<!FAST>(pt);
       D.template stamp<2>();
       if constexpr (!FAST) {  // (a rect always starts in this instance)
+        if (SCPR_UNLIKELY(D.oom)) D.bad = true;  // the arena is full (alloc_dense): nothing more is decoded, at most a rect late
         if (border_due) {
           wave_fence();
           if (lane < 33) tile[border_at] = border;
