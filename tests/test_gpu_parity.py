@@ -511,6 +511,40 @@ def test_a_near_window_wider_than_the_far_one_is_refused():
         enc.CompressFrame(np.zeros((48, 64, 4), np.uint8), 0)
 
 
+def test_two_streams_interleaved_on_their_own_codecs():
+    """Two streams of different geometry, their calls taken in turn (per-frame and small batches): a codec object owns every
+    piece of state - models, arenas, planes, the stream it launches on - so neither stream sees the other."""
+    import torch
+    specs = [(320, 240, 21, 11), (100, 37, 26, 12)]
+    st = []
+    for w, h, n, seed in specs:
+        seq = DesktopSequence(w, h, seed=seed, sparkles=25)
+        frames = np.stack([seq.frame(t) for t in range(n)])
+        keys = [t % 9 == 0 for t in range(n)]
+        ora = O.OracleCodec(w, h, 32)
+        ref = [ora.compress(f, key=k) for f, k in zip(frames, keys)]
+        st.append(dict(w=w, h=h, n=n, frames=frames, keys=keys, ref=ref, enc=_codec(w, h), dec=_codec(w, h), t=0, got=[]))
+    rng = np.random.default_rng(5)
+    while any(s["t"] < s["n"] for s in st):
+        s = st[int(rng.integers(0, 2))]
+        if s["t"] >= s["n"]:
+            continue
+        m = int(min(s["n"] - s["t"], rng.choice([1, 1, 3, 4])))
+        a, b = s["t"], s["t"] + m
+        if m == 1:
+            d, ft = s["enc"].CompressFrame(s["frames"][a], 0 if s["keys"][a] else 1)
+            assert (d, ft) == s["ref"][a]
+            r, out = s["dec"].DecompressFrame(d, ft)
+            assert r == 1 and np.array_equal(out.reshape(s["h"], s["w"], 4), s["frames"][a])
+        else:
+            dev = torch.from_numpy(s["frames"][a:b]).cuda().reshape(m, -1)
+            pk, sizes, fts = s["enc"].CompressBatch(dev, [0 if k else 1 for k in s["keys"][a:b]])
+            assert pk.cpu().numpy().tobytes() == b"".join(p for p, _ in s["ref"][a:b])
+            r, out = s["dec"].DecompressBatch(pk, sizes, fts)
+            assert r == m and torch.equal(out.reshape(m, -1), dev)
+        s["t"] = b
+
+
 def test_one_codec_object_through_deinit_and_init_with_other_geometries():
     """ScreenCodec::Deinit / Init on the same object (screencap.cpp:1565-1629): the device buffers of the earlier geometry
     are kept and reused (planes, scratch), the stream state is not - every stream equals the oracle's from its first frame."""
