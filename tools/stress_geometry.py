@@ -8,7 +8,15 @@ from screenpressor_amd.codec import ScreenCodec
 from screenpressor_amd.synth import DesktopSequence
 shapes = [(8000, 6, 8), (7999, 17, 6), (4099, 33, 6), (3, 2, 20), (3, 700, 10), (5, 3001, 6), (16, 16, 30), (17, 1, 0), (4, 2, 12), (1023, 2, 10), (1024, 3, 10),
           (1025, 4, 10), (2048, 2048, 3), (509, 1021, 4), (31, 33, 40), (15, 15, 40), (8000, 64, 3), (6000, 300, 3)]
-if len(sys.argv) > 1:  # w,h,n triples on the command line instead
+if len(sys.argv) > 1 and sys.argv[1] == "random":  # random extreme shapes: `random [count] [seed]`
+    r0 = np.random.default_rng(int(sys.argv[3]) if len(sys.argv) > 3 else 0)
+    shapes = []
+    for _ in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
+        k = int(r0.integers(0, 3))
+        if k == 0: shapes.append((int(r0.integers(3, 40)), int(r0.integers(100, 3000)), int(r0.integers(3, 10))))
+        elif k == 1: shapes.append((int(r0.integers(2000, 8001)), int(r0.integers(2, 40)), int(r0.integers(3, 10))))
+        else: shapes.append((int(r0.integers(3, 70)), int(r0.integers(2, 70)), int(r0.integers(5, 40))))
+elif len(sys.argv) > 1:  # w,h,n triples on the command line instead
     shapes = [tuple(int(x) for x in a.split(',')) for a in sys.argv[1:]]
 bad = 0
 for case, (w, h, n) in enumerate(shapes):
