@@ -511,6 +511,30 @@ def test_a_near_window_wider_than_the_far_one_is_refused():
         enc.CompressFrame(np.zeros((48, 64, 4), np.uint8), 0)
 
 
+def test_first_decode_attempt_overflows_its_arena_in_recycled_memory():
+    """A chunk is decoded with a small dense-table arena first and again with the worst case when that overflows (noise in all
+    channels: thousands of contexts go dense in one GOP).  After the overflow the first attempt used to decode on with
+    contexts sharing table 0, a state in which a record could name a table that does not exist - harmless in freshly mapped
+    (zero) memory, a wild address in memory that had held pictures.  The decoder now stops at the overflow."""
+    import torch
+    w, h, n = 400, 300, 5
+    rng = np.random.default_rng(12)
+    frames = np.full((n, h, w, 4), 255, np.uint8)
+    frames[..., :3] = rng.integers(0, 256, (n, h, w, 3))
+    ora = O.OracleCodec(w, h, 32)
+    ref = [ora.compress(f, key=(t == 0)) for t, f in enumerate(frames)]
+    junk = torch.full((768 << 20,), 0x5A, dtype=torch.uint8, device="cuda")  # what the allocator hands out next is not zero
+    del junk
+    torch.cuda.empty_cache()
+    dev = torch.from_numpy(frames).cuda().reshape(n, -1)
+    pk, sizes, fts = _codec(w, h).CompressBatch(dev, [0] + [1] * (n - 1))
+    assert pk.cpu().numpy().tobytes() == b"".join(p for p, _ in ref)
+    dec = _codec(w, h)
+    r, out = dec.DecompressBatch(pk, sizes, fts)
+    assert r == n and torch.equal(out.reshape(n, -1), dev)
+    assert dec.debug_arena()[1] > 1024 * 1536  # (the second attempt's arena: the first one's 1024 tables were not enough)
+
+
 def test_two_streams_interleaved_on_their_own_codecs():
     """Two streams of different geometry, their calls taken in turn (per-frame and small batches): a codec object owns every
     piece of state - models, arenas, planes, the stream it launches on - so neither stream sees the other."""
