@@ -14,8 +14,12 @@ for case in range(seed0, seed0 + cases):
     rng = np.random.default_rng(5000 + case)
     bpp = int(rng.choice([24, 16, 32]))
     version = int(rng.choice([4, 4, 3, 2]))
-    w, h = int(rng.integers(3, 150)), int(rng.integers(2, 100))
-    n = int(rng.integers(6, 60))
+    if os.environ.get("BIG"):
+        w, h = int(rng.integers(300, 2000)), int(rng.integers(200, 1100))
+        n = int(rng.integers(4, 14))
+    else:
+        w, h = int(rng.integers(3, 150)), int(rng.integers(2, 100))
+        n = int(rng.integers(6, 60))
     seq = DesktopSequence(w, h, seed=case, sparkles=int(rng.integers(0, 40)))
     pitch = w * 4 if bpp == 32 else (w * (bpp // 8) + 3) & ~3
     in_pitch = w * 2 if bpp == 16 else pitch
