@@ -552,7 +552,7 @@ static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int n
   // and write disjoint coder entries: they run side by side on two streams and join before the coder.
   const int buf_in = c->live_buf, buf_out = ngens > 1 ? 1 - c->live_buf : c->live_buf;
   {
-    hipStream_t s2 = c->stream2;
+    hipStream_t s2 = getenv("SCPR_SERIAL_CHAINS") ? st : c->stream2;  // (design aid: the two chain stages one after the other, to time each alone)
     HIPCHK(hipEventRecord(c->ev_fork, st));
     HIPCHK(hipStreamWaitEvent(s2, c->ev_fork, 0));
     stage_begin(c, ST_FIXED, s2);
