@@ -375,18 +375,51 @@ def run_rank(args):
         flag = torch.tensor([ready], device=dev, dtype=torch.int32)
         all_reduce(flag, dist.ReduceOp.MIN)
         if int(flag.item()) == 1:
-            m4 = measure(r4, wl4, f4, 1, 1, barrier, (wl4.lo, False, 0) if wl4.lo else None, exchange)
-            t4 = torch.tensor([m4["elapsed"]], device=dev, dtype=torch.float64)
-            all_reduce(t4, dist.ReduceOp.MAX)
-            pix4 = wl4.total_frames * wl4.w * wl4.h / 1e6
-            c4 = {"config": "configs[3]: ONE 3840x2160 stream, 1200 frames, key frame every 150, GOP-sharded over the ranks (strong scaling), packets gathered on rank 0 in the step",
-                  "workload": wl4.name, "scaling": "strong", "frames_total": wl4.total_frames, "frames_rank0": wl4.n, "gops_rank0": sum(1 for f in wl4.ftypes if f == 0),
-                  "value_MPix_s": round(pix4 / float(t4.item()), 2), "ms_per_step": round(float(t4.item()) * 1e3, 1),
-                  "enc_MPix_s_rank0": round(wl4.n * wl4.w * wl4.h / 1e6 / m4["t_enc"], 1), "dec_MPix_s_rank0": round(wl4.n * wl4.w * wl4.h / 1e6 / m4["t_dec"], 1),
-                  "lossless_roundtrip": True,
-                  "gathered_frames_rank0": int(gathered["s"].numel()) if gathered.get("s") is not None else None,
-                  "note": "a GOP is one serial chain (one wave): 8 GOPs run side by side on ONE GPU already, so this stream gains nothing from more GPUs - "
-                          "GPU count pays when the stream has more GOPs than one GPU has chain slots (768 at 1080p), see DESIGN.md 7"}
+            # No collective inside a try: whatever happens on one rank, every rank reaches the same collectives in the same
+            # order (a rank that skipped one would leave the others waiting, and the headline line would be lost with it).
+            seed4 = (wl4.lo, False, 0) if wl4.lo else None
+
+            def one_pass():
+                out, sizes, _, dec, a, b, _ = r4.step(f4, wl4.ftypes, seed4, None)
+                assert bool(torch.equal(dec.reshape(wl4.n, -1), f4)), "the decoded frames differ from the input"
+                return out, sizes, a, b
+
+            def all_ok(ok):
+                t = torch.tensor([1 if ok else 0], device=dev, dtype=torch.int32)
+                all_reduce(t, dist.ReduceOp.MIN)
+                return int(t.item()) == 1
+
+            err4 = None
+            try:
+                one_pass()  # warm-up
+            except Exception as e:  # noqa: BLE001
+                err4 = repr(e)
+            if all_ok(err4 is None):
+                barrier()
+                t0 = time.perf_counter()
+                res = None
+                try:
+                    res = one_pass()
+                except Exception as e:  # noqa: BLE001
+                    err4 = repr(e)
+                good = all_ok(res is not None)
+                if good:
+                    exchange(res[0], res[1])  # (all ranks, all fine: the gather is part of the step)
+                barrier()
+                t4 = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+                all_reduce(t4, dist.ReduceOp.MAX)
+                if good:
+                    pix4 = wl4.total_frames * wl4.w * wl4.h / 1e6
+                    c4 = {"config": "configs[3]: ONE 3840x2160 stream, 1200 frames, key frame every 150, GOP-sharded over the ranks (strong scaling), packets gathered on rank 0 in the step",
+                          "workload": wl4.name, "scaling": "strong", "frames_total": wl4.total_frames, "frames_rank0": wl4.n, "gops_rank0": sum(1 for f in wl4.ftypes if f == 0),
+                          "value_MPix_s": round(pix4 / float(t4.item()), 2), "ms_per_step": round(float(t4.item()) * 1e3, 1),
+                          "enc_MPix_s_rank0": round(wl4.n * wl4.w * wl4.h / 1e6 / res[2], 1), "dec_MPix_s_rank0": round(wl4.n * wl4.w * wl4.h / 1e6 / res[3], 1),
+                          "lossless_roundtrip": True,
+                          "gathered_frames_rank0": int(gathered["s"].numel()) if gathered.get("s") is not None else None,
+                          "note": "a GOP is one serial chain (one wave): 8 GOPs run side by side on ONE GPU already, so this stream gains nothing from more GPUs - "
+                                  "GPU count pays when the stream has more GOPs than one GPU has chain slots (768 at 1080p), see DESIGN.md 7"}
+            if c4 is None:
+                c4 = {"config": wl4.name, "error": err4 or "the pass failed on another rank"}
         elif c4 is None:
             c4 = {"config": wl4.name, "error": "another rank could not set the workload up"}
         del f4, r4
