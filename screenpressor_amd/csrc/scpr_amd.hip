@@ -1054,9 +1054,11 @@ int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* 
     if (ng) HIPCHK(hipMemcpyAsync(&atop, c->dec_arena_top.p, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));  // also covers fr / gops (host memory)
     HIPCHK(hipGetLastError());         // a kernel that could not be launched
+    if ((errv[0] & 1) && attempt == 0 && !(ng && gops[0].load)) continue;  // the arena was too small for this stream: once more with the worst case
+    // (bit 16 - a record named a table outside the arena, refused by the table cache - has only been seen in such a first
+    // attempt, in the row that is still decoded after the overflow; anywhere else it is an error of its own)
     if (errv[0] & 16) fprintf(stderr, "[scpr] decoder: a colour record named a dense table outside the arena (flags %u, attempt %d, %zu GOPs, continued %d)\n", errv[0], attempt, ng,
                               ng ? gops[0].load : 0);
-    if ((errv[0] & 1) && attempt == 0 && !(ng && gops[0].load)) continue;  // the arena was too small for this stream: once more with the worst case
     if (ng && !(errv[0] & 5)) {
       // keep the state of the last GOP for the next call; with one GOP in the chunk its tables stay where they are
       // (top read back: the arena does not grow with the number of calls), with several the next call's first
