@@ -1303,6 +1303,14 @@ struct WaveDec : WaveModel {
     if (SCPR_UNLIKELY(small0 >= 0)) {
       h.fshift = (int)((h0 >> 16) & 15u);
       h.dense = rfl(hz);
+#ifdef SCPR_PROFILE
+      if (h.kind >= 6 && h.dense >= arena.cap && !prof[18]) {  // design aid: the first record that names a table outside the arena
+        prof[18] = 0x100000000ull | (u32)ctxid;
+        prof[21] = h0;
+        prof[22] = h.dense;
+        prof[23] = ((u64)(oom ? 1u : 0u) << 32) | (u32)ndec;
+      }
+#endif
       if (h.kind < 4) {
         event<11>();
         fr = kProbScale, cf = 0;
