@@ -70,5 +70,11 @@ for case in range(seed0, seed0 + cases):
             print("case", case, (w, h, n, style, kprob, workers, loss, hr, lr), "ERROR at frame", t, "size", m, repr(e), flush=True); ok = False; break
         t += m
     bad += not ok
+    if os.environ.get("DBGPROF"):  # profile build (SCPR_AMD_LIB=...libscpr_amd_prof.so): the first record that named a table outside the arena
+        import ctypes as C
+        from screenpressor_amd import codec as K
+        o = (C.c_ulonglong * 24)()
+        K.load_library().scpr_debug_profile(o)
+        if o[18]: print("case", case, (w, h, n, style), "bogus record: ctx %d h0 %08x dense %08x oom %d ndec %d" % (o[18] & 0xFFFFFFFF, o[21] & 0xFFFFFFFF, o[22] & 0xFFFFFFFF, o[23] >> 32, o[23] & 0xFFFFFFFF), flush=True)
     if case % 5 == 4: print("...", case + 1 - seed0, "cases,", bad, "bad, %.0f s" % (time.time() - t0), flush=True)
 print("BAD %d" % bad if bad else "ALL OK (%d cases)" % cases)
