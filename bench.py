@@ -59,22 +59,59 @@ def parse_args(argv=None):
 
 # ------------------------------------------------------------------------------------------------ launcher ---
 def spawn_ranks(args, argv):
-    """the parent of a `--gpus N` run: starts N ranks and relays rank 0's JSON line; never touches the GPU itself"""
+    """the parent of a `--gpus N` run: starts N ranks (fresh child processes, before anything here touches a GPU), relays rank 0's
+    JSON line, keeps the tail of every rank's stderr and, when a rank dies, says which one and ends the others - a rank that is
+    gone before the first collective would otherwise leave the rest waiting for the RCCL timeout with nothing said"""
+    import tempfile
+    import threading
     n = args.gpus
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    procs = []
+    procs, errs = [], []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode())
+        ef = tempfile.TemporaryFile()
+        errs.append(ef)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=ef))
+    out = []
+    reader = threading.Thread(target=lambda: out.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = None
+    while True:
+        rcs = [p.poll() for p in procs]
+        bad = [r for r, rc in enumerate(rcs) if rc not in (None, 0)]
+        if bad:
+            failed = bad[0]
+            time.sleep(2.0)  # (ranks that are about to fail by themselves get to say why)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()  # the exact processes started above
+            break
+        if all(rc == 0 for rc in rcs):
+            break
+        time.sleep(0.2)
+    for p in procs:
+        p.wait()
+    reader.join(timeout=10)
+    sys.stdout.write((out[0] if out else b"").decode())
     sys.stdout.flush()
-    return max(abs(rc) for rc in rcs)
+
+    def tail(r, nbytes=3000):
+        errs[r].seek(0, os.SEEK_END)
+        size = errs[r].tell()
+        errs[r].seek(max(0, size - nbytes))
+        return errs[r].read().decode(errors="replace")
+    if failed is not None:
+        sys.stderr.write(f"[bench] rank {failed} of {n} exited with code {procs[failed].returncode}; the other ranks were stopped. Its stderr ends:\n{tail(failed)}\n")
+        for r in range(n):
+            if r != failed and procs[r].returncode not in (0, -9):
+                sys.stderr.write(f"[bench] rank {r} exited with code {procs[r].returncode}; its stderr ends:\n{tail(r, 1500)}\n")
+        return 1
+    sys.stderr.write(tail(0, 20000))  # rank 0's own messages, as before
+    return 0
 
 
 # ------------------------------------------------------------------------------------------------ workloads ---
@@ -88,13 +125,24 @@ def _render(job):
     return np.stack([np.ascontiguousarray(seq.frame(t) if bpp == 32 else pack24(seq.frame24(t))).reshape(-1) for t in range(t0, t1)])
 
 
-def make_frames(w, h, seed, bpp, t0, t1, dev=None):
+def host_cores(world=1):
+    """cores ONE rank may use: its affinity mask (not the machine's count) shared by the `world` ranks of the job, at most
+    one GPU's share of the box (16)"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:  # noqa: BLE001
+        n = os.cpu_count() or 1
+    return max(1, min(n // max(1, world), 16))
+
+
+def make_frames(w, h, seed, bpp, t0, t1, dev=None, world=1):
     """frames t0..t1-1 of the seeded synthetic desktop, rendered by a pool of host processes (a 4K frame takes
-    0.4 s of numpy); returned as one torch uint8 tensor (n, frame_bytes) on `dev` (or a numpy array)"""
+    0.4 s of numpy); returned as one torch uint8 tensor (n, frame_bytes) on `dev` (or a numpy array).  The pool is this
+    rank's share of the cores the job may use: `world` ranks render at the same time, and the box limits processes."""
     import multiprocessing as mp
     import numpy as np
     n = t1 - t0
-    nproc = max(1, min(8, (os.cpu_count() or 2) // 2, n // 4))
+    nproc = max(1, min(8, host_cores(world), n // 4))
     pitch = w * 4 if bpp == 32 else (w * 3 + 3) & ~3
     if dev is not None:
         import torch
@@ -165,12 +213,21 @@ class Runner:
         self.packets = torch.empty(max(256 << 20, n * w * h // 2), dtype=torch.uint8, device=dev)
         self.decoded = torch.empty(n * h * self.pitch, dtype=torch.uint8, device=dev)
 
-    def step(self, frames, ftypes, seed_args=None, after=None):
+    def reset(self):
         W, H, BPP = self.w, self.h, self.bpp
         self.enc.Deinit(); self.enc.Init(W, H, BPP)
         self.dec.Deinit(); self.dec.Init(W, H, BPP)
-        if seed_args:
-            self.enc.SeedShard(*seed_args)
+
+    def same(self, dec, frames):
+        return bool(self.torch.equal(dec.reshape(frames.shape[0], -1), frames))
+
+    def step(self, frames, ftypes, seed=None, after=None, reset=True):
+        """one pass of the hot path: fresh codecs, `seed(enc)` (a shard that does not start the stream: what crosses key
+        frames, sharding.py), compress, decompress, `after(packets, sizes)` (the exchange step)"""
+        if reset:
+            self.reset()
+            if seed:
+                seed(self.enc)
         t0 = time.perf_counter()
         out, sizes, ft = self.enc.CompressBatch(frames, ftypes, out=self.packets)
         t1 = time.perf_counter()
@@ -182,6 +239,35 @@ class Runner:
         if after:
             after(out, sizes)
         return out, sizes, ft, dec, t1 - t0, t2 - t1, {k: v for k, v in list(se.items()) + list(sd.items()) if v > 0}
+
+
+def shard_seeder(env, wl, frames):
+    """seed(enc) for a rank whose shard is frames [wl.lo, wl.hi) of a stream cut over env.world ranks: fn > 0 (the synthetic
+    desktop has no flat frames) and the motion-vector memory handed down the ranks (sharding.handover_mv_memory: a broadcast
+    per link, the motion-only pre-pass of this rank's shard in between).  Errors of the pre-pass are kept in `seed.error`
+    instead of raised: every rank must reach every collective of the chain."""
+    from screenpressor_amd.sharding import handover_mv_memory
+    import numpy as np
+    if env.world == 1 and not wl.lo:
+        return None
+
+    def seed(enc):
+        seed.error = None
+        if wl.lo:
+            enc.SeedShard(wl.lo, False, 0)
+
+        def prepass(mv_in):
+            try:
+                enc.ImportMvMemory(mv_in)
+                return enc.MotionPrepass(frames, wl.ftypes)
+            except Exception as e:  # noqa: BLE001
+                seed.error = repr(e)
+                return np.zeros_like(mv_in)
+        mv = handover_mv_memory(env.dist, env.rank, env.world, enc.nblocks, prepass, device=env.dev) if env.world > 1 else None
+        if mv is not None:
+            enc.ImportMvMemory(mv)
+    seed.error = None
+    return seed
 
 
 def stream_sha256(packets_host):
@@ -224,17 +310,18 @@ def parity_of(packets_host, sizes, one, nf):
     return ok
 
 
-def measure(runner, wl, frames, steps, warmup, barrier=None, seed_args=None, after=None):
+def measure(runner, wl, frames, steps, warmup, barrier=None, seed=None, after=None):
     tor = runner.torch
     for _ in range(warmup):
-        runner.step(frames, wl.ftypes, seed_args, after)
+        runner.step(frames, wl.ftypes, seed, after)
     if barrier:
         barrier()
-    acc, te, td = {}, 0.0, 0.0
+    acc, te, td, samples = {}, 0.0, 0.0, []
     t0 = time.perf_counter()
     for _ in range(steps):
-        out, sizes, ft, dec, a, b, st = runner.step(frames, wl.ftypes, seed_args, after)
+        out, sizes, ft, dec, a, b, st = runner.step(frames, wl.ftypes, seed, after)
         te, td = te + a, td + b
+        samples.append((a, b))
         for k, v in st.items():
             acc[k] = acc.get(k, 0.0) + v
     if barrier:
@@ -242,29 +329,85 @@ def measure(runner, wl, frames, steps, warmup, barrier=None, seed_args=None, aft
     else:
         tor.cuda.synchronize(runner.dev)
     elapsed = time.perf_counter() - t0
-    assert bool(tor.equal(dec.reshape(wl.n, -1), frames)), "the decoded frames differ from the input: the round trip is not lossless"
-    return dict(out=out, sizes=sizes, ft=ft, elapsed=elapsed, t_enc=te / steps, t_dec=td / steps, stage_ms={k: v / steps for k, v in acc.items()})
+    assert runner.same(dec, frames), "the decoded frames differ from the input: the round trip is not lossless"
+    return dict(out=out, sizes=sizes, ft=ft, elapsed=elapsed, t_enc=te / steps, t_dec=td / steps, samples=samples, stage_ms={k: v / steps for k, v in acc.items()})
 
 
-def other_config(runner_cache, dev, local_rank, label, wl, frames, gop, cpu_frames, no_cpu, golden=None):
-    """one of the single-GPU configs that is not the headline: 1 warm-up + 1 timed pass, CPU sample, parity"""
+def golden_stream(name):
+    """the committed sha256 of a full bench stream (tests/golden/manifest.json, made by the oracle: make_golden.py --streams)"""
+    try:
+        return json.load(open(os.path.join(ROOT, "tests", "golden", "manifest.json"))).get(name)
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def golden_stream_check(entry, packets_host, sizes, first_frame=0):
+    """packets (one uint8 array, in frame order, starting at frame `first_frame` of the stream - a GOP start) against the
+    committed hashes: the whole stream when all of it is here, otherwise GOP by GOP (a shorter run of the same stream, or
+    one rank's shard).  True / False, or a string saying why nothing could be compared."""
+    import numpy as np
+    if not entry:
+        return "not checked: no committed hash for this stream"
+    n, k = len(sizes), int(entry["key_interval"])
+    if first_frame == 0 and n == entry["frames"]:
+        return stream_sha256(packets_host) == entry["sha256"] and int(packets_host.size) == entry["bytes"]
+    if not entry.get("gop_sha256") or first_frame % k or n % k or first_frame + n > entry["frames"]:
+        return "not checked: the run is not a whole number of GOPs of the committed stream"
+    offs = np.concatenate([[0], np.cumsum(np.asarray(sizes, dtype=np.int64))])
+    g0 = first_frame // k
+    return all(hashlib.sha256(packets_host[offs[g * k]:offs[(g + 1) * k]].tobytes()).hexdigest() == entry["gop_sha256"][g0 + g] for g in range(n // k))
+
+
+def other_config(runner_cache, dev, local_rank, label, wl, frames, gop, cpu_frames, no_cpu, stream=None, threads_all=0, passes=3):
+    """one of the single-GPU configs that is not the headline: 1 warm-up + `passes` timed passes (a P-frame chain moves a few
+    per cent from pass to pass and more from box to box: median and best are both given), the full stream against its
+    committed hash, a bounded CPU sample and the parity flag against it"""
+    import statistics
     key = (wl.w, wl.h, wl.bpp)
     if key not in runner_cache or runner_cache[key].n < wl.n:
         runner_cache[key] = Runner(dev, local_rank, wl.w, wl.h, wl.bpp, wl.n)
-    r = measure(runner_cache[key], wl, frames, 1, 1)
+    r = measure(runner_cache[key], wl, frames, passes, 1)
     host = r["out"].cpu().numpy()
     pix = wl.n * wl.w * wl.h / 1e6
-    res = {"config": label, "workload": wl.name, "frames": wl.n, "enc_MPix_s": round(pix / r["t_enc"], 1), "dec_MPix_s": round(pix / r["t_dec"], 1),
-           "combined_MPix_s": round(pix / (r["t_enc"] + r["t_dec"]), 1), "compressed_bytes": int(host.size), "sha256": stream_sha256(host), "lossless_roundtrip": True,
+    te, td = [a for a, _ in r["samples"]], [b for _, b in r["samples"]]
+    tc = [a + b for a, b in r["samples"]]
+    res = {"config": label, "workload": wl.name, "frames": wl.n, "passes": passes, "statistic": "median of the timed passes (best in *_best)",
+           "enc_MPix_s": round(pix / statistics.median(te), 1), "dec_MPix_s": round(pix / statistics.median(td), 1),
+           "combined_MPix_s": round(pix / statistics.median(tc), 1),
+           "enc_MPix_s_best": round(pix / min(te), 1), "dec_MPix_s_best": round(pix / min(td), 1), "combined_MPix_s_best": round(pix / min(tc), 1),
+           "compressed_bytes": int(host.size), "sha256": stream_sha256(host), "lossless_roundtrip": True,
+           "golden_stream_ok": golden_stream_check(golden_stream(stream), host, r["sizes"]) if stream else None, "golden_stream": stream,
            "stage_ms": {k: round(v, 2) for k, v in r["stage_ms"].items()}}
-    if golden:
-        res["golden"] = golden(host, r["sizes"])
     if not no_cpu:
         nf = min(cpu_frames, wl.n)
-        one, cpu = cpu_sample(wl, frames[:nf].cpu().numpy(), nf, gop, 0)
+        one, cpu = cpu_sample(wl, frames[:nf].cpu().numpy(), nf, gop, threads_all)
         res["cpu_baseline"] = dict(cpu["one_thread"], sample=f"first {nf} frames, oracle/libspo.so, one thread")
+        if "all_cores" in cpu:
+            res["cpu_baseline"]["all_cores"] = cpu["all_cores"]
         res["parity"] = {"vs": "oracle (CPU restatement; pinned to the reference only for rANS)", "frames_checked": nf, "ok": parity_of(host, r["sizes"], one, nf)}
     return res
+
+
+def per_frame_api_ms(local_rank, frames_host, w, h, bpp):
+    """the drop-in pair as a VfW host drives it (host pointers, one frame per call, PCIe included): median milliseconds of
+    CompressFrame / DecompressFrame for key frames and P-frames (tools/perframe_latency.py)"""
+    import statistics
+    from screenpressor_amd.codec import ScreenCodec
+    enc, dec = ScreenCodec(local_rank).Init(w, h, bpp), ScreenCodec(local_rank).Init(w, h, bpp)
+    enc.CompressFrame(frames_host[0], 0)  # warm-up (allocations)
+    rows, pk = {}, []
+    for t, f in enumerate(frames_host):
+        t0 = time.perf_counter()
+        p, ft = enc.CompressFrame(f, 0 if t % 4 == 0 else 1)
+        rows.setdefault("encode_key" if ft == 0 else "encode_p", []).append((time.perf_counter() - t0) * 1e3)
+        pk.append((p, ft))
+    dec.DecompressFrame(pk[0][0], 0)
+    for p, ft in pk:
+        t0 = time.perf_counter()
+        r, _ = dec.DecompressFrame(p, ft)
+        assert r == 1
+        rows.setdefault("decode_key" if ft == 0 else "decode_p", []).append((time.perf_counter() - t0) * 1e3)
+    return {k: round(statistics.median(v), 2) for k, v in sorted(rows.items())}
 
 
 # ------------------------------------------------------------------------------------------------ a rank ---
@@ -274,6 +417,9 @@ def selftest_rank(args, rank, world):
     import torch.distributed as dist
     sys.path.insert(0, ROOT)
     from screenpressor_amd.sharding import gather_packets, shard_gops
+    if os.environ.get("SCPR_SELFTEST_DIE_RANK") == str(rank):  # (tests: a rank that is gone before the first collective)
+        sys.stderr.write("selftest: this rank gives up before the rendezvous\n")
+        sys.exit(3)
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     total, k = args.frames or 24, args.gop or 4
@@ -295,6 +441,105 @@ def selftest_rank(args, rank, world):
         dist.barrier()
         dist.destroy_process_group()
     return 0
+
+
+class Env:
+    """what a rank runs on: one GPU + RCCL in the bench; CPU tensors + gloo + a stand-in codec in tests/test_sharding.py, which
+    drives c4_leg() through the same collectives"""
+
+    def __init__(self, rank, world, dev, torch, dist, make_runner, render):
+        self.rank, self.world, self.dev, self.torch, self.dist, self.make_runner, self.render = rank, world, dev, torch, dist, make_runner, render
+
+    def sync(self):
+        if self.dev is not None and self.dev.type == "cuda":
+            self.torch.cuda.synchronize(self.dev)
+
+    def barrier(self):
+        self.sync()
+        if self.world > 1:
+            self.dist.barrier()
+        self.sync()
+
+    def all_reduce(self, t, op):
+        if self.world > 1:
+            self.dist.all_reduce(t, op=op)
+
+    def all_ok(self, ok):
+        t = self.torch.tensor([1 if ok else 0], device=self.dev, dtype=self.torch.int32)
+        self.all_reduce(t, self.dist.ReduceOp.MIN)
+        return int(t.item()) == 1
+
+
+def c4_leg(env, wl4, golden_name="stream_4k_ip_k150_1200"):
+    """BASELINE configs[3] on `env.world` ranks: ONE stream cut at key frames into contiguous GOP ranges (wl4 is this rank's),
+    every shard seeded with what crosses key frames - fn and the motion-vector memory handed down the ranks - so that the
+    gathered packets are the single stream's; one warm-up and one timed pass between barriers, the hand-over and the gather
+    of the packets on rank 0 inside the step; rank 0 compares the gathered stream with the committed oracle hash.
+    No collective sits inside a try: whatever happens on one rank, every rank reaches the same collectives in the same
+    order (a rank that skipped one would leave the others waiting, and the headline line would be lost with it).
+    Returns the entry for config.others (meaningful on rank 0)."""
+    from screenpressor_amd.sharding import gather_packets
+    torch, dist, rank, world, dev = env.torch, env.dist, env.rank, env.world, env.dev
+    ready, c4, f4, r4 = 1, None, None, None
+    try:
+        f4 = env.render(wl4)
+        r4 = env.make_runner(wl4)
+    except Exception as e:  # noqa: BLE001  (every rank still takes part in the collective below)
+        ready, c4 = 0, {"config": wl4.name, "error": repr(e)}
+    if not env.all_ok(ready == 1):
+        return c4 or {"config": wl4.name, "error": "another rank could not set the workload up"}
+    seed = shard_seeder(env, wl4, f4)
+    gathered = {}
+
+    def one_pass():
+        """(result or None, error): reset + seed (collectives) outside the try, the codec calls inside"""
+        r4.reset()
+        if seed:
+            seed(r4.enc)
+        err = seed.error if seed else None
+        if err is None:
+            try:
+                out, sizes, _, dec, a, b, _ = r4.step(f4, wl4.ftypes, reset=False)
+                assert r4.same(dec, f4), "the decoded frames differ from the input"
+                return (out, sizes, a, b), None
+            except Exception as e:  # noqa: BLE001
+                err = repr(e)
+        return None, err
+
+    _, err4 = one_pass()  # warm-up
+    if env.all_ok(err4 is None):
+        env.barrier()
+        t0 = time.perf_counter()
+        res, err4 = one_pass()
+        good = env.all_ok(res is not None)
+        if good:  # (all ranks, all fine: the gather is part of the step)
+            if world > 1:
+                gathered["p"], gathered["s"] = gather_packets(dist, rank, world, res[0], res[1], device=dev)
+            else:
+                gathered["p"], gathered["s"] = res[0], torch.as_tensor([int(x) for x in res[1]])
+        env.barrier()
+        t4 = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        env.all_reduce(t4, dist.ReduceOp.MAX)
+        if good:
+            pix4 = wl4.total_frames * wl4.w * wl4.h / 1e6
+            c4 = {"config": f"configs[3]: ONE {wl4.w}x{wl4.h} stream, {wl4.total_frames} frames, GOP-sharded over the ranks (strong scaling), every shard seeded with the "
+                            "motion-vector memory of the shards before it, packets gathered on rank 0 in the step",
+                  "workload": wl4.name, "scaling": "strong", "frames_total": wl4.total_frames, "frames_rank0": wl4.n, "gops_rank0": sum(1 for f in wl4.ftypes if f == 0),
+                  "value_MPix_s": round(pix4 / float(t4.item()), 2), "ms_per_step": round(float(t4.item()) * 1e3, 1),
+                  "enc_MPix_s_rank0": round(wl4.n * wl4.w * wl4.h / 1e6 / res[2], 1), "dec_MPix_s_rank0": round(wl4.n * wl4.w * wl4.h / 1e6 / res[3], 1),
+                  "lossless_roundtrip": True,
+                  "note": "a GOP is one serial chain (one wave): 8 GOPs run side by side on ONE GPU already, so this stream gains nothing from more GPUs - "
+                          "GPU count pays when the stream has more GOPs than one GPU has chain slots (768 at 1080p), see DESIGN.md 7"}
+            if rank == 0:
+                host = gathered["p"].cpu().numpy()
+                sizes = [int(x) for x in gathered["s"].cpu().tolist()]
+                c4.update({"gathered_frames_rank0": len(sizes), "compressed_bytes": int(host.size), "sha256": stream_sha256(host), "golden_stream": golden_name,
+                           "golden_stream_ok": golden_stream_check(golden_stream(golden_name), host, sizes),
+                           "parity": {"vs": "sha256 of ONE oracle codec over the whole stream (tests/golden/manifest.json), whole or GOP by GOP", "sharded_equals_single_stream": None}})
+                c4["parity"]["sharded_equals_single_stream"] = c4["golden_stream_ok"] if isinstance(c4["golden_stream_ok"], bool) else None
+    if c4 is None:
+        c4 = {"config": wl4.name, "error": err4 or "the pass failed on another rank"}
+    return c4
 
 
 def run_rank(args):
@@ -319,42 +564,33 @@ def run_rank(args):
     wl = describe(args, rank, world)
     W, H, BPP, N = wl.w, wl.h, wl.bpp, wl.n
     gop = 1 if args.workload == "keys" else (args.gop or (50 if args.workload == "ip" else 150))
+    env = Env(rank, world, dev, torch, dist, lambda q: Runner(dev, local_rank, q.w, q.h, q.bpp, q.n),
+              lambda q: make_frames(q.w, q.h, q.seed, q.bpp, q.lo, q.hi, dev, world))
 
     # synthetic input, resident in HBM before the timed region
-    frames = make_frames(W, H, wl.seed, BPP, wl.lo, wl.hi, dev)
-    runner = Runner(dev, local_rank, W, H, BPP, N)
-    seed_args = (wl.lo, False, 0) if wl.lo else None  # a shard that does not start the stream (the synthetic desktop has no flat frames)
-
-    def barrier():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
+    frames = env.render(wl)
+    runner = env.make_runner(wl)
+    seed = shard_seeder(env, wl, frames) if args.workload == "c4" else None  # (keys / ip: every rank has a stream of its own)
+    barrier = env.barrier
     gathered = {}
 
     def exchange(out, sizes):  # the exchange step: compressed chunks + sizes to rank 0 in frame order (RCCL over xGMI)
         if world > 1:
             gathered["p"], gathered["s"] = gather_packets(dist, rank, world, out, sizes, device=dev)
 
-    m = measure(runner, wl, frames, args.steps, args.warmup, barrier, seed_args, exchange)
+    m = measure(runner, wl, frames, args.steps, args.warmup, barrier, seed, exchange)
+    if seed is not None and seed.error:
+        raise RuntimeError("motion pre-pass: " + seed.error)
     tmax = torch.tensor([m["elapsed"]], device=dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    env.all_reduce(tmax, dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
     ms_per_step = elapsed / args.steps * 1e3
     total_frames = wl.total_frames
     value = total_frames * W * H / 1e6 / (elapsed / args.steps)
 
-    # N > 1: configs[3] as well - ONE 3840x2160 stream of 1200 frames, key frame every 150, cut at key frames into `world`
-    # contiguous GOP ranges (strong scaling: 1200 / N frames per rank), compressed chunks gathered on rank 0 inside the timed
-    # step.  One warm-up and one timed pass; reported under config.others, never as `value`.
+    # N > 1: configs[3] as well (c4_leg); reported under config.others, never as `value`.
     c4 = None
     head_gathered = (int(gathered["s"].numel()), int(gathered["p"].numel())) if gathered.get("s") is not None else None
-    def all_reduce(t, op):
-        if world > 1:
-            dist.all_reduce(t, op=op)
-
     if (world > 1 or args.c4_leg) and not args.no_others and args.workload == "keys" and (W, H, BPP) == (1920, 1080, 32) and not args.frames:
         import copy
         a4 = copy.copy(args)
@@ -366,63 +602,7 @@ def run_rank(args):
         runner = None
         m["out"] = headline_out
         torch.cuda.empty_cache()
-        ready, f4, r4 = 1, None, None
-        try:
-            f4 = make_frames(wl4.w, wl4.h, wl4.seed, wl4.bpp, wl4.lo, wl4.hi, dev)
-            r4 = Runner(dev, local_rank, wl4.w, wl4.h, wl4.bpp, wl4.n)
-        except Exception as e:  # noqa: BLE001  (every rank still takes part in the collective below)
-            ready, c4 = 0, {"config": wl4.name, "error": repr(e)}
-        flag = torch.tensor([ready], device=dev, dtype=torch.int32)
-        all_reduce(flag, dist.ReduceOp.MIN)
-        if int(flag.item()) == 1:
-            # No collective inside a try: whatever happens on one rank, every rank reaches the same collectives in the same
-            # order (a rank that skipped one would leave the others waiting, and the headline line would be lost with it).
-            seed4 = (wl4.lo, False, 0) if wl4.lo else None
-
-            def one_pass():
-                out, sizes, _, dec, a, b, _ = r4.step(f4, wl4.ftypes, seed4, None)
-                assert bool(torch.equal(dec.reshape(wl4.n, -1), f4)), "the decoded frames differ from the input"
-                return out, sizes, a, b
-
-            def all_ok(ok):
-                t = torch.tensor([1 if ok else 0], device=dev, dtype=torch.int32)
-                all_reduce(t, dist.ReduceOp.MIN)
-                return int(t.item()) == 1
-
-            err4 = None
-            try:
-                one_pass()  # warm-up
-            except Exception as e:  # noqa: BLE001
-                err4 = repr(e)
-            if all_ok(err4 is None):
-                barrier()
-                t0 = time.perf_counter()
-                res = None
-                try:
-                    res = one_pass()
-                except Exception as e:  # noqa: BLE001
-                    err4 = repr(e)
-                good = all_ok(res is not None)
-                if good:
-                    exchange(res[0], res[1])  # (all ranks, all fine: the gather is part of the step)
-                barrier()
-                t4 = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
-                all_reduce(t4, dist.ReduceOp.MAX)
-                if good:
-                    pix4 = wl4.total_frames * wl4.w * wl4.h / 1e6
-                    c4 = {"config": "configs[3]: ONE 3840x2160 stream, 1200 frames, key frame every 150, GOP-sharded over the ranks (strong scaling), packets gathered on rank 0 in the step",
-                          "workload": wl4.name, "scaling": "strong", "frames_total": wl4.total_frames, "frames_rank0": wl4.n, "gops_rank0": sum(1 for f in wl4.ftypes if f == 0),
-                          "value_MPix_s": round(pix4 / float(t4.item()), 2), "ms_per_step": round(float(t4.item()) * 1e3, 1),
-                          "enc_MPix_s_rank0": round(wl4.n * wl4.w * wl4.h / 1e6 / res[2], 1), "dec_MPix_s_rank0": round(wl4.n * wl4.w * wl4.h / 1e6 / res[3], 1),
-                          "lossless_roundtrip": True,
-                          "gathered_frames_rank0": int(gathered["s"].numel()) if gathered.get("s") is not None else None,
-                          "note": "a GOP is one serial chain (one wave): 8 GOPs run side by side on ONE GPU already, so this stream gains nothing from more GPUs - "
-                                  "GPU count pays when the stream has more GOPs than one GPU has chain slots (768 at 1080p), see DESIGN.md 7"}
-            if c4 is None:
-                c4 = {"config": wl4.name, "error": err4 or "the pass failed on another rank"}
-        elif c4 is None:
-            c4 = {"config": wl4.name, "error": "another rank could not set the workload up"}
-        del f4, r4
+        c4 = c4_leg(env, wl4)
         frames = None
 
     if rank == 0:
@@ -464,15 +644,23 @@ def run_rank(args):
                 parity["golden_fixture_ok"] = all(hashlib.sha256(host[offs[t]:offs[t + 1]].tobytes()).hexdigest() == man["frame_sha256"][t] for t in range(3))
             except Exception as e:  # noqa: BLE001
                 parity["golden_fixture_ok"] = f"not checked: {e}"
+        # the whole timed stream against the committed sha256 of ONE oracle codec over it (tests/golden/manifest.json)
+        gname = None
+        if (W, H, wl.seed, wl.lo) == (1920, 1080, 1, 0) and N == 300:
+            gname = {"keys": "stream_1080p_keys_300", "ip": {50: "stream_1080p_ip_k50_300", 300: "stream_1080p_ip_onegop_300"}.get(gop)}.get(args.workload)
+        elif args.workload == "c4" and (W, H, wl.seed, gop) == (3840, 2160, 1, 150):
+            gname = "stream_4k_ip_k150_1200"
+        if gname:
+            if args.workload == "c4" and world > 1 and gathered.get("p") is not None:  # the sharded stream as rank 0 gathered it
+                parity["golden_stream_ok"] = golden_stream_check(golden_stream(gname), gathered["p"].cpu().numpy(), [int(x) for x in gathered["s"].cpu().tolist()])
+            else:
+                parity["golden_stream_ok"] = golden_stream_check(golden_stream(gname), host, m["sizes"], wl.lo)
+            parity["golden_stream"] = gname
         cpu = None
         if not args.no_cpu and world == 1 and frames is not None:  # the CPU baseline is a rank-0, one-GPU measurement
             big = W * H > 1920 * 1080 or args.workload != "keys"
             nf = min(args.cpu_frames or (40 if big else N), N)
-            try:
-                ncores = len(os.sched_getaffinity(0))  # the cores this process may run on, not the machine's
-            except Exception:  # noqa: BLE001
-                ncores = os.cpu_count() or 1
-            ncores = min(ncores, 16)  # the GPU box gives one GPU's share of its host: 16 cores
+            ncores = host_cores()  # the cores this process may run on, at most one GPU's share of the box
             one, res = cpu_sample(wl, frames[:nf].cpu().numpy(), nf, gop, ncores if args.workload == "keys" else 0)
             parity["ok"] = parity_of(host, m["sizes"], one, nf)
             parity["frames_checked"] = nf
@@ -507,22 +695,28 @@ def run_rank(args):
                 del h_in, h_out, d_in
             except Exception as e:  # noqa: BLE001
                 config["incl_host_transfer_MPix_s"] = f"not measured: {e}"
+        if world == 1 and frames is not None and (W, H) == (1920, 1080) and args.workload == "keys":
+            try:
+                config["per_frame_api_ms"] = dict(per_frame_api_ms(local_rank, [f.reshape(-1) for f in frames[:8].cpu().numpy()], W, H, BPP),
+                                                  note="ScreenCodec::CompressFrame / DecompressFrame one frame per call, host pointers, PCIe included (median of 8 frames: 2 key, 6 P)")
+            except Exception as e:  # noqa: BLE001
+                config["per_frame_api_ms"] = f"not measured: {e}"
         if c4 is not None:
             config["others"] = [c4]
         if world == 1 and c4 is None and not args.no_others and args.workload == "keys" and (W, H, BPP) == (1920, 1080, 32) and not args.frames:
             others, cache = [], {(W, H, BPP): runner}
             cf = args.cpu_frames or 60
 
-            def sub(label, w, h, bpp, n, ft, fr, k, cpu_n):
+            def sub(label, w, h, bpp, n, ft, fr, k, cpu_n, stream=None, threads_all=0):
                 owl = Workload(label, w, h, bpp, 1, 0, n, ft, "weak", n)
                 try:
-                    others.append(other_config(cache, dev, local_rank, label, owl, fr, k, cpu_n, args.no_cpu))
+                    others.append(other_config(cache, dev, local_rank, label, owl, fr, k, cpu_n, args.no_cpu, stream, threads_all))
                 except Exception as e:  # noqa: BLE001
                     others.append({"config": label, "error": repr(e)})
-            sub("configs[2]: 1920x1080 RGB32 I+P, key frame every 50 (6 GOPs), 300 frames", W, H, 32, N, [0 if t % 50 == 0 else 1 for t in range(N)], frames, 50, cf)
-            sub("configs[2] as ONE GOP: key frame 0 then 299 P-frames (the reference's default key interval is 500, conf.h:7)", W, H, 32, N, [0] + [1] * (N - 1), frames, N, cf)
+            sub("configs[2]: 1920x1080 RGB32 I+P, key frame every 50 (6 GOPs), 300 frames", W, H, 32, N, [0 if t % 50 == 0 else 1 for t in range(N)], frames, 50, cf, "stream_1080p_ip_k50_300")
+            sub("configs[2] as ONE GOP: key frame 0 then 299 P-frames (the reference's default key interval is 500, conf.h:7)", W, H, 32, N, [0] + [1] * (N - 1), frames, N, cf, "stream_1080p_ip_onegop_300")
             f24 = make_frames(W, H, 1, 24, 0, N, dev)
-            sub("configs[4]: 1920x1080 RGB24 (3-byte pixels, pitch 5760) key-frame-only, 300 frames", W, H, 24, N, [0] * N, f24, 1, cf)
+            sub("configs[4]: 1920x1080 RGB24 (3-byte pixels, pitch 5760) key-frame-only, 300 frames", W, H, 24, N, [0] * N, f24, 1, cf, "stream_1080p_keys_300")
             others[-1]["stream_equals_rgb32_stream"] = others[-1].get("sha256") == parity["sha256"]
             del f24
             del frames
@@ -530,8 +724,8 @@ def run_rank(args):
             cache.clear()
             torch.cuda.empty_cache()
             f4k = make_frames(3840, 2160, 1, 32, 0, 150, dev)
-            sub("configs[3], one GPU's share of 8: 3840x2160 RGB32, 150 frames as key frames (a frame-sharded stream)", 3840, 2160, 32, 150, [0] * 150, f4k, 1, 10)
-            sub("configs[3], one GPU's share of 8: 3840x2160 RGB32, ONE GOP of 150 frames (key frame every 150)", 3840, 2160, 32, 150, [0] + [1] * 149, f4k, 150, 10)
+            sub("configs[3], one GPU's share of 8: 3840x2160 RGB32, 150 frames as key frames (a frame-sharded stream)", 3840, 2160, 32, 150, [0] * 150, f4k, 1, 10, "stream_4k_keys_150", host_cores())
+            sub("configs[3], one GPU's share of 8: 3840x2160 RGB32, ONE GOP of 150 frames (key frame every 150)", 3840, 2160, 32, 150, [0] + [1] * 149, f4k, 150, 10, "stream_4k_ip_k150_1200", host_cores())
             config["others"] = others
         line = {"metric": METRIC, "value": round(value, 2), "unit": "MPix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
                 "higher_is_better": True, "scaling": wl.scaling, "vs_baseline": None, "dtype": "u8", "data": "synthetic", "config": config,

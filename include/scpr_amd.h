@@ -99,9 +99,31 @@ int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* 
  * that does not start the stream: frames_before = frames coded before the
  * shard's first frame, last_was_flat / last_flat_rgb (b0 | b1<<8 | b2<<16 of the
  * RGB24 pixel) = whether the frame just before the shard was a flat one.  The
- * motion-vector memory mvs[] (:96-97, never reset) is NOT reproduced: P-frames
- * of a shard equal the reference run on that shard's frames. */
+ * third piece of state that crosses key frames, the motion-vector memory, has
+ * its own calls below. */
 int scpr_seed_shard(scpr_codec* c, uint32_t frames_before, int last_was_flat, uint32_t last_flat_rgb);
+
+/* The motion-vector memory `int *mvs[2]` of CScreenCapt (screencap.h:450;
+ * calloc'd by Init, screencap.cpp:96-97; written by FindMV :720-735, :740-811;
+ * read as "the vector of the block above" by every later P-frame, :726-735;
+ * never reset - RenewI :178-198 touches models only).  mx / my: host arrays of
+ * ceil(width/16) * ceil(height/16) ints in block raster order, components in
+ * [-256, 256].  Both return the number of blocks, or < 0.
+ * A shard that does not start the stream imports what the frames before it
+ * leave behind; with that (and scpr_seed_shard) its packets are the single
+ * stream's packets. */
+int scpr_export_mv_memory(scpr_codec* c, int32_t* mx, int32_t* my);
+int scpr_import_mv_memory(scpr_codec* c, const int32_t* mx, const int32_t* my);
+
+/* What mvs[] holds after scpr_compress_batch of these frames (same arguments),
+ * WITHOUT coding them and without changing the codec: conversion to RGB24,
+ * loss mask, frame-type decisions, block compare and motion search only
+ * (DecideBlockTypes :928-1087 and FindMV :684-814 read the planes and mvs[],
+ * nothing of the models).  A rank runs it over its own shard to produce the
+ * memory the next shard starts from, before any rank has coded anything.
+ * ftypes: host array (in only).  Returns the number of blocks, or < 0. */
+int scpr_motion_prepass(scpr_codec* c, const void* d_frames, int nframes, const int* ftypes, int loss,
+                        int32_t* mx, int32_t* my);
 
 /* ---- instrumentation ------------------------------------------------------ */
 /* Kernel time of the last batch call, measured with HIP events on the codec's

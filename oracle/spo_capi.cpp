@@ -51,6 +51,21 @@ void spo_seed_shard(void* h, uint32_t frames_before, int last_flat, uint32_t rgb
   ((ScreenCodec*)h)->seed_shard(frames_before, last_flat != 0, c);
 }
 
+// Sharding support: the vector memory mvs[] (screencap.cpp:96-97; never reset, read by FindMV :726-735) out of / into the
+// codec, so that the CPU ranks of tests/test_sharding.py can hand it from shard to shard the way the GPU ranks do.
+int spo_export_mv_memory(void* h, int32_t* mx, int32_t* my, int nblocks) {
+  FrameCodec* f = ((ScreenCodec*)h)->ensure_inner();
+  if ((int)f->mv[0].size() != nblocks) return -1;
+  for (int i = 0; i < nblocks; i++) mx[i] = f->mv[0][i], my[i] = f->mv[1][i];
+  return nblocks;
+}
+int spo_import_mv_memory(void* h, const int32_t* mx, const int32_t* my, int nblocks) {
+  FrameCodec* f = ((ScreenCodec*)h)->ensure_inner();
+  if ((int)f->mv[0].size() != nblocks) return -1;
+  for (int i = 0; i < nblocks; i++) f->mv[0][i] = mx[i], f->mv[1][i] = my[i];
+  return nblocks;
+}
+
 // ---- taps on the last compressed frame -------------------------------------
 int spo_tap_entries(void* h, uint16_t* out, int cap_entries) {
   FrameCodec* f = ((ScreenCodec*)h)->inner();

@@ -201,6 +201,10 @@ class ScreenCodec {  // screencap.h:519-541, screencap.cpp:1560-1743
     fc_->seed_shard(frames_before, last_flat, rgb);
   }
   FrameCodec* inner() { return fc_; }
+  FrameCodec* ensure_inner() {  // the lazily created codec object (CreateCodec, screencap.cpp:1646-1648), for the sharding calls
+    if (!fc_) create(p_.version == 3 ? 3 : p_.version == 2 ? 2 : 4);
+    return fc_;
+  }
 
  private:
   void create(int version);

@@ -18,7 +18,7 @@ _LIB_PATH = os.environ.get("SCPR_AMD_LIB", os.path.join(_PKG, "libscpr_amd.so"))
 SCPR_OK, SCPR_E_DEVICE, SCPR_E_PARAM, SCPR_E_BAD_VERSION, SCPR_E_CAPACITY, SCPR_E_STREAM = 0, -1, -2, -3, -4, -5
 EXPORTS = ["scpr_create", "scpr_destroy", "scpr_init", "scpr_deinit", "scpr_crash_happened", "scpr_compress_frame",
            "scpr_decompress_frame", "scpr_compress_batch", "scpr_decompress_batch", "scpr_last_timing", "scpr_stage_name",
-           "scpr_seed_shard", "scpr_debug_entries", "scpr_debug_arena", "scpr_debug_colour_chain", "scpr_version",
+           "scpr_seed_shard", "scpr_export_mv_memory", "scpr_import_mv_memory", "scpr_motion_prepass", "scpr_debug_entries", "scpr_debug_arena", "scpr_debug_colour_chain", "scpr_version",
            # include/scpr_driver.h, include/scpr_avi.h
            "scpr_driver_open", "scpr_driver_close", "scpr_driver_configure", "scpr_driver_compress_query", "scpr_driver_compress_get_format",
            "scpr_driver_compress_get_size", "scpr_driver_compress_begin", "scpr_driver_compress_end", "scpr_driver_compress",
@@ -67,6 +67,9 @@ def load_library() -> C.CDLL:
         L.scpr_debug_entries.restype = C.c_int64
         L.scpr_debug_entries.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
         L.scpr_seed_shard.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_uint32]
+        L.scpr_export_mv_memory.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.scpr_import_mv_memory.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.scpr_motion_prepass.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_void_p, C.c_void_p]
         L.scpr_debug_arena.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.scpr_debug_colour_chain.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.scpr_version.restype = C.c_char_p
@@ -106,6 +109,33 @@ class ScreenCodec:
         """scpr_seed_shard: the cross-GOP state of the single stream where this codec's shard starts"""
         self._check(self._L.scpr_seed_shard(self._h, frames_before, 1 if last_was_flat else 0, last_flat_rgb))
         return self
+
+    # the motion-vector memory mvs[] (screencap.cpp:96-97), the other state that crosses key frames: (2, blocks) int32
+    @property
+    def nblocks(self):
+        return ((self.width + 15) // 16) * ((self.height + 15) // 16)
+
+    def ExportMvMemory(self) -> np.ndarray:
+        mv = np.zeros((2, self.nblocks), dtype=np.int32)
+        self._check(self._L.scpr_export_mv_memory(self._h, mv[0].ctypes.data_as(C.c_void_p), mv[1].ctypes.data_as(C.c_void_p)))
+        return mv
+
+    def ImportMvMemory(self, mv):
+        mv = np.ascontiguousarray(mv, dtype=np.int32).reshape(2, self.nblocks)
+        self._check(self._L.scpr_import_mv_memory(self._h, mv[0].ctypes.data_as(C.c_void_p), mv[1].ctypes.data_as(C.c_void_p)))
+        return self
+
+    def MotionPrepass(self, frames, ftypes, loss: int | None = None) -> np.ndarray:
+        """scpr_motion_prepass: mvs[] as CompressBatch(frames, ftypes) would leave it; the codec itself is not changed"""
+        import torch
+        n = frames.shape[0]
+        assert frames.is_cuda and frames.dtype == torch.uint8 and frames.is_contiguous() and frames.numel() == n * self.frame_bytes
+        ft = (C.c_int * n)(*[int(x) for x in ftypes])
+        mv = np.zeros((2, self.nblocks), dtype=np.int32)
+        torch.cuda.synchronize(frames.device)
+        self._check(self._L.scpr_motion_prepass(self._h, C.c_void_p(frames.data_ptr()), n, ft, self.loss if loss is None else loss,
+                                                mv[0].ctypes.data_as(C.c_void_p), mv[1].ctypes.data_as(C.c_void_p)))
+        return mv
 
     def CrashHappened(self):
         self._L.scpr_crash_happened(self._h)
@@ -153,16 +183,23 @@ class ScreenCodec:
         import torch
         n = frames.shape[0]
         assert frames.is_cuda and frames.dtype == torch.uint8 and frames.is_contiguous() and frames.numel() == n * self.frame_bytes
-        if out is None:
+        own = out is None
+        if own:
             # room for incompressible pictures (a literal pixel costs a little over three bytes): a batch that does not fit ends in
             # SCPR_E_CAPACITY after the models have moved on, so the default is the safe size; pass `out` to reuse a smaller buffer
-            out = torch.empty(min(n * self.max_packet, max(64 << 20, n * (self.width * self.height * 4 + 1024))), dtype=torch.uint8, device=frames.device)
+            # (kept on the object and grown when a call needs more: 2.5 GB for 300 frames of 1080p is not allocated per call)
+            need = min(n * self.max_packet, max(64 << 20, n * (self.width * self.height * 4 + 1024)))
+            if getattr(self, "_out", None) is None or self._out.numel() < need or self._out.device != frames.device:
+                self._out = None
+                self._out = torch.empty(need, dtype=torch.uint8, device=frames.device)
+            out = self._out
         ft = (C.c_int * n)(*[int(x) for x in ftypes])
         sizes = (C.c_uint32 * n)()
         torch.cuda.synchronize(frames.device)
         total = self._check(self._L.scpr_compress_batch(self._h, C.c_void_p(frames.data_ptr()), n, ft, self.loss if loss is None else loss,
                                                         C.c_void_p(out.data_ptr()), out.numel(), sizes))
-        return out[:total], np.frombuffer(sizes, dtype=np.uint32).copy(), list(ft)
+        # (from the object's own buffer the packets are copied out - they are ~1 % of it - so that the next call cannot change them)
+        return (out[:total].clone() if own else out[:total]), np.frombuffer(sizes, dtype=np.uint32).copy(), list(ft)
 
     def DecompressBatch(self, packets, sizes, ftypes, pitch: int | None = None, out=None):
         import torch

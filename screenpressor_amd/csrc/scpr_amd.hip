@@ -110,7 +110,7 @@ struct scpr_codec {
   DevBuf mvdict, mvpre, gmask;
   DevBuf kinds, pidx, fidx, pframes, pflag, binfo, smv, btype, bmv, bcnt, boff, bflag, pinfo, ptot, pbase, misc, miscpos, miscranges;
   // state of the live generation, carried between calls (models are reset only by key frames, screencap.cpp:1118)
-  DevBuf mvs, fixed_persist, misc_persist, colour_persist;
+  DevBuf mvs, mvs_keep, fixed_persist, misc_persist, colour_persist;
   bool live_valid = false;   // a generation is live (a key frame or flat frame has been coded)
   bool live_has_state = false;  // ... and it has coded symbols (a flat frame renews the models without coding any)
   u32 live_stamp = 0, next_stamp = 1;
@@ -231,7 +231,8 @@ static int ensure_codec(scpr_codec* c, int version) {  // CreateCodec + CScreenC
   if (version < 2 || version > 4) return SCPR_E_BAD_VERSION;  // BadVersionException (:1589-1590); version 2 is decode-only here
   const scpr_params& p = c->prm;
   if (p.bits_per_pixel != 16 && p.bits_per_pixel != 24 && p.bits_per_pixel != 32) return SCPR_E_BAD_VERSION;
-  if (p.width < 3 || p.height < 2 || p.width > 8000 || p.workers < 1 || p.height < 2 * p.workers) return SCPR_E_PARAM;
+  // (width: the LDS row ring of the decoder; height: motion-block jobs carry x and y in 13 bits each, scpr_wave.hpp)
+  if (p.width < 3 || p.height < 2 || p.width > 8000 || p.height > 8191 || p.workers < 1 || p.height < 2 * p.workers) return SCPR_E_PARAM;
   // a near window wider than the far one makes the reference code motion symbols below zero (mv + msr_x with |mv| up to msrlow_x,
   // screencap.cpp:691-704, :1206): outside the format
   if (p.low_range_x > std::min<u32>(p.high_range_x, 256) || p.low_range_y > std::min<u32>(p.high_range_y, 256)) return SCPR_E_PARAM;
@@ -327,8 +328,55 @@ static int compact_tables(scpr_codec* c, DevBuf& arena, DevBuf& other, DevBuf& t
   if (*top > first) HIPCHK(hipMemcpyAsync(arena.as<DenseTab>() + first, other.as<DenseTab>() + first, (size_t)(*top - first) * sizeof(DenseTab), hipMemcpyDeviceToDevice, st));
   return SCPR_OK;
 }
+// Block compare and motion search of the P-frames `pfr` of a chunk (DecideBlockTypes / FindMV, screencap.cpp:928-1087, :684-814):
+// leaves binfo / btype / bmv / pinfo for the symbol stages and the vector memory mvs[] as the reference leaves it.  Shared by
+// the encoder and by scpr_motion_prepass, which needs nothing else of a P-frame.
+static int motion_stage(scpr_codec* c, const std::vector<PFrame>& pfr) {
+  const Geom& g = c->g;
+  hipStream_t st = c->stream;
+  const u8* planes = c->planes.as<u8>();
+  const int nbx = (g.W + 15) / 16, nby = (g.H + 15) / 16, nblocks = nbx * nby, np = (int)pfr.size();
+  const MvParams mp{(int)std::min<u32>(c->prm.high_range_x, 256), (int)std::min<u32>(c->prm.high_range_y, 256), (int)c->prm.low_range_x, (int)c->prm.low_range_y};
+  const size_t pb = (size_t)np * nblocks;
+  HIPCHK(c->binfo.reserve(pb * 4));
+  HIPCHK(c->smv.reserve(pb * 4));
+  HIPCHK(c->btype.reserve(pb));
+  HIPCHK(c->bmv.reserve(pb * 4));
+  HIPCHK(hipMemcpyAsync(c->pframes.p, pfr.data(), np * sizeof(PFrame), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemsetAsync(c->pflag.p, 0, (size_t)np * 4, st));
+  const int grp = std::min(64, nbx), ngrp = (nblocks + grp - 1) / grp;
+  HIPCHK(c->gmask.reserve((size_t)np * ngrp * 8));
+  HIPCHK(hipMemsetAsync(c->gmask.p, 0, (size_t)np * ngrp * 8, st));
+  HIPCHK(hipMemsetAsync(c->btype.p, 0, pb, st));       // untouched groups are not visited by k_mvresolve
+  HIPCHK(hipMemsetAsync(c->bmv.p, 0, pb * 4, st));
+  hipLaunchKernelGGL(k_pblocks, dim3((nblocks + 3) / 4, np), dim3(64), 0, st, planes, g, c->pframes.as<PFrame>(), c->binfo.as<u32>(), c->pflag.as<u32>(),
+                     c->gmask.as<unsigned long long>());
+  hipLaunchKernelGGL(k_mvsearch, dim3(nblocks, np), dim3(64), 0, st, planes, g, c->pframes.as<PFrame>(), c->binfo.as<u32>(), mp, c->smv.as<u32>());
+  HIPCHK(c->mvdict.reserve((size_t)np * MVDICT * 4));
+  HIPCHK(c->mvpre.reserve(pb * 4));
+  hipLaunchKernelGGL(k_mvdict, dim3(np), dim3(256), 0, st, g, c->binfo.as<u32>(), c->smv.as<u32>(), c->mvdict.as<u32>());
+  hipLaunchKernelGGL(k_mvpretest, dim3((nblocks + 3) / 4, np), dim3(64), 0, st, planes, g, c->pframes.as<PFrame>(), c->binfo.as<u32>(), mp, c->mvdict.as<u32>(), c->mvpre.as<u32>());
+  if ((size_t)nblocks * 4 <= 150 * 1024 && nblocks + nbx < 0xFFFF) {  // frames pipelined over sixteen waves, the vector memory in LDS
+    const size_t lds = (size_t)nblocks * 4;
+    HIPCHK(hipFuncSetAttribute((const void*)k_mvresolve_pipe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_mvresolve_pipe, dim3(1), dim3(64 * MVP_WAVES), lds, st, planes, g, c->pframes.as<PFrame>(), np, c->binfo.as<u32>(), c->smv.as<u32>(), c->mvdict.as<u32>(),
+                       c->mvpre.as<u32>(), mp, c->mvs.as<u32>(), c->btype.as<u8>(), c->bmv.as<u32>(), c->pinfo.as<int>(), c->gmask.as<unsigned long long>(), c->err.as<u32>());
+  } else {
+    const size_t lds = (size_t)nblocks * 16;  // the frame's block arrays + the vector memory in LDS when they fit
+    const int use_lds = lds <= 150 * 1024 ? 1 : 0;
+    if (use_lds) HIPCHK(hipFuncSetAttribute((const void*)k_mvresolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_mvresolve, dim3(1), dim3(256), use_lds ? lds : 0, st, planes, g, c->pframes.as<PFrame>(), np, c->binfo.as<u32>(), c->smv.as<u32>(), c->mvdict.as<u32>(),
+                       c->mvpre.as<u32>(), mp, c->mvs.as<u32>(), c->btype.as<u8>(), c->bmv.as<u32>(), c->pinfo.as<int>(), c->gmask.as<unsigned long long>(), use_lds);
+  }
+  return SCPR_OK;
+}
+static u64 chunk_total_limit() {  // SCPR_DEBUG_CHUNK_LIMIT: tests reach the re-cut of a chunk with small frames
+  static const u64 v = getenv("SCPR_DEBUG_CHUNK_LIMIT") ? strtoull(getenv("SCPR_DEBUG_CHUNK_LIMIT"), nullptr, 0) : kChunkTotalLimit;
+  return v;
+}
 constexpr int kMaxChunkGens = 512;  // generations per encode chunk (see scpr_compress_batch)
-static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int ngens, bool load_first, std::vector<FrameBase>& hb, std::vector<u32>& pchanged) {
+constexpr int kRecut = 1;  // encode_chunk: the chunk's symbol totals pass 32 bits - nothing has been coded, *nfit frames would fit
+static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int ngens, bool load_first, std::vector<FrameBase>& hb, std::vector<u32>& pchanged, int* nfit) {
   const Geom& g = c->g;
   hipStream_t st = c->stream;
   const u8* planes = c->planes.as<u8>();
@@ -387,39 +435,13 @@ static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int n
   }
   if (np) {
     const size_t pb = (size_t)np * nblocks;
-    HIPCHK(c->binfo.reserve(pb * 4));
-    HIPCHK(c->smv.reserve(pb * 4));
-    HIPCHK(c->btype.reserve(pb));
-    HIPCHK(c->bmv.reserve(pb * 4));
     HIPCHK(c->bcnt.reserve(pb * 4));
     HIPCHK(c->boff.reserve(pb * sizeof(BOff)));
     HIPCHK(c->bflag.reserve(pb * 4));
-    HIPCHK(hipMemcpyAsync(c->pframes.p, pfr.data(), np * sizeof(PFrame), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemsetAsync(c->pflag.p, 0, (size_t)np * 4, st));
-    const int grp = std::min(64, nbx), ngrp = (nblocks + grp - 1) / grp;
-    HIPCHK(c->gmask.reserve((size_t)np * ngrp * 8));
-    HIPCHK(hipMemsetAsync(c->gmask.p, 0, (size_t)np * ngrp * 8, st));
-    HIPCHK(hipMemsetAsync(c->btype.p, 0, pb, st));       // untouched groups are not visited by k_mvresolve
-    HIPCHK(hipMemsetAsync(c->bmv.p, 0, pb * 4, st));
     stage_begin(c, ST_INTER);
-    hipLaunchKernelGGL(k_pblocks, dim3((nblocks + 3) / 4, np), dim3(64), 0, st, planes, g, c->pframes.as<PFrame>(), c->binfo.as<u32>(), c->pflag.as<u32>(),
-                       c->gmask.as<unsigned long long>());
-    hipLaunchKernelGGL(k_mvsearch, dim3(nblocks, np), dim3(64), 0, st, planes, g, c->pframes.as<PFrame>(), c->binfo.as<u32>(), mp, c->smv.as<u32>());
-    HIPCHK(c->mvdict.reserve((size_t)np * MVDICT * 4));
-    HIPCHK(c->mvpre.reserve(pb * 4));
-    hipLaunchKernelGGL(k_mvdict, dim3(np), dim3(256), 0, st, g, c->binfo.as<u32>(), c->smv.as<u32>(), c->mvdict.as<u32>());
-    hipLaunchKernelGGL(k_mvpretest, dim3((nblocks + 3) / 4, np), dim3(64), 0, st, planes, g, c->pframes.as<PFrame>(), c->binfo.as<u32>(), mp, c->mvdict.as<u32>(), c->mvpre.as<u32>());
-    if ((size_t)nblocks * 4 <= 150 * 1024 && nblocks + nbx < 0xFFFF) {  // frames pipelined over sixteen waves, the vector memory in LDS
-      const size_t lds = (size_t)nblocks * 4;
-      HIPCHK(hipFuncSetAttribute((const void*)k_mvresolve_pipe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(k_mvresolve_pipe, dim3(1), dim3(64 * MVP_WAVES), lds, st, planes, g, c->pframes.as<PFrame>(), np, c->binfo.as<u32>(), c->smv.as<u32>(), c->mvdict.as<u32>(),
-                         c->mvpre.as<u32>(), mp, c->mvs.as<u32>(), c->btype.as<u8>(), c->bmv.as<u32>(), c->pinfo.as<int>(), c->gmask.as<unsigned long long>(), c->err.as<u32>());
-    } else {
-      const size_t lds = (size_t)nblocks * 16;  // the frame's block arrays + the vector memory in LDS when they fit
-      const int use_lds = lds <= 150 * 1024 ? 1 : 0;
-      if (use_lds) HIPCHK(hipFuncSetAttribute((const void*)k_mvresolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(k_mvresolve, dim3(1), dim3(256), use_lds ? lds : 0, st, planes, g, c->pframes.as<PFrame>(), np, c->binfo.as<u32>(), c->smv.as<u32>(), c->mvdict.as<u32>(),
-                         c->mvpre.as<u32>(), mp, c->mvs.as<u32>(), c->btype.as<u8>(), c->bmv.as<u32>(), c->pinfo.as<int>(), c->gmask.as<unsigned long long>(), use_lds);
+    {
+      int rc = motion_stage(c, pfr);
+      if (rc != SCPR_OK) return rc;
     }
     hipLaunchKernelGGL(k_pcount, dim3((nblocks + 63) / 64, np), dim3(64), 0, st, planes, g, c->pframes.as<PFrame>(), c->binfo.as<u32>(), c->btype.as<u8>(), c->bcnt.as<u32>());
     hipLaunchKernelGGL(k_pscan, dim3(np), dim3(64), 0, st, g, np, c->btype.as<u8>(), c->bmv.as<u32>(), c->bcnt.as<u32>(), c->pinfo.as<int>(), c->boff.as<BOff>(),
@@ -427,12 +449,14 @@ static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int n
     stage_end(c, ST_INTER);
   }
   hipLaunchKernelGGL(k_bases, dim3(1), dim3(64), 0, st, c->kinds.as<int>(), c->pidx.as<int>(), n, c->frametot.as<u32>(),
-                     c->hdrcnt.as<u32>(), c->ptot.as<u32>(), c->bases.as<FrameBase>(), c->totals.as<u32>());
-  u32 tot[4];
+                     c->hdrcnt.as<u32>(), c->ptot.as<u32>(), c->bases.as<FrameBase>(), c->totals.as<u32>(), chunk_total_limit());
+  u32 tot[5];
   HIPCHK(hipMemcpyAsync(hb.data(), c->bases.p, n * sizeof(FrameBase), hipMemcpyDeviceToHost, st));
   HIPCHK(hipMemcpyAsync(tot, c->totals.p, sizeof tot, hipMemcpyDeviceToHost, st));
   if (np) HIPCHK(hipMemcpyAsync(pchanged.data(), c->pflag.p, (size_t)np * 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
+  *nfit = (int)tot[4];
+  if (*nfit < n) return kRecut;  // (the 32-bit bases of the frames past *nfit have wrapped: the caller cuts the chunk there)
   const size_t Rtot = tot[0], Ttot = tot[1], Ctot = tot[2], Mtot = tot[3];
   const size_t nchains = (size_t)ngens * NCOLCTX;
   HIPCHK(c->runs.reserve(Rtot * 4 + 64));
@@ -656,7 +680,7 @@ void scpr_destroy(scpr_codec* c) {
   DevBuf* all[] = {&c->planes, &c->tnmap, &c->exitmap, &c->entry, &c->runrec, &c->tilecnt, &c->tileoff, &c->hdrrec, &c->hdrcnt, &c->frametot, &c->flags, &c->slotlist, &c->genlist,
                    &c->bases, &c->totals, &c->runs, &c->runpos, &c->keys[0], &c->keys[1], &c->vals[0], &c->vals[1], &c->cstart, &c->sorttmp,
                    &c->entries, &c->ranges, &c->rblocks, &c->rscratch, &c->rsize, &c->packets, &c->pktoff, &c->blkdst, &c->outsizes, &c->total64, &c->arena,
-                   &c->arena_top, &c->err, &c->rcp, &c->decframes, &c->decstates, &c->hoststage_in, &c->hoststage_out, &c->chainlists, &c->chaincounts, &c->kinds, &c->pidx, &c->fidx, &c->pframes, &c->pflag, &c->binfo, &c->smv, &c->btype, &c->bmv, &c->bcnt, &c->boff, &c->bflag, &c->pinfo, &c->ptot, &c->pbase, &c->misc, &c->miscpos, &c->miscranges, &c->mvs, &c->fixed_persist, &c->misc_persist, &c->colour_persist, &c->decgops, &c->decfixed, &c->dec_fixed_persist, &c->dec_colour_persist, &c->dec_arena, &c->dec_arena2, &c->arena2, &c->dec_arena_top, &c->mvdict, &c->mvpre, &c->gmask};
+                   &c->arena_top, &c->err, &c->rcp, &c->decframes, &c->decstates, &c->hoststage_in, &c->hoststage_out, &c->chainlists, &c->chaincounts, &c->kinds, &c->pidx, &c->fidx, &c->pframes, &c->pflag, &c->binfo, &c->smv, &c->btype, &c->bmv, &c->bcnt, &c->boff, &c->bflag, &c->pinfo, &c->ptot, &c->pbase, &c->misc, &c->miscpos, &c->miscranges, &c->mvs, &c->mvs_keep, &c->fixed_persist, &c->misc_persist, &c->colour_persist, &c->decgops, &c->decfixed, &c->dec_fixed_persist, &c->dec_colour_persist, &c->dec_arena, &c->dec_arena2, &c->arena2, &c->dec_arena_top, &c->mvdict, &c->mvpre, &c->gmask};
   for (DevBuf* b : all) b->release();
   for (int s = 0; s < ST_COUNT + 1; s++)
     for (int k = 0; k < 2; k++) (void)hipEventDestroy(c->ev[s][k]);
@@ -691,6 +715,140 @@ int scpr_seed_shard(scpr_codec* c, uint32_t frames_before, int last_was_flat, ui
     c->dec_live = false;
   }
   return SCPR_OK;
+}
+
+// The vector memory mvs[] (screencap.cpp:96-97): calloc'd by Init, written by every motion search that finds a vector, read as
+// "the vector of the block above" by every later P-frame (:726-735) and never reset - RenewI (:178-198) touches models only.  It is
+// the one piece of encoder state that crosses key frames besides the flat-frame memory, so a shard that does not start the stream
+// needs it handed over (sharding.py, handover_mv_memory).
+int scpr_export_mv_memory(scpr_codec* c, int32_t* mx, int32_t* my) {
+  if (!c || !c->inited || !mx || !my) return SCPR_E_PARAM;
+  if (hipSetDevice(c->device) != hipSuccess) return SCPR_E_DEVICE;
+  int rc = ensure_codec(c, c->have_codec ? c->version : 4);
+  if (rc != SCPR_OK) return rc;
+  const int nblocks = ((c->g.W + 15) / 16) * ((c->g.H + 15) / 16);
+  std::vector<u32> h(nblocks);
+  HIPCHK(hipMemcpyAsync(h.data(), c->mvs.p, (size_t)nblocks * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  for (int i = 0; i < nblocks; i++) mx[i] = (int16_t)(h[i] & 0xFFFF), my[i] = (int16_t)(h[i] >> 16);
+  return nblocks;
+}
+
+int scpr_import_mv_memory(scpr_codec* c, const int32_t* mx, const int32_t* my) {
+  if (!c || !c->inited || !mx || !my) return SCPR_E_PARAM;
+  if (hipSetDevice(c->device) != hipSuccess) return SCPR_E_DEVICE;
+  int rc = ensure_codec(c, c->have_codec ? c->version : 4);
+  if (rc != SCPR_OK) return rc;
+  const int nblocks = ((c->g.W + 15) / 16) * ((c->g.H + 15) / 16);
+  std::vector<u32> h(nblocks);
+  for (int i = 0; i < nblocks; i++) {
+    if (mx[i] < -256 || mx[i] > 256 || my[i] < -256 || my[i] > 256) return SCPR_E_PARAM;  // (msr_x = msr_y = min(high_range, 256), :76-80)
+    h[i] = ((u32)(mx[i] & 0xFFFF)) | ((u32)(my[i] & 0xFFFF) << 16);
+  }
+  HIPCHK(hipMemcpyAsync(c->mvs.p, h.data(), (size_t)nblocks * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return nblocks;
+}
+
+// What scpr_compress_batch would leave in mvs[] after these frames, without coding them: conversion, loss mask, frame-type
+// decisions, block compare and the motion search - the only stages mvs[] depends on (DecideBlockTypes / FindMV read planes and
+// mvs[] and nothing of the models).  The codec is left exactly as it was (planes of the chunk slots are scratch).
+int scpr_motion_prepass(scpr_codec* c, const void* d_frames, int nframes, const int* ftypes, int loss, int32_t* mx, int32_t* my) {
+  if (!c || !c->inited || !d_frames || !ftypes || !mx || !my || nframes < 0) return SCPR_E_PARAM;
+  if (hipSetDevice(c->device) != hipSuccess) return SCPR_E_DEVICE;
+  if (c->have_codec && c->version == 2) return SCPR_E_BAD_VERSION;
+  int rc = ensure_codec(c, c->have_codec ? c->version : 4);
+  if (rc != SCPR_OK) return rc;
+  const Geom& g = c->g;
+  hipStream_t st = c->stream;
+  const int nblocks = ((g.W + 15) / 16) * ((g.H + 15) / 16);
+  const int loss_before = c->last_loss;
+  if (loss != c->last_loss) setup_loss(c, loss);
+  const size_t frame_bytes = (size_t)c->pitch_in * g.H;
+  // saved: the vector memory and the previous frame of the stream
+  DevBuf keep;
+  HIPCHK(keep.reserve((size_t)nblocks * 4 + g.plane_stride));
+  HIPCHK(hipMemcpyAsync(keep.p, c->mvs.p, (size_t)nblocks * 4, hipMemcpyDeviceToDevice, st));
+  HIPCHK(hipStreamSynchronize(st));
+  struct Restore {  // (every return below leaves the codec as it was)
+    scpr_codec* c;
+    DevBuf& keep;
+    int nblocks, loss_before;
+    bool planes_saved = false;
+    ~Restore() {
+      (void)hipMemcpyAsync(c->mvs.p, keep.p, (size_t)nblocks * 4, hipMemcpyDeviceToDevice, c->stream);
+      if (planes_saved)
+        (void)hipMemcpyAsync(c->planes.as<u8>() + (size_t)c->pslot * c->g.plane_stride, (u8*)keep.p + (size_t)nblocks * 4, c->g.plane_stride, hipMemcpyDeviceToDevice, c->stream);
+      (void)hipStreamSynchronize(c->stream);
+      keep.release();
+      if (loss_before != c->last_loss) setup_loss(c, loss_before);
+    }
+  } restore{c, keep, nblocks, loss_before};
+  u32 frames_done = c->frames_done;
+  HIPCHK(hipMemsetAsync(c->err.p, 0, 32, st));
+  // chunks no larger than the encoder's, and small enough that the block arrays of the chunk stay modest
+  const int chunk = std::max(1, std::min(c->slots, 256));
+  for (int f0 = 0; f0 < nframes; f0 += chunk) {
+    const int n = std::min(chunk, nframes - f0);
+    if ((rc = ensure_planes(c, (size_t)n)) != SCPR_OK) return rc;  // (carries the previous frame over when it grows)
+    if (!restore.planes_saved) {
+      HIPCHK(hipMemcpyAsync((u8*)keep.p + (size_t)nblocks * 4, c->planes.as<u8>() + (size_t)c->pslot * g.plane_stride, g.plane_stride, hipMemcpyDeviceToDevice, st));
+      restore.planes_saved = true;
+    }
+    const size_t ns = (size_t)n + 1;
+    HIPCHK(c->flags.reserve(ns * 8));
+    HIPCHK(c->slotlist.reserve(ns * 4));
+    HIPCHK(c->pframes.reserve(ns * sizeof(PFrame)));
+    HIPCHK(c->pflag.reserve(ns * 4));
+    HIPCHK(c->pinfo.reserve(ns * 8));
+    const u8* src = (const u8*)d_frames + (size_t)f0 * frame_bytes;
+    u32* d_nonflat = c->flags.as<u32>();
+    u32* d_first = d_nonflat + n;
+    HIPCHK(hipMemsetAsync(d_nonflat, 0, (size_t)n * 8, st));
+    if (c->bpp == 4) {
+      dim3 gr((g.H * ((g.W + 3) >> 2) + 256 * PACK_ITEMS - 1) / (256 * PACK_ITEMS), n);
+      hipLaunchKernelGGL(k_pack32, gr, dim3(256), 0, st, src, c->planes.as<u8>(), g, d_nonflat, d_first);
+    } else if (c->bpp == 3) {
+      dim3 gr((g.H * (g.S >> 2) + 256 * PACK_ITEMS - 1) / (256 * PACK_ITEMS), n);
+      hipLaunchKernelGGL(k_pack24, gr, dim3(256), 0, st, src, c->planes.as<u8>(), g, d_nonflat, d_first);
+    } else {
+      dim3 gr((g.H * g.W + 256 * PACK_ITEMS - 1) / (256 * PACK_ITEMS), n);
+      hipLaunchKernelGGL(k_pack16, gr, dim3(256), 0, st, src, c->planes.as<u8>(), g, d_nonflat, d_first, c->prm.red_mask, c->prm.green_mask, c->prm.blue_mask, c->rs, c->gs,
+                         c->bs);
+    }
+    std::vector<u32> hflags((size_t)n * 2);
+    HIPCHK(hipMemcpyAsync(hflags.data(), d_nonflat, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    // P-frame iff the picture is not flat, a frame has been coded and the caller allows it (screencap.cpp:1488-1511)
+    std::vector<PFrame> pfr;
+    std::vector<int> lossslots;
+    for (int i = 0; i < n; i++) {
+      if (hflags[i] == 0) continue;  // flat frame: 4 bytes, fn not incremented
+      lossslots.push_back(i);
+      if (frames_done && ftypes[f0 + i]) pfr.push_back({i, i > 0 ? i - 1 : c->pslot});
+      frames_done++;
+    }
+    if (c->loss_mask != 0xFFFFFFFFu && !lossslots.empty()) {
+      HIPCHK(hipMemcpyAsync(c->slotlist.p, lossslots.data(), lossslots.size() * 4, hipMemcpyHostToDevice, st));
+      dim3 gl((g.H * (g.S >> 2) + 255) / 256, (unsigned)lossslots.size());
+      hipLaunchKernelGGL(k_loss, gl, dim3(256), 0, st, c->planes.as<u8>(), g, c->slotlist.as<int>(), c->loss_mask, c->corr_mask);
+    }
+    if (!pfr.empty() && (rc = motion_stage(c, pfr)) != SCPR_OK) return rc;
+    HIPCHK(hipMemcpyAsync(c->planes.as<u8>() + (size_t)c->pslot * g.plane_stride, c->planes.as<u8>() + (size_t)(n - 1) * g.plane_stride, g.plane_stride, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));  // (pfr / lossslots are host memory)
+    HIPCHK(hipGetLastError());
+  }
+  u32 err = 0;
+  std::vector<u32> h(nblocks);
+  HIPCHK(hipMemcpyAsync(h.data(), c->mvs.p, (size_t)nblocks * 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(&err, c->err.p, 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  if (err & 8) {
+    fprintf(stderr, "[scpr] motion-vector pipeline stalled\n");
+    return SCPR_E_DEVICE;
+  }
+  for (int i = 0; i < nblocks; i++) mx[i] = (int16_t)(h[i] & 0xFFFF), my[i] = (int16_t)(h[i] >> 16);
+  return nblocks;
 }
 
 int64_t scpr_compress_batch(scpr_codec* c, const void* d_frames, int nframes, int* ftypes, int loss, void* d_out, size_t out_capacity, uint32_t* sizes) {
@@ -733,73 +891,93 @@ int64_t scpr_compress_batch(scpr_codec* c, const void* d_frames, int nframes, in
     HIPCHK(hipMemcpyAsync(hflags.data(), d_nonflat, (size_t)n * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
 
-    // frame-type decisions: CScreenCapt::CompressFrame, screencap.cpp:1488-1511
-    std::vector<ChunkFrame> cf(n);
-    int ngens = 0;
-    bool load_first = false;
-    for (int i = 0; i < n; i++) {
-      ChunkFrame& fr = cf[i];
-      const bool flat = hflags[i] == 0;
-      const u32 rgb = hflags[npacked + i] & 0xFFFFFFu;
-      // The colour symbols are partitioned by a radix sort over (generation, context): bits 8 .. 22 + log2(generations).
-      // rocPRIM 4.2 (ROCm 7.2) returns UNSORTED output for a bit range that ends at bit 32 when the input has ~10^5 elements
-      // (its merge-sort path: tools/rocprim_sort_check.hip; 10^3 and 2*10^6 elements are fine), so a chunk stops before its
-      // 513th generation and the sort never sees bit 31.
-      const bool starts_gen = flat ? !(c->last_flat && c->last_flat_rgb == rgb) : !(c->frames_done && ftypes[f0 + i]);
-      if (starts_gen && ngens == kMaxChunkGens) {
-        n = i;
-        break;
-      }
-      if (flat) {
-        fr.kind = 1;
-        fr.hdr_len = 4;
-        fr.hdr = (u32)(1 + (c->version - 1) * 16) | (rgb << 8);
-        if (!(c->last_flat && c->last_flat_rgb == rgb)) {  // :1490-1494: prev := this frame, models renewed
-          fr.gen = ngens++;
-          c->live_valid = true;
-        } else {
-          fr.gen = -1;
-        }
-        c->last_flat = true;
-        c->last_flat_rgb = rgb;
-        ftypes[f0 + i] = 0;
-        continue;
-      }
-      c->last_flat = false;
-      if (c->frames_done && ftypes[f0 + i]) {
-        fr.kind = 2;
-        fr.hdr_len = 1;
-        fr.hdr = 1;
-        if (ngens == 0) {  // continues the generation that was live when the call started
-          ngens = 1;
-          load_first = c->live_valid && c->live_has_state;
-        }
-        fr.gen = ngens - 1;
-        ftypes[f0 + i] = 1;
-      } else {
-        fr.kind = 0;
-        fr.hdr_len = 1;
-        fr.hdr = (u32)(2 + (c->version - 1) * 16);
-        fr.gen = ngens++;
-        c->live_valid = true;
-        ftypes[f0 + i] = 0;
-      }
-      c->frames_done++;
-    }
-    cf.resize(n);
-    used = n;
-    // a flat frame that renews the models starts a generation of its own; if it is first in the chunk nothing is loaded
-    const bool any_gen = ngens > 0;
-    if (ngens == 0) ngens = 1, load_first = c->live_valid && c->live_has_state;
-    if (any_gen) {  // does the generation that is live after this chunk hold coded symbols?
-      bool coded = false;
-      for (int i = 0; i < n; i++) coded |= cf[i].kind != 1 && cf[i].gen == ngens - 1;
-      c->live_has_state = coded;
-    }
+    // frame-type decisions: CScreenCapt::CompressFrame, screencap.cpp:1488-1511 - and once more over fewer frames if the
+    // chunk's symbol totals turn out to pass 32 bits (k_bases; noise-like content only: ~5 symbols per pixel)
+    std::vector<ChunkFrame> cf;
     std::vector<FrameBase> hb;
     std::vector<u32> pchanged;
-    rc = encode_chunk(c, n, cf, ngens, load_first, hb, pchanged);
-    if (rc != SCPR_OK) return rc;
+    int ngens = 0;
+    bool load_first = false;
+    const u32 s_frames_done = c->frames_done, s_flat_rgb = c->last_flat_rgb;
+    const bool s_flat = c->last_flat, s_live_valid = c->live_valid, s_live_has_state = c->live_has_state;
+    const int nblk = ((g.W + 15) / 16) * ((g.H + 15) / 16);
+    HIPCHK(c->mvs_keep.reserve((size_t)nblk * 4));
+    HIPCHK(hipMemcpyAsync(c->mvs_keep.p, c->mvs.p, (size_t)nblk * 4, hipMemcpyDeviceToDevice, st));  // (the motion stage of a chunk that is cut again has moved it on)
+    for (;;) {
+      cf.assign(n, ChunkFrame{});
+      ngens = 0;
+      load_first = false;
+      for (int i = 0; i < n; i++) {
+        ChunkFrame& fr = cf[i];
+        const bool flat = hflags[i] == 0;
+        const u32 rgb = hflags[npacked + i] & 0xFFFFFFu;
+        // The colour symbols are partitioned by a radix sort over (generation, context): bits 8 .. 22 + log2(generations).
+        // rocPRIM 4.2 (ROCm 7.2) returns UNSORTED output for a bit range that ends at bit 32 when the input has ~10^5 elements
+        // (its merge-sort path: tools/rocprim_sort_check.hip; 10^3 and 2*10^6 elements are fine), so a chunk stops before its
+        // 513th generation and the sort never sees bit 31.
+        const bool starts_gen = flat ? !(c->last_flat && c->last_flat_rgb == rgb) : !(c->frames_done && ftypes[f0 + i]);
+        if (starts_gen && ngens == kMaxChunkGens) {
+          n = i;
+          break;
+        }
+        if (flat) {
+          fr.kind = 1;
+          fr.hdr_len = 4;
+          fr.hdr = (u32)(1 + (c->version - 1) * 16) | (rgb << 8);
+          if (!(c->last_flat && c->last_flat_rgb == rgb)) {  // :1490-1494: prev := this frame, models renewed
+            fr.gen = ngens++;
+            c->live_valid = true;
+          } else {
+            fr.gen = -1;
+          }
+          c->last_flat = true;
+          c->last_flat_rgb = rgb;
+          ftypes[f0 + i] = 0;
+          continue;
+        }
+        c->last_flat = false;
+        if (c->frames_done && ftypes[f0 + i]) {
+          fr.kind = 2;
+          fr.hdr_len = 1;
+          fr.hdr = 1;
+          if (ngens == 0) {  // continues the generation that was live when the call started
+            ngens = 1;
+            load_first = c->live_valid && c->live_has_state;
+          }
+          fr.gen = ngens - 1;
+          ftypes[f0 + i] = 1;
+        } else {
+          fr.kind = 0;
+          fr.hdr_len = 1;
+          fr.hdr = (u32)(2 + (c->version - 1) * 16);
+          fr.gen = ngens++;
+          c->live_valid = true;
+          ftypes[f0 + i] = 0;
+        }
+        c->frames_done++;
+      }
+      cf.resize(n);
+      used = n;
+      // a flat frame that renews the models starts a generation of its own; if it is first in the chunk nothing is loaded
+      const bool any_gen = ngens > 0;
+      if (ngens == 0) ngens = 1, load_first = c->live_valid && c->live_has_state;
+      if (any_gen) {  // does the generation that is live after this chunk hold coded symbols?
+        bool coded = false;
+        for (int i = 0; i < n; i++) coded |= cf[i].kind != 1 && cf[i].gen == ngens - 1;
+        c->live_has_state = coded;
+      }
+      int nfit = n;
+      rc = encode_chunk(c, n, cf, ngens, load_first, hb, pchanged, &nfit);
+      if (rc == kRecut) {
+        if (nfit < 1) return SCPR_E_DEVICE;  // (one frame always fits: 5 symbols per pixel of at most 8000 x 8191 pixels)
+        c->frames_done = s_frames_done, c->last_flat_rgb = s_flat_rgb, c->last_flat = s_flat, c->live_valid = s_live_valid, c->live_has_state = s_live_has_state;
+        HIPCHK(hipMemcpyAsync(c->mvs.p, c->mvs_keep.p, (size_t)nblk * 4, hipMemcpyDeviceToDevice, st));
+        n = nfit;
+        continue;
+      }
+      if (rc != SCPR_OK) return rc;
+      break;
+    }
     // the last plane of the chunk is the "previous frame" of the next call
     HIPCHK(hipMemcpyAsync(c->planes.as<u8>() + (size_t)c->pslot * g.plane_stride, c->planes.as<u8>() + (size_t)(n - 1) * g.plane_stride, g.plane_stride, hipMemcpyDeviceToDevice, st));
 

@@ -544,19 +544,24 @@ __global__ __launch_bounds__(256) void k_scan_tiles(const u32* __restrict__ tile
 }
 
 // per batch: frame bases (one thread).  kinds: 0 key frame, 1 flat (no symbols), 2 P-frame
+constexpr u64 kChunkTotalLimit = 0xFFFF0000ull;  // runs / coder entries / colour symbols / P-frame symbols of one encode chunk (32-bit positions)
 struct FrameBase {
   u32 run_base, sym_base, col_base, misc_base, nruns, nsyms, ncol, nmisc, hdr_runs, nbt, pad0, pad1;
 };
 __global__ void k_bases(const int* __restrict__ kinds, const int* __restrict__ pidx, int nfr, const u32* __restrict__ frametot,
-                        const u32* __restrict__ hdrcnt, const u32* __restrict__ ptot, FrameBase* __restrict__ bases, u32* __restrict__ totals) {
+                        const u32* __restrict__ hdrcnt, const u32* __restrict__ ptot, FrameBase* __restrict__ bases, u32* __restrict__ totals, u64 limit) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  u32 rb = 0, sb = 0, cb = 0, mb = 0;
+  // Bases are 32-bit (stream positions travel through the sort as 32-bit values), the sums are kept in 64 bits: totals[4] =
+  // the number of leading frames whose bases and totals all stay below 2^32 - the host cuts the chunk there and codes the
+  // rest in the next one (an incompressible 1080p frame has ~10 M symbols: 413 of them, or 103 at 4K, pass 2^32).
+  u64 rb = 0, sb = 0, cb = 0, mb = 0;
+  u32 nfit = (u32)nfr;
   for (int i = 0; i < nfr; i++) {
     FrameBase b;
-    b.run_base = rb;
-    b.sym_base = sb;
-    b.col_base = cb;
-    b.misc_base = mb;
+    b.run_base = (u32)rb;
+    b.sym_base = (u32)sb;
+    b.col_base = (u32)cb;
+    b.misc_base = (u32)mb;
     b.nruns = b.nsyms = b.ncol = b.nmisc = b.hdr_runs = b.nbt = b.pad0 = b.pad1 = 0;
     if (kinds[i] == 0) {
       const int slot = i;  // planes of a chunk sit in slots 0..n-1
@@ -578,11 +583,14 @@ __global__ void k_bases(const int* __restrict__ kinds, const int* __restrict__ p
     sb += b.nsyms;
     cb += b.ncol;
     mb += b.nmisc;
+    const u64 most = max(max(rb, sb), max(cb, mb));
+    if (most >= limit && nfit == (u32)nfr) nfit = (u32)i;
   }
-  totals[0] = rb;
-  totals[1] = sb;
-  totals[2] = cb;
-  totals[3] = mb;
+  totals[0] = (u32)rb;
+  totals[1] = (u32)sb;
+  totals[2] = (u32)cb;
+  totals[3] = (u32)mb;
+  totals[4] = nfit;
 }
 
 // colour context ids from the two previous bytes (SC_CXSHIFT = 2, MAKECX1,

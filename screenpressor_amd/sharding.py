@@ -6,13 +6,16 @@ contiguous GOP ranges, one per rank; each rank encodes its range as an independe
 the packets are gathered to rank 0 in frame order.  No collective touches the data path until
 that gather.
 
-Two pieces of state do cross key frames in the reference.  (1) The flat-frame rule compares with the previous
+Three pieces of state do cross key frames in the reference.  (1, 2) The flat-frame rule compares with the previous
 flat frame and P-frames need "a frame has been coded" (last_was_flat / last_flat_clr / fn, screencap.cpp:1490-1504):
 `shard_seed` computes that state from the frames right before a cut and `scpr_seed_shard` installs it, so a shard
-that starts at or after a repeated flat colour produces the single stream's bytes.  (2) The reference's motion search also remembers, per block, the last vector found in ANY
-earlier frame (mvs[], screencap.cpp:96-97, :726-735, never reset), so a shard is byte-identical
-to the reference run on that shard's frames from a fresh codec, not to a single process that
-encoded the whole stream.  Key-frame-only streams have no such memory and shard exactly.
+that starts at or after a repeated flat colour produces the single stream's bytes.  (3) The motion search remembers, per
+block, the last vector found in ANY earlier frame (mvs[], screencap.cpp:96-97; read as "the vector of the block above",
+:726-735; never reset - RenewI :178-198 touches models only).  `handover_mv_memory` passes it down the ranks before
+anything is coded: rank r takes the memory rank r-1's shard leaves behind, runs the motion-only pre-pass over its own
+shard (scpr_motion_prepass: conversion, block compare, motion search - a few per cent of an encode) and passes the
+result on; then every rank imports what it received and all ranks code their shards side by side.  With (1)-(3) seeded
+a shard's packets are the single stream's packets.
 """
 from __future__ import annotations
 
@@ -68,6 +71,28 @@ def shard_seed(get_frame, lo: int, width: int, height: int, bpp: int):
     return coded, last is not None, (last or 0)
 
 
+def handover_mv_memory(dist, rank: int, world: int, nblocks: int, prepass, device=None) -> np.ndarray:
+    """The motion-vector memory this rank's shard starts from, as a (2, nblocks) int32 array (x row, y row).
+
+    `prepass(mv_in) -> mv_out`: the memory after this rank's shard when it starts from `mv_in` (ScreenCodec.ImportMvMemory +
+    MotionPrepass on the GPU; any codec that can do the same in the CPU tests).  The last rank never runs it.  The chain
+    is serial by nature (shard r's vectors depend on shard r-1's); one broadcast per link rather than send/recv pairs: a
+    collective every backend has, no pairwise communicators to set up, and the payload is 8 bytes per block (260 KB at
+    3840x2160).  Rank 0 starts from zeros (calloc, screencap.cpp:96-97)."""
+    import torch
+    buf = torch.zeros(2 * nblocks, dtype=torch.int32, device=device if device is not None else "cpu")
+    mine = np.zeros((2, nblocks), dtype=np.int32)
+    for src in range(world - 1):  # link src -> src + 1
+        if rank == src:
+            out = np.ascontiguousarray(prepass(mine), dtype=np.int32).reshape(-1)
+            assert out.size == 2 * nblocks
+            buf.copy_(torch.from_numpy(out))
+        dist.broadcast(buf, src=src)
+        if rank == src + 1:
+            mine = buf.cpu().numpy().reshape(2, nblocks).copy()
+    return mine
+
+
 def gather_packets(dist, rank: int, world: int, payload: np.ndarray, sizes: np.ndarray, device=None):
     """Rank 0 receives every rank's packets and per-frame sizes, in rank (= frame) order.
     `payload` is a uint8 array (numpy on CPU/gloo, or a torch tensor on the GPU for RCCL)."""
@@ -78,19 +103,18 @@ def gather_packets(dist, rank: int, world: int, payload: np.ndarray, sizes: np.n
         t_payload, t_sizes = t_payload.to(device), t_sizes.to(device)
     meta = torch.tensor([t_payload.numel(), t_sizes.numel()], dtype=torch.int64, device=t_payload.device)
     metas = [torch.zeros_like(meta) for _ in range(world)]
-    dist.all_gather(metas, meta)
+    dist.all_gather(metas, meta)  # every rank learns every rank's byte and frame count (16 bytes each) ...
     max_bytes = int(max(int(m[0]) for m in metas))
     max_frames = int(max(int(m[1]) for m in metas))
     pad_p = torch.zeros(max_bytes, dtype=torch.uint8, device=t_payload.device)
     pad_p[: t_payload.numel()] = t_payload
     pad_s = torch.zeros(max_frames, dtype=torch.int64, device=t_payload.device)
     pad_s[: t_sizes.numel()] = t_sizes
-    # all_gather rather than gather: the one collective every backend (RCCL included) implements natively; the
-    # payload is the compressed stream (about 1 % of the raw frames), so the extra copies cost microseconds
-    gp = [torch.empty_like(pad_p) for _ in range(world)]
-    gs = [torch.empty_like(pad_s) for _ in range(world)]
-    dist.all_gather(gp, pad_p)
-    dist.all_gather(gs, pad_s)
+    # ... and the packets themselves travel to rank 0 only (sizes, then a gather of the chunks to rank 0)
+    gp = [torch.empty_like(pad_p) for _ in range(world)] if rank == 0 else None
+    gs = [torch.empty_like(pad_s) for _ in range(world)] if rank == 0 else None
+    dist.gather(pad_p, gather_list=gp, dst=0)
+    dist.gather(pad_s, gather_list=gs, dst=0)
     if rank != 0:
         return None, None
     out_p = torch.cat([gp[r][: int(metas[r][0])] for r in range(world)])

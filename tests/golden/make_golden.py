@@ -6,6 +6,8 @@ Provenance: the reference cannot be built in this image (every translation unit 
 CPU restatement of the reference algorithm) on seeded synthetic input.  They pin the
 oracle against regressions and give the GPU box byte-level targets that do not depend on
 the oracle being rebuilt there.  Re-run:  python tests/golden/make_golden.py
+`--streams` also recomputes the sha256 of the FULL streams bench.py times (300 frames of 1080p, 150 / 1200 frames of 4K: a few
+minutes of rendering and CPU coding); without it those entries are carried over from the manifest as they are.
 """
 import hashlib
 import json
@@ -43,6 +45,51 @@ V3_CASES = [("desktop_100x37_v3_ip", 100, 37, 32, 7, (0, 4), 11, 0.0, 1, 0, True
 CASES_ALL = CASES + V2_CASES + V3_CASES
 
 
+# The full streams of bench.py (BASELINE configs[1]-[4]; hashes only): name, width, height, bpp, frames, key interval, seed.
+# bench.py compares the sha256 of the packets of its timed run with these (`golden_stream_ok`), so parity of a whole timed
+# stream does not hang on running the CPU over a sample of it on the GPU box.
+STREAMS = [
+    ("stream_1080p_keys_300", 1920, 1080, 32, 300, 1, 1),        # configs[1]; configs[4] (RGB24 input) must give the same stream
+    ("stream_1080p_ip_k50_300", 1920, 1080, 32, 300, 50, 1),     # configs[2], key frame every 50
+    ("stream_1080p_ip_onegop_300", 1920, 1080, 32, 300, 300, 1),  # configs[2] as one GOP
+    ("stream_4k_keys_150", 3840, 2160, 32, 150, 1, 1),           # configs[3], one GPU's share as key frames
+    ("stream_4k_ip_k150_1200", 3840, 2160, 32, 1200, 150, 1),    # configs[3]: the whole stream (its first GOP = the one-GOP share)
+]
+
+
+def _render_job(job):
+    w, h, seed, bpp, t0, t1 = job
+    seq = DesktopSequence(w, h, seed=seed)
+    return np.stack([np.ascontiguousarray(seq.frame(t) if bpp == 32 else pack24(seq.frame24(t))).reshape(-1) for t in range(t0, t1)])
+
+
+def stream_hash(case, nproc=8):
+    """ONE oracle codec over the whole stream, frames rendered a few at a time by a pool; sha256 of all packets, of every
+    GOP's packets (a sharded run can be checked rank by rank, a shorter run by prefix) and the total size"""
+    import multiprocessing as mp
+    name, w, h, bpp, n, k, seed = case
+    enc = O.OracleCodec(w, h, bpp)
+    per = 4 if w > 1920 else 10
+    jobs = [(w, h, seed, bpp, a, min(n, a + per)) for a in range(0, n, per)]
+    whole, gop, gops, total, sizes_head = hashlib.sha256(), None, [], 0, []
+    with mp.get_context("spawn").Pool(nproc) as pool:
+        for job, block in zip(jobs, pool.imap(_render_job, jobs)):
+            for i, t in enumerate(range(job[4], job[5])):
+                if t % k == 0:
+                    if gop is not None:
+                        gops.append(gop.hexdigest())
+                    gop = hashlib.sha256()
+                data, _ = enc.compress(block[i], key=(t % k == 0))
+                whole.update(data)
+                gop.update(data)
+                total += len(data)
+                if t < 8:
+                    sizes_head.append(len(data))
+    gops.append(gop.hexdigest())
+    return {"kind": "stream_hash", "width": w, "height": h, "bpp": bpp, "frames": n, "key_interval": k, "seed": seed, "workers": 1, "loss": 0, "version": 4,
+            "bytes": total, "sha256": whole.hexdigest(), "gop_sha256": gops if k > 1 else None, "first_sizes": sizes_head}
+
+
 def to_rgb16(f24, w, h):
     """RGB555 rows back to back (the layout the reference's compress side reads)"""
     c = f24.astype(np.uint16) >> 3
@@ -71,6 +118,20 @@ def frames_of(case):
 
 def main():
     manifest = {}
+    try:  # the full-stream hashes are carried over unless --streams asks for them again
+        old = json.load(open(os.path.join(HERE, "manifest.json")))
+        manifest.update({k: v for k, v in old.items() if v.get("kind") == "stream_hash"})
+    except Exception:  # noqa: BLE001
+        pass
+    if "--streams" in sys.argv:
+        for case in STREAMS:
+            manifest[case[0]] = stream_hash(case)
+            print(case[0], manifest[case[0]]["bytes"], manifest[case[0]]["sha256"][:16], flush=True)
+        if "--streams-only" in sys.argv:
+            old.update(manifest)
+            with open(os.path.join(HERE, "manifest.json"), "w") as fh:
+                json.dump(old, fh, indent=1)
+            return
     for case in CASES_ALL:
         name, w, h, bpp, n, keys, seed, noise, workers, loss, keep = case
         version = 2 if case in V2_CASES else 3 if case in V3_CASES else 4

@@ -38,6 +38,8 @@ def lib():
         L.spo_decompress_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int]
         L.spo_crash_happened.argtypes = [C.c_void_p]
         L.spo_seed_shard.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_uint32]
+        L.spo_export_mv_memory.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.spo_import_mv_memory.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.spo_tap_entries.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.spo_tap_tags.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.spo_tap_blocks.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
@@ -99,6 +101,15 @@ class OracleCodec:
 
     def seed_shard(self, frames_before, last_flat, rgb):
         lib().spo_seed_shard(self.h_, frames_before, 1 if last_flat else 0, rgb)
+
+    def export_mv_memory(self):
+        mv = np.zeros((2, self.nblocks), dtype=np.int32)
+        assert lib().spo_export_mv_memory(self.h_, _ptr(mv[0]), _ptr(mv[1]), self.nblocks) == self.nblocks
+        return mv
+
+    def import_mv_memory(self, mv):
+        mv = np.ascontiguousarray(mv, dtype=np.int32).reshape(2, self.nblocks)
+        assert lib().spo_import_mv_memory(self.h_, _ptr(mv[0]), _ptr(mv[1]), self.nblocks) == self.nblocks
 
     def decompress(self, data, ftype, pitch=None):
         pitch = self.pitch if pitch is None else pitch

@@ -48,6 +48,17 @@ int main(int argc, char** argv) {
     threw = e.version == 6;
   }
   if (!threw) return 5;
+  // a parameter set the library refuses (near window wider than the far one): Init does not throw (the reference's only stores
+  // the parameters), the frame calls return 0 as for any refusal, and LastError() names the code
+  CodecParameters odd = prm;
+  odd.high_range_x = 4, odd.low_range_x = 8;
+  ScreenCodec e3;
+  e3.Init(&odd);
+  int ft3 = 0;
+  if (e3.CompressFrame(&src[0], &dst[0], (int)dst.size(), ft3, 0) != 0 || e3.LastError() != SCPR_E_PARAM) return 6;
+  BYTE key4[8] = {0x32, 0, 0, 0, 0, 0, 0, 0};  // a version 4 key frame header
+  if (e3.DecompressFrame(key4, 8, &out[0], W * 4, 0) != 0 || e3.LastError() != SCPR_E_PARAM) return 7;
+  if (enc.LastError() != SCPR_OK) return 8;
   printf("fnv %llu\nok\n", fnv);
   return 0;
 }

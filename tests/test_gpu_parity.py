@@ -1,6 +1,7 @@
 """GPU parity tests (-m gpu): the HIP path behind the C ABI against the oracle
 on the same seeded inputs.  Integer/byte work: the bar is bit-exact."""
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -456,9 +457,9 @@ def test_batch_longer_than_the_slot_pool():
     assert r == n and torch.equal(out.reshape(n, -1), dev)
 
 
-@pytest.mark.parametrize("w,h,n", [(8000, 6, 5), (4099, 33, 4), (3, 2, 12), (3, 80, 8), (5, 701, 5), (16, 40, 8), (17, 17, 8), (1023, 2, 6), (1025, 4, 6)])
+@pytest.mark.parametrize("w,h,n", [(8000, 6, 5), (4099, 33, 4), (3, 2, 12), (3, 80, 8), (5, 701, 5), (16, 40, 8), (17, 17, 8), (1023, 2, 6), (1025, 4, 6), (20, 8191, 4)])
 def test_extreme_frame_shapes(w, h, n):
-    """The documented limits (W >= 3, H >= 2, W <= 8000) and the shapes in between that change the structure of the work: one
+    """The documented limits (W >= 3, H >= 2, W <= 8000, H <= 8191: a motion block's job word holds x and y in 13 bits each) and the shapes in between that change the structure of the work: one
     column of 16x16 blocks (a block's row is its number), one row of blocks, a 1024-pixel tile that spans hundreds of rows, a
     row that spans several tiles.  Key and P-frames, batch and per-frame calls, against the oracle; its packets decoded."""
     import torch
@@ -851,3 +852,51 @@ def test_dense_table_arenas_stay_bounded_over_a_long_gop():
             sizes.append((enc.debug_arena()[0], dec.debug_arena()[1]))
     assert max(sizes[1]) <= 12288 * 1536 * 1.6 + (1 << 20), sizes  # never more than one generation's worth (+ the allocator's slack)
     # (the old policy reserved 19 MB more per decoded P-frame: 7 GB by now)
+
+
+@pytest.mark.gpu
+def test_a_picture_taller_than_8191_rows_is_refused():
+    """motion-block jobs of the decoder carry y in 13 bits (scpr_wave.hpp): beyond that P-frames would be copied to the wrong rows"""
+    enc = _codec(16, 8192)
+    with pytest.raises(RuntimeError):
+        enc.CompressFrame(np.zeros((8192, 16, 4), np.uint8), 0)
+
+
+@pytest.mark.gpu
+def test_chunk_whose_symbol_totals_pass_32_bits_is_cut_again():
+    """An encode chunk's runs / coder entries / colour symbols are addressed with 32-bit positions; 413 noise frames of 1080p (103
+    of 4K) pass 2^32.  k_bases sums in 64 bits and reports how many leading frames fit, the host undoes its frame decisions (and the
+    motion search's vector memory) and codes the chunk up to there.  Reached here with small frames by lowering the limit
+    (SCPR_DEBUG_CHUNK_LIMIT, read once per process: a child process): noise frames, key and P, one batch call, against the oracle."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import numpy as np, torch
+import oracle_api as O
+from screenpressor_amd.codec import ScreenCodec
+w, h, n = 64, 48, 14
+rng = np.random.default_rng(3)
+frames = np.full((n, h, w, 4), 255, np.uint8)
+frames[..., :3] = rng.integers(0, 256, (n, h, w, 3))
+for t in (3, 4, 9):  # P-frames that move a band (vectors found: the vector memory matters across the cut) / change part of the picture
+    frames[t] = frames[t - 1]
+    frames[t, 16:32] = frames[t - 1, 12:28]
+keys = [t in (0, 6, 7, 11) for t in range(n)]
+ora = O.OracleCodec(w, h, 32)
+want = [ora.compress(f, key=k) for f, k in zip(frames, keys)]
+dev = torch.from_numpy(frames).cuda().reshape(n, -1)
+enc = ScreenCodec(0).Init(w, h, 32)
+pk, sizes, fts = enc.CompressBatch(dev, [0 if k else 1 for k in keys])
+assert fts == [ft for _, ft in want] and pk.cpu().numpy().tobytes() == b"".join(p for p, _ in want), "packets differ"
+dec = ScreenCodec(0).Init(w, h, 32)
+r, out = dec.DecompressBatch(pk, sizes, fts)
+assert r == n and torch.equal(out.reshape(n, -1), dev)
+print("RECUT_OK", int(sizes.sum()))
+""" % (root, root)
+    # a noise key frame of 64x48 has ~15 000 coder entries: three or four frames per chunk
+    env = dict(os.environ, SCPR_DEBUG_CHUNK_LIMIT="50000")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert "RECUT_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]

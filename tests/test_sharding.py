@@ -25,24 +25,72 @@ def test_shard_ranges_cut_at_key_frames():
     assert all(hi - lo in (2, 3) for lo, hi in r)
 
 
-def _worker(rank, world, port, q):
+def stale_vector_stream(w=96, h=64):
+    """Two GOPs built so that the motion-vector memory decides bytes across the key frame between them (mvs[],
+    screencap.cpp:96-97, :726-735).  GOP 0: block row 1 becomes the rows four higher - every row of the picture is
+    different, so the search finds (0, -4) and nothing else, and mvs[] of block row 1 keeps it.  GOP 1: the picture is six
+    rows repeated; block row 2 scrolls by two, so its blocks match at dy = +2, -4, +8, ...: the search order (:737-760)
+    meets +2 first, but a codec that remembers GOP 0 tries the vector of the block above, (0, -4), before it searches."""
+    rng = np.random.default_rng(5)
+
+    def rgb32(a):
+        f = np.full((h, w, 4), 255, np.uint8)
+        f[..., :3] = a
+        return f
+    f0 = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    f1 = f0.copy()
+    f1[16:32] = f0[12:28]
+    rows = rng.integers(0, 256, (6, w, 3), dtype=np.uint8)
+    f2 = np.stack([rows[y % 6] for y in range(h)])
+    f3 = f2.copy()
+    f3[32:48] = np.stack([rows[(y + 2) % 6] for y in range(32, 48)])
+    return [rgb32(f0), rgb32(f1), rgb32(f2), rgb32(f3)], [0, 1, 0, 1]
+
+
+def _streams(name):
+    """(frames, ftypes asked for, w, h) of the sharding test streams"""
+    if name == "stale":
+        frames, ft = stale_vector_stream(96, 64)
+        return frames, ft, 96, 64
+    from screenpressor_amd.synth import DesktopSequence
+    w, h, n = 96, 64, 12
+    seq = DesktopSequence(w, h, seed=11)
+    return [seq.frame(t) for t in range(n)], [0 if t % 4 == 0 else 1 for t in range(n)], w, h
+
+
+def _oracle_prepass(w, h, frames, ft_in, lo, hi):
+    """what scpr_motion_prepass computes, done the long way with the checker: a throw-away codec seeded like the shard's own
+    codes the shard's frames, and what is left in its vector memory is the answer"""
+    import oracle_api as O
+    from screenpressor_amd.sharding import shard_seed
+
+    def run(mv_in):
+        tmp = O.OracleCodec(w, h, 32)
+        tmp.seed_shard(*shard_seed(lambda t: frames[t], lo, w, h, 32))
+        tmp.import_mv_memory(mv_in)
+        for t in range(lo, hi):
+            tmp.compress(frames[t], key=(ft_in[t] == 0))
+        return tmp.export_mv_memory()
+    return run
+
+
+def _worker(rank, world, port, q, name):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
     sys.path.insert(0, os.path.join(root, "tests"))
     import torch.distributed as dist
     import oracle_api as O
-    from screenpressor_amd.sharding import gather_packets, shard_gops
-    from screenpressor_amd.synth import DesktopSequence
+    from screenpressor_amd.sharding import gather_packets, handover_mv_memory, shard_gops, shard_seed
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    w, h, n = 96, 64, 12
-    ft_in = [0 if t % 4 == 0 else 1 for t in range(n)]
-    seq = DesktopSequence(w, h, seed=11)
+    frames, ft_in, w, h = _streams(name)
     lo, hi = shard_gops(ft_in, world)[rank]
     enc = O.OracleCodec(w, h, 32)
-    pk = [enc.compress(seq.frame(t), key=(ft_in[t] == 0))[0] for t in range(lo, hi)]
+    enc.seed_shard(*shard_seed(lambda t: frames[t], lo, w, h, 32))
+    enc.import_mv_memory(handover_mv_memory(dist, rank, world, enc.nblocks, _oracle_prepass(w, h, frames, ft_in, lo, hi)))
+    pk = [enc.compress(frames[t], key=(ft_in[t] == 0))[0] for t in range(lo, hi)]
     payload = np.frombuffer(b"".join(pk), dtype=np.uint8)
     out_p, out_s = gather_packets(dist, rank, world, payload, [len(p) for p in pk])
     if rank == 0:
@@ -51,40 +99,87 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_gather_equals_single_stream_of_independent_gops():
+def _run_ranks(world, name):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, name)) for r in range(world)]
     for p in procs:
         p.start()
     blob, sizes = q.get(timeout=120)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    # expected: every GOP from a fresh codec, concatenated in frame order (see sharding.py docstring)
+    return blob, sizes
+
+
+@pytest.mark.parametrize("world,name", [(2, "desktop"), (3, "desktop"), (2, "stale")])
+def test_sharded_stream_equals_the_single_stream(world, name):
+    """GOP ranges coded by separate ranks, each seeded with what crosses key frames (flat-frame state, fn, and the
+    motion-vector memory handed down the ranks): the gathered packets are the packets of ONE codec over the whole stream."""
     import oracle_api as O
-    from screenpressor_amd.synth import DesktopSequence
-    w, h, n = 96, 64, 12
-    seq = DesktopSequence(w, h, seed=11)
-    want, want_sizes = b"", []
-    for lo, hi in shard_gops([0 if t % 4 == 0 else 1 for t in range(n)], 2):
-        enc = O.OracleCodec(w, h, 32)
-        for t in range(lo, hi):
-            d, _ = enc.compress(seq.frame(t), key=(t % 4 == 0))
-            want += d
-            want_sizes.append(len(d))
-    assert sizes == want_sizes and blob == want
+    frames, ft_in, w, h = _streams(name)
+    one = O.OracleCodec(w, h, 32)
+    single = [one.compress(f, key=(k == 0))[0] for f, k in zip(frames, ft_in)]
+    if name == "stale":  # the stream is built so that the hand-over matters: a shard from a fresh codec codes other bytes
+        lo, hi = shard_gops(ft_in, 2)[1]
+        fresh = O.OracleCodec(w, h, 32)
+        assert [fresh.compress(frames[t], key=(ft_in[t] == 0))[0] for t in range(lo, hi)] != single[lo:hi]
+    blob, sizes = _run_ranks(world, name)
+    assert sizes == [len(p) for p in single] and blob == b"".join(single)
     # and the gathered stream decodes losslessly with one decoder
     dec = O.OracleCodec(w, h, 32)
     off = 0
     for t, sz in enumerate(sizes):
-        r, out = dec.decompress(blob[off:off + sz], 0 if t % 4 == 0 else 1)
+        r, out = dec.decompress(blob[off:off + sz], ft_in[t])
         off += sz
-        assert r == 1 and np.array_equal(out.reshape(h, w, 4), seq.frame(t))
+        assert r == 1 and np.array_equal(out.reshape(h, w, 4), frames[t])
+
+
+@pytest.mark.gpu
+def test_gpu_shards_with_the_vector_memory_handed_over_equal_the_single_stream():
+    """two HIP codecs on one GPU, the second seeded through scpr_import_mv_memory with what scpr_motion_prepass says the
+    first shard leaves behind: packets == ONE oracle codec over the whole stream; the pre-pass result == the memory after the
+    real encode; the pre-pass leaves the codec as it was"""
+    import torch
+    import oracle_api as O
+    from screenpressor_amd.codec import ScreenCodec
+    for name in ("stale", "desktop"):
+        frames, ft_in, w, h = _streams(name)
+        one = O.OracleCodec(w, h, 32)
+        single = [one.compress(f, key=(k == 0))[0] for f, k in zip(frames, ft_in)]
+        dev = torch.from_numpy(np.stack(frames)).cuda().reshape(len(frames), -1)
+        got, mv = [], None
+        ranges = shard_gops(ft_in, 2)
+        for lo, hi in ranges:
+            c = ScreenCodec(0).Init(w, h, 32)
+            if lo:
+                c.SeedShard(lo, False, 0)
+                c.ImportMvMemory(mv)
+            said = c.MotionPrepass(dev[lo:hi], ft_in[lo:hi])
+            assert np.array_equal(c.ExportMvMemory(), mv if lo else np.zeros_like(said))  # the codec's own memory is untouched
+            pk, sizes, _ = c.CompressBatch(dev[lo:hi], ft_in[lo:hi])
+            assert np.array_equal(c.ExportMvMemory(), said)
+            blob, off = pk.cpu().numpy().tobytes(), 0
+            for sz in sizes:
+                got.append(blob[off:off + int(sz)])
+                off += int(sz)
+            mv = said
+        assert got == single, name
+        if name == "stale":  # without the hand-over the second shard codes other bytes (what round 2 shipped)
+            lo, hi = ranges[1]
+            c = ScreenCodec(0).Init(w, h, 32)
+            c.SeedShard(lo, False, 0)
+            pk, sizes, _ = c.CompressBatch(dev[lo:hi], ft_in[lo:hi])
+            assert pk.cpu().numpy().tobytes() != b"".join(single[lo:hi])
+            # per-frame calls after a pre-pass: the previous frame and the models were not disturbed either
+            c = ScreenCodec(0).Init(w, h, 32)
+            first = c.CompressFrame(frames[0], 0)[0]
+            c.MotionPrepass(dev[1:2], [1])
+            assert [first, c.CompressFrame(frames[1], 1)[0]] == single[:2]
 
 
 @pytest.mark.gpu
@@ -234,3 +329,135 @@ def test_bench_launcher_spawns_ranks_and_gathers_in_frame_order():
         line = json.loads(r.stdout.strip().splitlines()[-1])
         assert line["n_gpus"] == n and line["gathered_ok"] and line["sizes_ok"], line
         assert line["ranges"][0][0] == 0 and line["ranges"][-1][1] == 24 and all(lo % 4 == 0 for lo, _ in line["ranges"])
+
+
+# ---- bench.py's configs[3] leg (c4_leg) through its real collectives, on CPU ranks ------------------------------------
+class _OracleEnc:
+    """the encoder half of bench.Runner's codec pair with the checker behind it: the calls shard_seeder() makes"""
+
+    def __init__(self, w, h):
+        import oracle_api as O
+        self.O, self.w, self.h = O, w, h
+        self.c = O.OracleCodec(w, h, 32)
+        self.nblocks = self.c.nblocks
+        self.seeded, self.mv = None, None
+
+    def SeedShard(self, frames_before, last_flat, rgb=0):
+        self.seeded = (frames_before, last_flat, rgb)
+        self.c.seed_shard(*self.seeded)
+
+    def ImportMvMemory(self, mv):
+        self.mv = np.array(mv, dtype=np.int32)
+        self.c.import_mv_memory(self.mv)
+
+    def MotionPrepass(self, frames, ftypes):
+        tmp = self.O.OracleCodec(self.w, self.h, 32)  # (the long way: a throw-away codec seeded alike codes the frames)
+        if self.seeded:
+            tmp.seed_shard(*self.seeded)
+        if self.mv is not None:
+            tmp.import_mv_memory(self.mv)
+        for f, t in zip(frames.numpy(), ftypes):
+            tmp.compress(f, key=(t == 0))
+        return tmp.export_mv_memory()
+
+
+class _OracleRunner:
+    def __init__(self, wl, fail_prepass=False):
+        self.wl, self.fail_prepass = wl, fail_prepass
+        self.reset()
+
+    def reset(self):
+        import oracle_api as O
+        self.enc = _OracleEnc(self.wl.w, self.wl.h)
+        if self.fail_prepass:
+            def boom(frames, ftypes):
+                raise RuntimeError("injected: the pre-pass failed on this rank")
+            self.enc.MotionPrepass = boom
+        self.dec = O.OracleCodec(self.wl.w, self.wl.h, 32)
+
+    def same(self, dec, frames):
+        import torch
+        return bool(torch.equal(dec.reshape(frames.shape[0], -1), frames))
+
+    def step(self, frames, ftypes, seed=None, after=None, reset=True):
+        import torch
+        assert not reset
+        pk = [self.enc.c.compress(f, key=(t == 0)) for f, t in zip(frames.numpy(), ftypes)]
+        dec = [self.dec.decompress(p, ft)[1] for p, ft in pk]
+        out = torch.from_numpy(np.frombuffer(b"".join(p for p, _ in pk), dtype=np.uint8).copy())
+        return out, np.array([len(p) for p, _ in pk], dtype=np.uint32), [ft for _, ft in pk], torch.from_numpy(np.stack(dec)), 1e-3, 1e-3, {}
+
+
+def _worker_c4(rank, world, port, q, mode):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "tests"))
+    import torch
+    import torch.distributed as dist
+    import bench
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    frames, ft_in, w, h = _streams("stale")
+    lo, hi = shard_gops(ft_in, world)[rank]
+    wl = bench.Workload("test stream", w, h, 32, 0, lo, hi, ft_in[lo:hi], "strong", len(frames))
+
+    def make_runner(q_):
+        if mode == "no_setup" and rank == 1:
+            raise MemoryError("injected: this rank cannot set the workload up")
+        return _OracleRunner(q_, fail_prepass=(mode == "prepass_fails" and rank == 0))
+    env = bench.Env(rank, world, torch.device("cpu"), torch, dist, make_runner, lambda q_: torch.from_numpy(np.stack(frames[q_.lo:q_.hi])).reshape(q_.n, -1))
+    res = bench.c4_leg(env, wl, golden_name=None)
+    q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["fine", "no_setup", "prepass_fails"])
+def test_bench_c4_leg_control_flow_on_two_cpu_ranks(mode):
+    """bench.c4_leg - setup vote, seeding with the vector memory handed down the ranks, warm-up vote, timed pass, gather on
+    rank 0, hash - with gloo ranks and the checker as the codec: the gathered stream is the single stream (a stream on which
+    that takes the hand-over), and a rank that cannot set up, or whose pre-pass fails, ends the leg on EVERY rank with an
+    error entry instead of leaving the others in a collective"""
+    import hashlib
+    import oracle_api as O
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_c4, args=(r, 2, port, q, mode)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    if mode == "fine":
+        frames, ft_in, w, h = _streams("stale")
+        one = O.OracleCodec(w, h, 32)
+        single = b"".join(one.compress(f, key=(k == 0))[0] for f, k in zip(frames, ft_in))
+        r0 = got[0]
+        assert "error" not in r0 and r0["lossless_roundtrip"] and r0["gathered_frames_rank0"] == 4
+        assert r0["sha256"] == hashlib.sha256(single).hexdigest() and r0["compressed_bytes"] == len(single)
+        assert isinstance(r0["golden_stream_ok"], str)  # no committed hash for this test stream: said, not guessed
+    else:
+        assert all("error" in got[r] for r in (0, 1)), got
+        assert "injected" in got[1 if mode == "no_setup" else 0]["error"]
+
+
+def test_bench_launcher_names_the_rank_that_died():
+    """a rank that exits before the first collective: the launcher stops the others at once (instead of leaving them in the
+    rendezvous until its timeout), exits non-zero and says which rank it was and what it wrote last"""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["SCPR_SELFTEST_DIE_RANK"] = "1"
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--selftest-launcher"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and time.time() - t0 < 120
+    assert "rank 1 of 2 exited with code 3" in r.stderr and "gives up before the rendezvous" in r.stderr, r.stderr[-2000:]
