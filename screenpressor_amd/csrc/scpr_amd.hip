@@ -16,6 +16,7 @@
 #include "../../include/scpr_amd.h"
 #include "scpr_kernels.hpp"
 #include "scpr_wave.hpp"
+#include "scpr_fixed.hpp"
 #include "scpr_v2.hpp"
 #include "scpr_inter.hpp"
 
@@ -105,7 +106,7 @@ struct scpr_codec {
   // per-batch buffers
   DevBuf flags, slotlist, genlist, bases, totals, runs, runpos, keys[2], vals[2], cstart, sorttmp, entries, ranges;
   DevBuf rblocks, rscratch, rsize, packets, pktoff, blkdst, outsizes, total64, arena, arena2, arena_top, err, rcp;  // (arena2: where compact_tables moves the live tables)
-  DevBuf decframes, decstates, hoststage_in, hoststage_out, chainlists, chaincounts;
+  DevBuf decframes, decstates, hoststage_in, hoststage_out, chainlists, chaincounts, fixcnt, fixoff, fixtot, fixsym, fixpos, fixgen;
   // P-frame buffers
   DevBuf mvdict, mvpre, gmask;
   DevBuf kinds, pidx, fidx, pframes, pflag, binfo, smv, btype, bmv, bcnt, boff, bflag, pinfo, ptot, pbase, misc, miscpos, miscranges;
@@ -580,8 +581,25 @@ static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int n
     HIPCHK(hipEventRecord(c->ev_fork, st));
     HIPCHK(hipStreamWaitEvent(s2, c->ev_fork, 0));
     stage_begin(c, ST_FIXED, s2);
-    hipLaunchKernelGGL(k_fixed_chain, dim3(ngens), dim3(768), 0, s2, c->runs.as<u32>(), c->runpos.as<u32>(), c->ranges.as<GenRange>(), ngens, load_first ? 1 : 0,
-                       c->fixed_persist.as<FixedPersist>() + buf_in * 12, c->fixed_persist.as<FixedPersist>() + buf_out * 12, c->entries.as<u32>());
+    {
+      // the run list partitioned by model (scpr_fixed.hpp), then one wave per (generation, model) over its own symbols
+      const u32 nblk = (u32)((Rtot + FIX_B - 1) / FIX_B);
+      HIPCHK(c->fixcnt.reserve((size_t)FIX_CLASSES * (nblk + 1) * 4));
+      HIPCHK(c->fixoff.reserve((size_t)FIX_CLASSES * (nblk + 1) * 4));
+      HIPCHK(c->fixtot.reserve(64));
+      HIPCHK(c->fixsym.reserve(2 * Rtot + 64));
+      HIPCHK(c->fixpos.reserve((2 * Rtot + 16) * 4));
+      HIPCHK(c->fixgen.reserve((size_t)FIX_CLASSES * ngens * 2 * 4));
+      if (nblk) hipLaunchKernelGGL(k_fix_count, dim3(nblk), dim3(256), 0, s2, c->runs.as<u32>(), (u32)Rtot, c->fixcnt.as<u32>(), nblk);
+      hipLaunchKernelGGL(k_fix_scan, dim3(FIX_CLASSES), dim3(256), 0, s2, c->fixcnt.as<u32>(), c->fixoff.as<u32>(), nblk, c->fixtot.as<u32>());
+      if (nblk)
+        hipLaunchKernelGGL(k_fix_scatter, dim3(nblk), dim3(256), 0, s2, c->runs.as<u32>(), c->runpos.as<u32>(), (u32)Rtot, c->fixoff.as<u32>(), nblk, c->fixtot.as<u32>(), c->fixsym.as<u8>(),
+                           c->fixpos.as<u32>());
+      hipLaunchKernelGGL(k_fix_genstart, dim3(ngens), dim3(64), 0, s2, c->runs.as<u32>(), (u32)Rtot, c->ranges.as<GenRange>(), ngens, c->fixoff.as<u32>(), nblk, c->fixtot.as<u32>(),
+                         c->fixgen.as<u32>());
+      hipLaunchKernelGGL(k_fixed_chain2, dim3(ngens), dim3(768), 0, s2, c->fixsym.as<u8>(), c->fixpos.as<u32>(), c->fixgen.as<u32>(), ngens, load_first ? 1 : 0,
+                         c->fixed_persist.as<FixedPersist>() + buf_in * 12, c->fixed_persist.as<FixedPersist>() + buf_out * 12, c->entries.as<u32>());
+    }
     if (Mtot)
       hipLaunchKernelGGL(k_misc_chain, dim3(MC_COUNT, ngens), dim3(64), 0, s2, c->misc.as<u32>(), c->miscpos.as<u32>(), c->miscranges.as<MiscRange>(), ngens, load_first ? 1 : 0,
                          c->misc_persist.as<FixedPersist>() + buf_in * MC_COUNT, c->misc_persist.as<FixedPersist>() + buf_out * MC_COUNT, c->entries.as<u32>());
@@ -680,7 +698,7 @@ void scpr_destroy(scpr_codec* c) {
   DevBuf* all[] = {&c->planes, &c->tnmap, &c->exitmap, &c->entry, &c->runrec, &c->tilecnt, &c->tileoff, &c->hdrrec, &c->hdrcnt, &c->frametot, &c->flags, &c->slotlist, &c->genlist,
                    &c->bases, &c->totals, &c->runs, &c->runpos, &c->keys[0], &c->keys[1], &c->vals[0], &c->vals[1], &c->cstart, &c->sorttmp,
                    &c->entries, &c->ranges, &c->rblocks, &c->rscratch, &c->rsize, &c->packets, &c->pktoff, &c->blkdst, &c->outsizes, &c->total64, &c->arena,
-                   &c->arena_top, &c->err, &c->rcp, &c->decframes, &c->decstates, &c->hoststage_in, &c->hoststage_out, &c->chainlists, &c->chaincounts, &c->kinds, &c->pidx, &c->fidx, &c->pframes, &c->pflag, &c->binfo, &c->smv, &c->btype, &c->bmv, &c->bcnt, &c->boff, &c->bflag, &c->pinfo, &c->ptot, &c->pbase, &c->misc, &c->miscpos, &c->miscranges, &c->mvs, &c->mvs_keep, &c->fixed_persist, &c->misc_persist, &c->colour_persist, &c->decgops, &c->decfixed, &c->dec_fixed_persist, &c->dec_colour_persist, &c->dec_arena, &c->dec_arena2, &c->arena2, &c->dec_arena_top, &c->mvdict, &c->mvpre, &c->gmask};
+                   &c->arena_top, &c->err, &c->rcp, &c->decframes, &c->decstates, &c->hoststage_in, &c->hoststage_out, &c->chainlists, &c->chaincounts, &c->fixcnt, &c->fixoff, &c->fixtot, &c->fixsym, &c->fixpos, &c->fixgen, &c->kinds, &c->pidx, &c->fidx, &c->pframes, &c->pflag, &c->binfo, &c->smv, &c->btype, &c->bmv, &c->bcnt, &c->boff, &c->bflag, &c->pinfo, &c->ptot, &c->pbase, &c->misc, &c->miscpos, &c->miscranges, &c->mvs, &c->mvs_keep, &c->fixed_persist, &c->misc_persist, &c->colour_persist, &c->decgops, &c->decfixed, &c->dec_fixed_persist, &c->dec_colour_persist, &c->dec_arena, &c->dec_arena2, &c->arena2, &c->dec_arena_top, &c->mvdict, &c->mvpre, &c->gmask};
   for (DevBuf* b : all) b->release();
   for (int s = 0; s < ST_COUNT + 1; s++)
     for (int k = 0; k < 2; k++) (void)hipEventDestroy(c->ev[s][k]);
@@ -1328,6 +1346,16 @@ int scpr_last_timing(scpr_codec* c, float* total_ms, float* stage_ms, int cap) {
 }
 
 #ifdef SCPR_PROFILE
+// design work only (libscpr_amd_prof.so): the records of the long colour chains since the last call (tools/profile_chains.py)
+extern "C" int scpr_debug_chains(unsigned* out, int cap) {
+  unsigned n = 0, zero = 0;
+  if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(scpr::g_chainrec_n), 4) != hipSuccess) return -1;
+  const unsigned m = n < 8192u ? n : 8192u;
+  const unsigned take = m < (unsigned)cap ? m : (unsigned)cap;
+  if (take && hipMemcpyFromSymbol(out, HIP_SYMBOL(scpr::g_chainrec), (size_t)take * 32) != hipSuccess) return -1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(scpr::g_chainrec_n), &zero, 4) != hipSuccess) return -1;
+  return (int)n;
+}
 // design work only (libscpr_amd_prof.so): s_memtime ticks per decoder section summed over all GOPs since the last call
 extern "C" int scpr_debug_profile(unsigned long long* out) {
   unsigned long long z[24] = {0};

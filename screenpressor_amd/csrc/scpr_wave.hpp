@@ -687,10 +687,46 @@ struct WaveModel {
     }
     return DEC ? (j & 255) : j;  // (a table that other contexts have scribbled on after an arena overflow may match no lane: own = -1)
   }
+  // The rescale of dense_impl() by itself, on a table whose counts are up to date (encoder chains: k_colour_chain_w counts a
+  // whole epoch's symbols with LDS atomics and then calls this): Cx7::incrCnt's rebuild (:963-980) / Cx6::rescale (:742-796).
+  template <bool LDS>
+  __device__ __forceinline__ void dense_rescale(DenseTab* t, u32* r, ColHdr& h) {
+    wave_fence();
+    const u32x2 cq = tab_ld<LDS>(t->cnt, lane);
+    int cn[4] = {(int)(cq.x & 0xFFFF), (int)(cq.x >> 16), (int)(cq.y & 0xFFFF), (int)(cq.y >> 16)};
+    int fr[4];
+    if (h.kind == 7) {
+      for (int q = 0; q < 4; q++) {
+        fr[q] = cn[q];
+        cn[q] -= cn[q] >> 1;
+      }
+      h.total = write_dense<LDS>(t, fr, cn);
+    } else {
+      const u32 bits = set_bits4(r);
+      const int wdt = 1 << (h.fshift > 0 ? h.fshift - 1 : 0);
+      if (h.fshift > 0) h.fshift--;
+      for (int q = 0; q < 4; q++) {
+        if ((bits >> q) & 1u) {
+          fr[q] = cn[q];
+          cn[q] -= cn[q] >> 1;
+        } else {
+          fr[q] = wdt;
+          cn[q] = 0;
+        }
+      }
+      const int sum = write_dense<LDS>(t, fr, cn);
+      h.total = ((256 - h.d) << (h.fshift > 0 ? h.fshift - 1 : 0)) + sum;
+    }
+    wave_fence();
+  }
 };
 
 #ifdef SCPR_PROFILE
 __device__ u64 g_prof[24];
+// design aid (tools/profile_chains.py): one record per colour chain of 2048 symbols or more - length, cycles, final kind | d << 8,
+// symbols that took the general small-table path, symbols coded by the epoch-parallel dense path, raw symbols
+__device__ u32 g_chainrec[8192][8];
+__device__ u32 g_chainrec_n;
 #endif
 struct WaveDec : WaveModel {
   WaveLds& L;
@@ -2126,6 +2162,7 @@ __global__ __launch_bounds__(64) void k_colour_chain_w(const u32* __restrict__ s
                                                        const u32* __restrict__ counts, u32 cap, int f0, Arena arena, ChainPersist cp, u32* __restrict__ entries) {
   __shared__ u32 rec[16];
   __shared__ u16 tmp[256];
+  __shared__ __attribute__((aligned(16))) DenseTab ltab;  // the chain's dense table while the context is of kind 6 or 7
   WaveModel M(tmp, arena, f0);
   const int lane = M.lane;
   u32 cn[CHAIN_CLASSES], n = 0;
@@ -2150,9 +2187,17 @@ __global__ __launch_bounds__(64) void k_colour_chain_w(const u32* __restrict__ s
     const int gen = (int)(q / NCOLCTX), ctx = (int)(q - (u32)gen * NCOLCTX);
     ColHdr h = WaveModel::unpack(0, 0, 0);
     u32 T = kSmallNone;
-    bool tlive = false;  // the context's dense table is in tfq / tcu / tcq (dense_enc_hit), tbits = which of a lane's symbols have been met
-    u32x2 tfq = {0u, 0u}, tcu = {0u, 0u}, tcq = {0u, 0u};
-    u32 tbits = 0;
+#ifdef SCPR_PROFILE
+    const u64 pr_t0 = __builtin_readcyclecounter();
+    u32 pr_slow = 0, pr_par = 0, pr_raw = 0, pr_dser = 0, pr_batch = 0;
+#endif
+    // A dense context (kinds 6/7) keeps its table in LDS for the chain (`ltab`; tlive: it is there).  Its intervals are frozen
+    // between rescales and a rescale comes after a known number of symbols (`room`: every symbol adds the same step to the
+    // total, ans_contexts.h:686-691, :954-981), so the symbols up to there are INDEPENDENT lookups: one lane each, the counts by
+    // LDS atomics, the rebuild by a wave scan (dense_rescale) - the epoch parallelism of the fixed models (k_fixed_chain).
+    // Only a symbol the context has not met (kind 6: at most 24 in its life) goes through the general path by itself.
+    // (One symbol at a time, a chain of 10^5 symbols through a dense context was the critical path of the stage.)
+    bool tlive = false;
     wave_fence();
     if (gen == 0 && cp.load_first) {  // continue the model of this context from the previous call
       const u32* src = (const u32*)&cp.states_in[ctx];
@@ -2168,15 +2213,119 @@ __global__ __launch_bounds__(64) void k_colour_chain_w(const u32* __restrict__ s
         }
       }
     }
+    // (the sorted lists stream from HBM, a microsecond away: the loads of the next two trips are in flight while one is coded)
+    u32 k1 = 0, p1 = 0, k2 = 0, p2 = 0;
+    if ((u32)lane < len) k1 = skeys[start + lane], p1 = svals[start + lane];
+    if (64u + (u32)lane < len) k2 = skeys[start + 64u + lane], p2 = svals[start + 64u + lane];
     for (u32 base = 0; base < len; base += 64) {
       const int m = (int)min(64u, len - base);
-      u32 key = 0, pos = 0, mine = 0;
-      if (lane < m) {
-        key = skeys[start + base + lane];
-        pos = svals[start + base + lane];
-      }
-      for (int j = 0; j < m; j++) {
-        const int c = (int)(rdl(key, j) & 255u);
+      const u32 key = k1, pos = p1;
+      u32 mine = 0;
+      k1 = k2, p1 = p2;
+      if (base + 128u + (u32)lane < len) k2 = skeys[start + base + 128u + lane], p2 = svals[start + base + 128u + lane];
+      const int cl = (int)(key & 255u);  // this lane's symbol
+      int j = 0;
+      while (j < m) {
+        if (h.kind >= 6) {
+          if (!tlive) {
+            wave_fence();
+            WaveModel::copy_tab<true>(&ltab, arena.tabs + h.dense, lane);
+            tlive = true;
+          }
+          wave_fence();
+          const int step = h.kind == 7 ? kStepDense : kStepHash << h.fshift;
+          const bool act = lane >= j && lane < m;
+          const bool met = h.kind == 7 || ((rec[4 + (cl >> 5)] >> (cl & 31)) & 1u);
+          const u64 um = __ballot(act && !met);
+          const int first_unmet = um ? (int)__builtin_ctzll(um) : m;
+          const int room = (kProbScale - step - h.total) / step + 1;  // symbols until the rescale (the room-th one brings it on)
+          const int take = min(min(first_unmet, m) - j, room);
+          if (SCPR_LIKELY(take > 0)) {
+            if (lane >= j && lane < j + take) {
+              mine = (u32)ltab.freq[cl] | ((u32)ltab.cum[cl] << 16);
+              atomicAdd((u32*)&ltab.cnt[cl & ~1], (u32)step << (16 * (cl & 1)));  // (two 16-bit counts per word; a count stays below 4096 + step)
+            }
+            h.total += take * step;
+            j += take;
+#ifdef SCPR_PROFILE
+            pr_par += (u32)take;
+#endif
+            if (take == room) {
+              M.dense_rescale<true>(&ltab, rec, h);
+              WaveModel::scalar_hdr(h);
+            }
+            continue;
+          }
+          // symbol j has not been met by this context (or the total leaves no room: never, the rescale keeps it below): by itself
+          const int c = (int)rdl((u32)cl, j);
+          u32 fr = 0, cf = (u32)c;
+          wave_fence();
+          M.dense_impl<false, true>(&ltab, rec, h, c, fr, cf);
+          WaveModel::scalar_hdr(h);
+#ifdef SCPR_PROFILE
+          pr_dser++;
+#endif
+          if (lane == j) mine = (fr & 0xFFFFu) | (cf << 16);
+          j++;
+          continue;
+        }
+        // A small table (kinds 4/5) changes with every symbol, but what a HIT changes is plain arithmetic: 50 on the entry's count,
+        // on the sums before the entries above it and on the total (SmallContext::encode, ans_contexts.h:195-236).  So the
+        // interval of the i-th symbol of a batch of hits is a closed form of the table at the batch's start and of how many
+        // earlier symbols of the batch hit the same entry / a lower entry - counts that ballots give every lane at once.  The
+        // batch ends before the first symbol that is not such a hit: a symbol the table does not hold, the symbol after which a
+        // rescale is due (total + 100 > 4096: after 41 hits at most), or a hit that makes another entry the top one (the spare
+        // code space moves with it); that symbol goes through the general path below by itself.  (One symbol at a time a hit
+        // costs a lone wave ~470 cycles: chains of 10^5 symbols through contexts with a handful of colours - text on a
+        // background - were the critical path of the stage, 40 ms of a one-GOP encode.)
+        if ((h.kind | 1) == 5 && m - j >= 3) {
+          const bool act = lane >= j && lane < m;
+          const int d = h.d, mp = h.maxpos;
+          int pe = -1;            // this lane's symbol is entry pe of the table (-1: not in it)
+          u32 wp = 0, ceq = 0, clt = 0, hmp = 0;  // its packed entry; earlier symbols of the batch on the same entry / on lower entries / on the top entry
+          for (int e = 0; e < d; e++) {
+            const u32 we = rdl(T, e), se = we & 255u;
+            const bool eq = act && (u32)cl == se;
+            const u64 me = __ballot(eq);
+            const u32 below = __builtin_amdgcn_mbcnt_hi((u32)(me >> 32), __builtin_amdgcn_mbcnt_lo((u32)me, 0u));
+            pe = eq ? e : pe;
+            wp = eq ? we : wp;
+            ceq = eq ? below : ceq;
+            clt += (u32)cl > se ? below : 0u;  // (entries are sorted by symbol)
+            hmp = e == mp ? below : hmp;
+          }
+          const int i = lane - j;
+          const int tot_i = h.total + kStepSmall * i;
+          const int fq = (int)sm_fq(wp) + kStepSmall * (int)ceq, pp = (int)sm_p(wp) + kStepSmall * (int)clt;
+          const int sh = __builtin_clz((u32)(tot_i - 1)) - 20, bonus = (kProbScale >> sh) - tot_i;
+          const int ap = (int)sm_sym(wp) + pp - pe + (pe > mp ? bonus : 0), width = fq + (pe == mp ? bonus : 0);
+          const bool bad = act && (pe < 0 || tot_i + 2 * kStepSmall > kProbScale || (pe != mp && fq + kStepSmall > h.fmax + kStepSmall * (int)hmp));
+          const u64 bm = __ballot(bad);
+          const int cut = bm ? (int)__builtin_ctzll(bm) : m;
+          const int take = cut - j;
+          if (SCPR_LIKELY(take > 0)) {
+            const bool taken = act && lane < cut;
+            if (taken) mine = ((u32)width << sh) | (((u32)ap << sh) << 16);
+            // the table after the batch: every entry's count + 50 per symbol that hit it, the sums before the entries rebuilt
+            int addv = 0, nmp = 0;
+            for (int e = 0; e < d; e++) {
+              const int ne = __builtin_popcountll(__ballot(taken && pe == e));
+              addv = M.l15 == e ? ne : addv;
+              nmp = e == mp ? ne : nmp;
+            }
+            M.small_pack(T, (int)sm_sym(T), (int)sm_fq(T) + kStepSmall * addv, d);
+            h.total += kStepSmall * take;
+            h.fmax += kStepSmall * nmp;
+            h.top = M.small_top(h, T);
+            WaveModel::scalar_hdr(h);
+            j += take;
+#ifdef SCPR_PROFILE
+            pr_batch += (u32)take;
+#endif
+            continue;
+          }
+        }
+        const int c = (int)rdl((u32)cl, j);
         u32 fr = 0, cf = (u32)c;
         wave_fence();
         // plain ifs, the common case first (see the decoder's colour())
@@ -2187,39 +2336,37 @@ __global__ __launch_bounds__(64) void k_colour_chain_w(const u32* __restrict__ s
           if (SCPR_UNLIKELY(tt >= 0)) {
             M.small_op<false>(rec, h, T, c, fr, cf);
             if ((h.kind | 1) == 5) h.top = M.small_top(h, T);
+#ifdef SCPR_PROFILE
+            pr_slow++;
+#endif
           }
         }
         small = (int)rfl((u32)small);  // (keeps the two tests apart)
-        if (SCPR_UNLIKELY(small >= 0)) {
-          if (h.kind < 4) {
-            M.note_raw(rec, h, c, T);
-            WaveModel::scalar_hdr(h);
-          } else {
-            DenseTab* tp = arena.tabs + h.dense;
-            if (!tlive) {
-              wave_fence();
-              tfq = tab_ld<false>(tp->freq, lane), tcu = tab_ld<false>(tp->cum, lane), tcq = tab_ld<false>(tp->cnt, lane);
-              tbits = h.kind == 6 ? M.set_bits4(rec) : 15u;
-              tlive = true;
-            }
-            int tt = M.dense_enc_hit(h, c, tfq, tcu, tcq, tbits, fr, cf);
-            tt = (int)rfl((u32)tt);
-            if (SCPR_UNLIKELY(tt >= 0)) {  // a symbol the context has not met, or a rescale: on the table in the arena
-              tab_st<false>(tp->cnt, lane, tcq);
-              M.dense_op<false>(rec, h, c, fr, cf);
-              WaveModel::scalar_hdr(h);
-              tlive = false;
-            }
-          }
+        if (SCPR_UNLIKELY(small >= 0)) {  // kinds 0-3: the symbol goes out raw (and may make the context a table)
+#ifdef SCPR_PROFILE
+          pr_raw++;
+#endif
+          M.note_raw(rec, h, c, T);
+          WaveModel::scalar_hdr(h);
           if ((h.kind | 1) == 5) h.top = M.small_top(h, T);
         }
         if (lane == j) mine = (fr & 0xFFFFu) | (cf << 16);
+        j++;
       }
       if (lane < m) entries[pos] = mine;
     }
+#ifdef SCPR_PROFILE
+    if (len >= 2048u && lane == 0) {
+      const u32 k = atomicAdd(&g_chainrec_n, 1u);
+      if (k < 8192u) {
+        u32* o = g_chainrec[k];
+        o[0] = len, o[1] = (u32)(__builtin_readcyclecounter() - pr_t0), o[2] = (u32)h.kind | ((u32)h.d << 8), o[3] = pr_slow, o[4] = pr_par, o[5] = pr_raw, o[6] = pr_dser | (pr_batch << 8), o[7] = q;
+      }
+    }
+#endif
     if (gen == cp.ngens - 1) {  // live generation: keep the state for the next call
       wave_fence();
-      if (tlive) tab_st<false>(arena.tabs[h.dense].cnt, lane, tcq);  // (only the counts change between rescales)
+      if (tlive) WaveModel::copy_tab<false>(arena.tabs + h.dense, &ltab, lane);
       if (h.kind == 4 || h.kind == 5) M.store_small(rec, h.d, T);
       M.store_header(rec, h);
       if (lane == 0) rec[3] = cp.stamp_out;
