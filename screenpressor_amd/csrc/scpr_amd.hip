@@ -83,6 +83,9 @@ const char* kStageNames[ST_COUNT] = {"pack", "classify", "inter", "scan", "symbo
 
 }  // namespace
 
+struct FixBufs {  // scratch of fixed_chains(): block counts and offsets, model totals, the partitioned lists, generation starts
+  DevBuf cnt, off, tot, sym, pos, gen;
+};
 struct scpr_codec {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -106,7 +109,8 @@ struct scpr_codec {
   // per-batch buffers
   DevBuf flags, slotlist, genlist, bases, totals, runs, runpos, keys[2], vals[2], cstart, sorttmp, entries, ranges;
   DevBuf rblocks, rscratch, rsize, packets, pktoff, blkdst, outsizes, total64, arena, arena2, arena_top, err, rcp;  // (arena2: where compact_tables moves the live tables)
-  DevBuf decframes, decstates, hoststage_in, hoststage_out, chainlists, chaincounts, fixcnt, fixoff, fixtot, fixsym, fixpos, fixgen;
+  DevBuf decframes, decstates, hoststage_in, hoststage_out, chainlists, chaincounts;
+  FixBufs fixr, fixm;  // run list / P-frame symbol list
   // P-frame buffers
   DevBuf mvdict, mvpre, gmask;
   DevBuf kinds, pidx, fidx, pframes, pflag, binfo, smv, btype, bmv, bcnt, boff, bflag, pinfo, ptot, pbase, misc, miscpos, miscranges;
@@ -371,6 +375,27 @@ static int motion_stage(scpr_codec* c, const std::vector<PFrame>& pfr) {
   }
   return SCPR_OK;
 }
+// The fixed-alphabet chains over one list (scpr_fixed.hpp): partition by model, then one workgroup per generation, one wave per model.
+template <class SRC, int MAXSYM>
+static int fixed_chains(scpr_codec* c, hipStream_t s2, FixBufs& fb, const u32* el, const u32* elpos, size_t n, const uint2* ranges, int ngens, bool load_first,
+                        const FixedPersist* pin, FixedPersist* pout) {
+  constexpr int NC = SRC::NCLS;
+  const u32 nblk = (u32)((n + PART_B - 1) / PART_B);
+  HIPCHK(fb.cnt.reserve((size_t)NC * (nblk + 1) * 4));
+  HIPCHK(fb.off.reserve((size_t)NC * (nblk + 1) * 4));
+  HIPCHK(fb.tot.reserve(64));
+  HIPCHK(fb.sym.reserve((2 * n + 64) * 2));
+  HIPCHK(fb.pos.reserve((2 * n + 16) * 4));
+  HIPCHK(fb.gen.reserve((size_t)NC * ngens * 2 * 4));
+  if (nblk) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_part_count<SRC>), dim3(nblk), dim3(256), 0, s2, el, (u32)n, fb.cnt.as<u32>(), nblk);
+  hipLaunchKernelGGL(k_part_scan, dim3(NC), dim3(256), 0, s2, fb.cnt.as<u32>(), fb.off.as<u32>(), nblk, fb.tot.as<u32>());
+  if (nblk) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_part_scatter<SRC>), dim3(nblk), dim3(256), 0, s2, el, elpos, (u32)n, fb.off.as<u32>(), nblk, fb.tot.as<u32>(), fb.sym.as<u16>(), fb.pos.as<u32>());
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_part_genstart<SRC>), dim3(ngens), dim3(64), 0, s2, el, (u32)n, ranges, ngens, fb.off.as<u32>(), nblk, fb.tot.as<u32>(), fb.gen.as<u32>());
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fixed_chain2<SRC, MAXSYM>), dim3(ngens), dim3(64 * NC), (size_t)NC * 2 * MAXSYM * 4, s2, fb.sym.as<u16>(), fb.pos.as<u32>(), fb.gen.as<u32>(), ngens,
+                     load_first ? 1 : 0, pin, pout, c->entries.as<u32>());
+  (void)c;
+  return SCPR_OK;
+}
 static u64 chunk_total_limit() {  // SCPR_DEBUG_CHUNK_LIMIT: tests reach the re-cut of a chunk with small frames
   static const u64 v = getenv("SCPR_DEBUG_CHUNK_LIMIT") ? strtoull(getenv("SCPR_DEBUG_CHUNK_LIMIT"), nullptr, 0) : kChunkTotalLimit;
   return v;
@@ -581,30 +606,19 @@ static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int n
     HIPCHK(hipEventRecord(c->ev_fork, st));
     HIPCHK(hipStreamWaitEvent(s2, c->ev_fork, 0));
     stage_begin(c, ST_FIXED, s2);
+    // the run list, then the list of P-frame symbols: partitioned by model (scpr_fixed.hpp), one wave per (generation, model)
     {
-      // the run list partitioned by model (scpr_fixed.hpp), then one wave per (generation, model) over its own symbols
-      const u32 nblk = (u32)((Rtot + FIX_B - 1) / FIX_B);
-      HIPCHK(c->fixcnt.reserve((size_t)FIX_CLASSES * (nblk + 1) * 4));
-      HIPCHK(c->fixoff.reserve((size_t)FIX_CLASSES * (nblk + 1) * 4));
-      HIPCHK(c->fixtot.reserve(64));
-      HIPCHK(c->fixsym.reserve(2 * Rtot + 64));
-      HIPCHK(c->fixpos.reserve((2 * Rtot + 16) * 4));
-      HIPCHK(c->fixgen.reserve((size_t)FIX_CLASSES * ngens * 2 * 4));
-      if (nblk) hipLaunchKernelGGL(k_fix_count, dim3(nblk), dim3(256), 0, s2, c->runs.as<u32>(), (u32)Rtot, c->fixcnt.as<u32>(), nblk);
-      hipLaunchKernelGGL(k_fix_scan, dim3(FIX_CLASSES), dim3(256), 0, s2, c->fixcnt.as<u32>(), c->fixoff.as<u32>(), nblk, c->fixtot.as<u32>());
-      if (nblk)
-        hipLaunchKernelGGL(k_fix_scatter, dim3(nblk), dim3(256), 0, s2, c->runs.as<u32>(), c->runpos.as<u32>(), (u32)Rtot, c->fixoff.as<u32>(), nblk, c->fixtot.as<u32>(), c->fixsym.as<u8>(),
-                           c->fixpos.as<u32>());
-      hipLaunchKernelGGL(k_fix_genstart, dim3(ngens), dim3(64), 0, s2, c->runs.as<u32>(), (u32)Rtot, c->ranges.as<GenRange>(), ngens, c->fixoff.as<u32>(), nblk, c->fixtot.as<u32>(),
-                         c->fixgen.as<u32>());
-      hipLaunchKernelGGL(k_fixed_chain2, dim3(ngens), dim3(768), 0, s2, c->fixsym.as<u8>(), c->fixpos.as<u32>(), c->fixgen.as<u32>(), ngens, load_first ? 1 : 0,
-                         c->fixed_persist.as<FixedPersist>() + buf_in * 12, c->fixed_persist.as<FixedPersist>() + buf_out * 12, c->entries.as<u32>());
+      int rc = fixed_chains<RunItems, 256>(c, s2, c->fixr, c->runs.as<u32>(), c->runpos.as<u32>(), Rtot, (const uint2*)c->ranges.p, ngens, load_first,
+                                           c->fixed_persist.as<FixedPersist>() + buf_in * 12, c->fixed_persist.as<FixedPersist>() + buf_out * 12);
+      if (rc != SCPR_OK) return rc;
+      if (Mtot) {
+        rc = fixed_chains<MiscItems, 512>(c, s2, c->fixm, c->misc.as<u32>(), c->miscpos.as<u32>(), Mtot, (const uint2*)c->miscranges.p, ngens, load_first,
+                                          c->misc_persist.as<FixedPersist>() + buf_in * MC_COUNT, c->misc_persist.as<FixedPersist>() + buf_out * MC_COUNT);
+        if (rc != SCPR_OK) return rc;
+      } else if (!(load_first && ngens == 1)) {  // a new generation without any P-frame symbol: its P-frame models are the renewed ones, not the kept ones
+        HIPCHK(hipMemsetAsync(c->misc_persist.as<FixedPersist>() + buf_out * MC_COUNT, 0, MC_COUNT * sizeof(FixedPersist), s2));
+      }
     }
-    if (Mtot)
-      hipLaunchKernelGGL(k_misc_chain, dim3(MC_COUNT, ngens), dim3(64), 0, s2, c->misc.as<u32>(), c->miscpos.as<u32>(), c->miscranges.as<MiscRange>(), ngens, load_first ? 1 : 0,
-                         c->misc_persist.as<FixedPersist>() + buf_in * MC_COUNT, c->misc_persist.as<FixedPersist>() + buf_out * MC_COUNT, c->entries.as<u32>());
-    else if (!(load_first && ngens == 1))  // a new generation without any P-frame symbol: its P-frame models are the renewed ones, not the kept ones
-      HIPCHK(hipMemsetAsync(c->misc_persist.as<FixedPersist>() + buf_out * MC_COUNT, 0, MC_COUNT * sizeof(FixedPersist), s2));
     stage_end(c, ST_FIXED, s2);
     HIPCHK(hipEventRecord(c->ev_join, s2));
   }
@@ -698,7 +712,7 @@ void scpr_destroy(scpr_codec* c) {
   DevBuf* all[] = {&c->planes, &c->tnmap, &c->exitmap, &c->entry, &c->runrec, &c->tilecnt, &c->tileoff, &c->hdrrec, &c->hdrcnt, &c->frametot, &c->flags, &c->slotlist, &c->genlist,
                    &c->bases, &c->totals, &c->runs, &c->runpos, &c->keys[0], &c->keys[1], &c->vals[0], &c->vals[1], &c->cstart, &c->sorttmp,
                    &c->entries, &c->ranges, &c->rblocks, &c->rscratch, &c->rsize, &c->packets, &c->pktoff, &c->blkdst, &c->outsizes, &c->total64, &c->arena,
-                   &c->arena_top, &c->err, &c->rcp, &c->decframes, &c->decstates, &c->hoststage_in, &c->hoststage_out, &c->chainlists, &c->chaincounts, &c->fixcnt, &c->fixoff, &c->fixtot, &c->fixsym, &c->fixpos, &c->fixgen, &c->kinds, &c->pidx, &c->fidx, &c->pframes, &c->pflag, &c->binfo, &c->smv, &c->btype, &c->bmv, &c->bcnt, &c->boff, &c->bflag, &c->pinfo, &c->ptot, &c->pbase, &c->misc, &c->miscpos, &c->miscranges, &c->mvs, &c->mvs_keep, &c->fixed_persist, &c->misc_persist, &c->colour_persist, &c->decgops, &c->decfixed, &c->dec_fixed_persist, &c->dec_colour_persist, &c->dec_arena, &c->dec_arena2, &c->arena2, &c->dec_arena_top, &c->mvdict, &c->mvpre, &c->gmask};
+                   &c->arena_top, &c->err, &c->rcp, &c->decframes, &c->decstates, &c->hoststage_in, &c->hoststage_out, &c->chainlists, &c->chaincounts, &c->fixr.cnt, &c->fixr.off, &c->fixr.tot, &c->fixr.sym, &c->fixr.pos, &c->fixr.gen, &c->fixm.cnt, &c->fixm.off, &c->fixm.tot, &c->fixm.sym, &c->fixm.pos, &c->fixm.gen, &c->kinds, &c->pidx, &c->fidx, &c->pframes, &c->pflag, &c->binfo, &c->smv, &c->btype, &c->bmv, &c->bcnt, &c->boff, &c->bflag, &c->pinfo, &c->ptot, &c->pbase, &c->misc, &c->miscpos, &c->miscranges, &c->mvs, &c->mvs_keep, &c->fixed_persist, &c->misc_persist, &c->colour_persist, &c->decgops, &c->decfixed, &c->dec_fixed_persist, &c->dec_colour_persist, &c->dec_arena, &c->dec_arena2, &c->arena2, &c->dec_arena_top, &c->mvdict, &c->mvpre, &c->gmask};
   for (DevBuf* b : all) b->release();
   for (int s = 0; s < ST_COUNT + 1; s++)
     for (int k = 0; k < 2; k++) (void)hipEventDestroy(c->ev[s][k]);

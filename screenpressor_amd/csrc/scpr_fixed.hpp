@@ -1,73 +1,116 @@
 // Fixed-alphabet chains of the encoder (FixedSizeRansCtx, ans_contexts.h:1054-1132): the six pixel-type models (keyed by the
-// previous run's type) and the six run-length models (keyed by the run's type) of a generation, over the unified run list.
+// previous run's type) and the six run-length models (keyed by the run's type) of a generation over the unified run list, and
+// the nine P-frame models (block index bytes, block-type runs, block types, four rect coordinates, two vector components) over
+// the list of P-frame symbols.
 //
 // A model's table only changes when its running total crosses the scale (incrCnt, :1070-1091), after a number of symbols that
 // is known when the epoch starts: the symbols up to there are independent lookups, the rebuild is a wave prefix scan.  What
-// the chain of ONE model needs is therefore its own symbols, densely, in stream order: round 2's k_fixed_chain walked the whole
-// run list with every one of its twelve waves, 64 runs at a time, and kept the few its model was concerned with - on a one-GOP
-// stream (one generation, 3 M runs) that was one workgroup for 79 ms.  Here the run list is first PARTITIONED by model, stably
-// (count per block of 2048 runs, scan, scatter: two streaming passes), and a chain then takes 64 of its own symbols per trip,
-// with the next trip's loads in flight.
+// the chain of ONE model needs is therefore its own symbols, densely, in stream order: round 2's chains walked the whole list
+// with every one of their waves, 64 elements at a time, and kept the few their model was concerned with - on a one-GOP stream
+// (one generation, 3 M runs, 7 M P-frame symbols) that was one workgroup for 79 ms.  Here the lists are first PARTITIONED by
+// model, stably (count per block of 2048 elements, scan, scatter: two streaming passes, every thread over eight consecutive
+// elements, two barriers per block), and a chain then takes 256 of its own symbols per trip with the next trips' loads in flight.
 //
-//   k_fix_count     per block of FIX_B runs: how many belong to each of the twelve models
-//   k_fix_scan      per model: exclusive scan of the block counts (+ the model's total)
-//   k_fix_scatter   every run to its place in the list of its pixel-type model and of its run-length model: symbol, position
-//   k_fix_genstart  where each generation's share of each model's list begins and ends
-//   k_fixed_chain2  one workgroup per generation, one wave per model: the epoch-parallel chain over the model's own list
+//   k_part_count     per block of PART_B elements: how many items belong to each model
+//   k_part_scan      per model: exclusive scan of the block counts (+ the model's total)
+//   k_part_scatter   every item to its place in its model's list: symbol, stream position
+//   k_part_genstart  where each generation's share of each model's list begins and ends
+//   k_fixed_chain2   one workgroup per generation, one wave per model: the epoch-parallel chain over the model's own list
 #pragma once
 #include "scpr_wave.hpp"
+#include "scpr_inter.hpp"
 
 namespace scpr {
 
-constexpr int FIX_B = 2048;       // runs per partition block (256 threads x 8 rounds)
-constexpr int FIX_CLASSES = 12;   // 0..5 pixel-type model keyed by the previous type, 6..11 run-length model keyed by the type
+constexpr int PART_B = 2048;  // elements per partition block (256 threads x 8 consecutive elements)
 
-// the two models a run belongs to (-1: a header run codes no pixel type), its two symbols and their stream positions
-struct FixRun {
-  int ct, cn;
-  u32 st, sn, pt, pn;
+// What a list element contributes: up to two items (model, symbol, stream position); model -1: none.
+struct RunItems {  // runs[i], runpos[i]: the run's pixel type goes to the model of the previous type (a header run codes none),
+                   // its length to the model of its own type
+  static constexpr int NCLS = 12;
+  static __device__ __forceinline__ void get(u32 r, u32 pos, int& c0, u32& s0, u32& p0, int& c1, u32& s1, u32& p1) {
+    const int type = (int)(r & 7u), lastt = (int)((r >> 3) & 7u);
+    const bool hdr = (r >> 31) != 0;
+    c0 = hdr ? -1 : lastt;
+    s0 = (u32)type;
+    p0 = pos;
+    c1 = 6 + type;
+    s1 = (r >> 8) & 255u;
+    p1 = pos + (hdr ? 3u : (type == 0 ? 4u : 1u));  // a literal's three colour bytes sit between the type and the length
+  }
+  static __device__ __forceinline__ int nsym(int cls) { return cls >= 6 ? 256 : 6; }
 };
-__device__ __forceinline__ FixRun fix_run(u32 r, u32 pos) {
-  const int type = (int)(r & 7u), lastt = (int)((r >> 3) & 7u);
-  const bool hdr = (r >> 31) != 0;
-  FixRun f;
-  f.ct = hdr ? -1 : lastt;
-  f.cn = 6 + type;
-  f.st = (u32)type;
-  f.sn = (r >> 8) & 255u;
-  f.pt = pos;
-  f.pn = pos + (hdr ? 3u : (type == 0 ? 4u : 1u));  // a literal's three colour bytes sit between the type and the length
-  return f;
+struct MiscItems {  // misc[i] = model << 16 | symbol, miscpos[i]
+  static constexpr int NCLS = MC_COUNT;
+  static __device__ __forceinline__ void get(u32 v, u32 pos, int& c0, u32& s0, u32& p0, int& c1, u32& s1, u32& p1) {
+    c0 = (int)(v >> 16);
+    s0 = v & 0xFFFFu;
+    p0 = pos;
+    c1 = -1;
+    s1 = p1 = 0;
+  }
+  static __device__ __forceinline__ int nsym(int cls) { return cls == MC_BT ? 5 : (cls >= MC_SXY && cls < MC_SXY + 4) ? 16 : (cls >= MC_MX) ? 512 : 256; }
+};
+
+// per-model counters of a thread (or, summed, of a wave: at most 512): 10-bit fields, three to a word
+template <int NW>
+__device__ __forceinline__ void fld_add(u32 (&w)[NW], int c) {
+  const int k = (c * 11) >> 5, sh = 10 * (c - 3 * k);  // c / 3 for c < 12
+#pragma unroll
+  for (int q = 0; q < NW; q++) w[q] += q == k ? 1u << sh : 0u;
+}
+template <int NW>
+__device__ __forceinline__ u32 fld_get(const u32 (&w)[NW], int c) {
+  const int k = (c * 11) >> 5, sh = 10 * (c - 3 * k);
+  u32 v = 0;
+#pragma unroll
+  for (int q = 0; q < NW; q++) v = q == k ? w[q] : v;
+  return (v >> sh) & 1023u;
 }
 
-__global__ __launch_bounds__(256) void k_fix_count(const u32* __restrict__ runs, u32 R, u32* __restrict__ blkcnt, u32 nblk) {
-  __shared__ u32 cnt[FIX_CLASSES];
-  if (threadIdx.x < FIX_CLASSES) cnt[threadIdx.x] = 0;
+template <class SRC>
+__global__ __launch_bounds__(256) void k_part_count(const u32* __restrict__ el, u32 n, u32* __restrict__ blkcnt, u32 nblk) {
+  constexpr int NC = SRC::NCLS, NW = (NC + 2) / 3;
+  __shared__ u32 cnt[NC];
+  if (threadIdx.x < NC) cnt[threadIdx.x] = 0;
   __syncthreads();
-  u32 mine[FIX_CLASSES];
+  u32 w[NW];
 #pragma unroll
-  for (int c = 0; c < FIX_CLASSES; c++) mine[c] = 0;
-  for (int it = 0; it < FIX_B / 256; it++) {
-    const u32 i = blockIdx.x * FIX_B + it * 256 + threadIdx.x;
-    const bool ok = i < R;
-    const FixRun f = fix_run(ok ? runs[i] : 0x80000000u, 0);
-#pragma unroll
-    for (int c = 0; c < FIX_CLASSES; c++) {
-      const u64 b = __ballot(ok && (c < 6 ? f.ct == c : f.cn == c));
-      mine[c] += (u32)__builtin_popcountll(b);  // (the same in every lane of the wave)
+  for (int q = 0; q < NW; q++) w[q] = 0;
+  const u32 i0 = blockIdx.x * PART_B + threadIdx.x * 8;
+  if (i0 < n) {
+    u32 v[8];
+    if (i0 + 8 <= n) {
+      *(uint4*)&v[0] = *(const uint4*)(el + i0);
+      *(uint4*)&v[4] = *(const uint4*)(el + i0 + 4);
+    } else {
+      for (int q = 0; q < 8; q++) v[q] = i0 + q < n ? el[i0 + q] : 0;
     }
+#pragma unroll
+    for (int q = 0; q < 8; q++)
+      if (i0 + q < n) {
+        int c0, c1;
+        u32 s0, p0, s1, p1;
+        SRC::get(v[q], 0, c0, s0, p0, c1, s1, p1);
+        if (c0 >= 0) fld_add<NW>(w, c0);
+        if (c1 >= 0) fld_add<NW>(w, c1);
+      }
   }
+#pragma unroll
+  for (int q = 0; q < NW; q++) w[q] = (u32)wave_sum((int)w[q]);  // (fields stay below 1024: 64 lanes x 8)
   if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-    for (int c = 0; c < FIX_CLASSES; c++)
-      if (mine[c]) atomicAdd(&cnt[c], mine[c]);
+    for (int c = 0; c < NC; c++) {
+      const u32 k = fld_get<NW>(w, c);
+      if (k) atomicAdd(&cnt[c], k);
+    }
   }
   __syncthreads();
-  if (threadIdx.x < FIX_CLASSES) blkcnt[(size_t)threadIdx.x * (nblk + 1) + blockIdx.x] = cnt[threadIdx.x];
+  if (threadIdx.x < NC) blkcnt[(size_t)threadIdx.x * (nblk + 1) + blockIdx.x] = cnt[threadIdx.x];
 }
 
-// blkoff[c][b] = runs of model c before block b (b = nblk: the model's total, also written to ctotal[c])
-__global__ __launch_bounds__(256) void k_fix_scan(const u32* __restrict__ blkcnt, u32* __restrict__ blkoff, u32 nblk, u32* __restrict__ ctotal) {
+// blkoff[c][b] = items of model c before block b (b = nblk: the model's total, also written to ctotal[c])
+__global__ __launch_bounds__(256) void k_part_scan(const u32* __restrict__ blkcnt, u32* __restrict__ blkoff, u32 nblk, u32* __restrict__ ctotal) {
   __shared__ u32 part[256];
   const int c = blockIdx.x, t = threadIdx.x;
   const u32* in = blkcnt + (size_t)c * (nblk + 1);
@@ -95,72 +138,111 @@ __global__ __launch_bounds__(256) void k_fix_scan(const u32* __restrict__ blkcnt
   }
 }
 
-// Stable: a model's list holds its runs in run-list (= stream) order.  fl_sym / fl_pos: the twelve lists back to back.
-__global__ __launch_bounds__(256) void k_fix_scatter(const u32* __restrict__ runs, const u32* __restrict__ runpos, u32 R, const u32* __restrict__ blkoff, u32 nblk,
-                                                     const u32* __restrict__ ctotal, u8* __restrict__ fl_sym, u32* __restrict__ fl_pos) {
-  __shared__ u32 base[FIX_CLASSES], wcnt[4][FIX_CLASSES];
-  const int wv = threadIdx.x >> 6;
-  if (threadIdx.x < FIX_CLASSES) {
-    u32 cb = 0;
-    for (int c = 0; c < (int)threadIdx.x; c++) cb += ctotal[c];
-    base[threadIdx.x] = cb + blkoff[(size_t)threadIdx.x * (nblk + 1) + blockIdx.x];
+// Stable: a model's list holds its items in list (= stream) order.  fl_sym / fl_pos: the models' lists back to back.
+template <class SRC>
+__global__ __launch_bounds__(256) void k_part_scatter(const u32* __restrict__ el, const u32* __restrict__ elpos, u32 n, const u32* __restrict__ blkoff, u32 nblk,
+                                                      const u32* __restrict__ ctotal, u16* __restrict__ fl_sym, u32* __restrict__ fl_pos) {
+  constexpr int NC = SRC::NCLS, NW = (NC + 2) / 3;
+  __shared__ u32 wtot[4][NW], wb[4][NC];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const u32 i0 = blockIdx.x * PART_B + threadIdx.x * 8;
+  u32 v[8], ps[8];
+#pragma unroll
+  for (int q = 0; q < 8; q++) v[q] = ps[q] = 0;
+  if (i0 + 8 <= n) {
+    *(uint4*)&v[0] = *(const uint4*)(el + i0);
+    *(uint4*)&v[4] = *(const uint4*)(el + i0 + 4);
+    *(uint4*)&ps[0] = *(const uint4*)(elpos + i0);
+    *(uint4*)&ps[4] = *(const uint4*)(elpos + i0 + 4);
+  } else {
+    for (int q = 0; q < 8; q++)
+      if (i0 + q < n) v[q] = el[i0 + q], ps[q] = elpos[i0 + q];
+  }
+  u32 w[NW];
+#pragma unroll
+  for (int q = 0; q < NW; q++) w[q] = 0;
+#pragma unroll
+  for (int q = 0; q < 8; q++)
+    if (i0 + q < n) {
+      int c0, c1;
+      u32 s0, p0, s1, p1;
+      SRC::get(v[q], ps[q], c0, s0, p0, c1, s1, p1);
+      if (c0 >= 0) fld_add<NW>(w, c0);
+      if (c1 >= 0) fld_add<NW>(w, c1);
+    }
+  u32 pre[NW];  // items of each model in the lanes before this one (of the wave)
+#pragma unroll
+  for (int q = 0; q < NW; q++) {
+    const u32 inc = (u32)wave_incl_scan((int)w[q]);
+    pre[q] = inc - w[q];
+    if (lane == 63) wtot[wv][q] = inc;
   }
   __syncthreads();
-  for (int it = 0; it < FIX_B / 256; it++) {
-    const u32 i = blockIdx.x * FIX_B + it * 256 + threadIdx.x;
-    const bool ok = i < R;
-    const FixRun f = fix_run(ok ? runs[i] : 0x80000000u, ok ? runpos[i] : 0u);
-    u32 rt = 0, rn = 0;
-    const u64 lt = lanemask_lt();
+  if (threadIdx.x < NC) {  // where each wave's items of model c begin: the model's place in the lists + the blocks before + the waves before
+    const int c = threadIdx.x;
+    u32 at = blkoff[(size_t)c * (nblk + 1) + blockIdx.x];
+    for (int k = 0; k < c; k++) at += ctotal[k];
+    for (int q = 0; q < 4; q++) {
+      wb[q][c] = at;
+      u32 t[NW];
 #pragma unroll
-    for (int c = 0; c < FIX_CLASSES; c++) {
-      const bool in = ok && (c < 6 ? f.ct == c : f.cn == c);
-      const u64 b = __ballot(in);
-      if (in) (c < 6 ? rt : rn) = (u32)__builtin_popcountll(b & lt);
-      if ((threadIdx.x & 63) == 0) wcnt[wv][c] = (u32)__builtin_popcountll(b);
+      for (int z = 0; z < NW; z++) t[z] = wtot[q][z];
+      at += fld_get<NW>(t, c);
     }
-    __syncthreads();
-    if (ok) {
-      if (f.ct >= 0) {
-        u32 d = base[f.ct] + rt;
-        for (int w = 0; w < wv; w++) d += wcnt[w][f.ct];
-        fl_sym[d] = (u8)f.st;
-        fl_pos[d] = f.pt;
-      }
-      u32 d = base[f.cn] + rn;
-      for (int w = 0; w < wv; w++) d += wcnt[w][f.cn];
-      fl_sym[d] = (u8)f.sn;
-      fl_pos[d] = f.pn;
-    }
-    __syncthreads();
-    if (threadIdx.x < FIX_CLASSES) base[threadIdx.x] += wcnt[0][threadIdx.x] + wcnt[1][threadIdx.x] + wcnt[2][threadIdx.x] + wcnt[3][threadIdx.x];
-    __syncthreads();
   }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 8; q++)
+    if (i0 + q < n) {
+      int c0, c1;
+      u32 s0, p0, s1, p1;
+      SRC::get(v[q], ps[q], c0, s0, p0, c1, s1, p1);
+      if (c0 >= 0) {
+        const u32 d = wb[wv][c0] + fld_get<NW>(pre, c0);
+        fl_sym[d] = (u16)s0;
+        fl_pos[d] = p0;
+        fld_add<NW>(pre, c0);
+      }
+      if (c1 >= 0) {
+        const u32 d = wb[wv][c1] + fld_get<NW>(pre, c1);
+        fl_sym[d] = (u16)s1;
+        fl_pos[d] = p1;
+        fld_add<NW>(pre, c1);
+      }
+    }
 }
 
-// gstart[(c * ngens + g) * 2 + {0, 1}]: first and one-past-last index of generation g's symbols in model c's part of the lists
-__global__ __launch_bounds__(64) void k_fix_genstart(const u32* __restrict__ runs, u32 R, const GenRange* __restrict__ ranges, int ngens, const u32* __restrict__ blkoff, u32 nblk,
-                                                     const u32* __restrict__ ctotal, u32* __restrict__ gstart) {
+// gstart[(c * ngens + g) * 2 + {0, 1}]: first and one-past-last index of generation g's items in model c's part of the lists.
+// ranges: the generation's [begin, end) in the element list (GenRange / MiscRange: two words).
+template <class SRC>
+__global__ __launch_bounds__(64) void k_part_genstart(const u32* __restrict__ el, u32 n, const uint2* __restrict__ ranges, int ngens, const u32* __restrict__ blkoff, u32 nblk,
+                                                      const u32* __restrict__ ctotal, u32* __restrict__ gstart) {
+  constexpr int NC = SRC::NCLS, NW = (NC + 2) / 3;
   const int g = blockIdx.x, lane = threadIdx.x;
-  const GenRange rg = ranges[g];
+  const uint2 rg = ranges[g];
   for (int e = 0; e < 2; e++) {
-    const u32 idx = min(e ? rg.run_end : rg.run_begin, R);
-    const u32 blk = idx / FIX_B;
-    u32 part[FIX_CLASSES];
+    const u32 idx = min(e ? rg.y : rg.x, n);
+    const u32 blk = idx / PART_B;
+    u32 w[NW];  // this lane's 32 consecutive elements of the block, as far as they lie before idx (a field stays below 64)
 #pragma unroll
-    for (int c = 0; c < FIX_CLASSES; c++) part[c] = 0;
-    for (u32 i0 = blk * FIX_B; i0 < idx; i0 += 64) {
-      const u32 i = i0 + lane;
-      const bool ok = i < idx;
-      const FixRun f = fix_run(ok ? runs[i] : 0x80000000u, 0);
-#pragma unroll
-      for (int c = 0; c < FIX_CLASSES; c++) part[c] += (u32)__builtin_popcountll(__ballot(ok && (c < 6 ? f.ct == c : f.cn == c)));
+    for (int q = 0; q < NW; q++) w[q] = 0;
+    const u32 i0 = blk * PART_B + (u32)lane * 32u;
+    for (u32 i = i0; i < min(idx, i0 + 32u); i++) {
+      int c0, c1;
+      u32 s0, p0, s1, p1;
+      SRC::get(el[i], 0, c0, s0, p0, c1, s1, p1);
+      if (c0 >= 0) fld_add<NW>(w, c0);
+      if (c1 >= 0) fld_add<NW>(w, c1);
     }
-    if (lane < FIX_CLASSES) {
-      u32 cb = 0, mine = 0;
-      for (int c = 0; c < lane; c++) cb += ctotal[c];
+    u32 mine = 0;
 #pragma unroll
-      for (int c = 0; c < FIX_CLASSES; c++) mine = c == lane ? part[c] : mine;
+    for (int c = 0; c < NC; c++) {
+      const u32 t = (u32)wave_sum((int)fld_get<NW>(w, c));
+      mine = c == lane ? t : mine;
+    }
+    if (lane < NC) {
+      u32 cb = 0;
+      for (int c = 0; c < lane; c++) cb += ctotal[c];
       gstart[((size_t)lane * ngens + g) * 2 + e] = cb + blkoff[(size_t)lane * (nblk + 1) + blk] + mine;
     }
   }
@@ -168,16 +250,18 @@ __global__ __launch_bounds__(64) void k_fix_genstart(const u32* __restrict__ run
 
 // persist_in / persist_out: the tables kept between calls (P-frames continue the models, screencap.cpp:1118).  They are the same
 // array when the call has one generation; with several, the first generation's workgroup reads while the last one's writes, so
-// the host hands out two arrays and swaps them.
-__global__ __launch_bounds__(768) void k_fixed_chain2(const u8* __restrict__ fl_sym, const u32* __restrict__ fl_pos, const u32* __restrict__ gstart, int ngens, int load_first,
-                                                      const FixedPersist* persist /* [12] */, FixedPersist* persist_out, u32* __restrict__ entries) {
+// the host hands out two arrays and swaps them.  Dynamic LDS: 2 * MAXSYM words per wave.
+template <class SRC, int MAXSYM>
+__global__ __launch_bounds__(64 * SRC::NCLS) void k_fixed_chain2(const u16* __restrict__ fl_sym, const u32* __restrict__ fl_pos, const u32* __restrict__ gstart, int ngens, int load_first,
+                                                                 const FixedPersist* persist /* [NCLS] */, FixedPersist* persist_out, u32* __restrict__ entries) {
   // one wave per model; a wave owns its table: fc = freq | cum << 16 (what goes to the coder as it is), cnt; lanes of a wave
   // talk through LDS in program order (wavefront fences only, no barriers)
-  __shared__ u32 tab[FIX_CLASSES][2][256];
+  extern __shared__ __align__(16) u32 chain_lds[];
   const int cls = threadIdx.x >> 6, gen = blockIdx.x, lane = threadIdx.x & 63;
-  u32* fc = tab[cls][0];
-  u32* cnt = tab[cls][1];
-  const int nsym = cls >= 6 ? 256 : 6;
+  u32* fc = chain_lds + (size_t)cls * 2 * MAXSYM;
+  u32* cnt = fc + MAXSYM;
+  const int nsym = SRC::nsym(cls);
+  const int per = nsym >= 64 ? nsym >> 6 : 1;  // table entries per lane in a rebuild (lanes past the alphabet hold none)
   int total;
   if (gen == 0 && load_first && persist[cls].valid) {
     for (int j = lane; j < nsym; j += 64) {
@@ -197,14 +281,16 @@ __global__ __launch_bounds__(768) void k_fixed_chain2(const u8* __restrict__ fl_
   wave_fence();
   const u32 s = rfl(gstart[((size_t)cls * ngens + gen) * 2]), e = rfl(gstart[((size_t)cls * ngens + gen) * 2 + 1]);
   // A trip is 256 symbols, four consecutive ones per lane (symbol i of the trip: lane i / 4, slot i % 4), and the loads of the
-  // next TWO trips are in flight while one is coded: the list streams from HBM (a microsecond away), a trip is a few hundred
-  // cycles of work, and with one trip of 64 in flight the chain spent its time waiting for its own input.
-  auto ld_sym = [&](u32 at) __attribute__((always_inline)) -> u32 {  // four symbols (bytes) from list index `at` (any alignment)
-    u32 v = 0;
+  // next two trips are in flight while one is coded (the list streams from HBM).
+  auto ld_sym = [&](u32 at) __attribute__((always_inline)) -> uint2 {  // four 16-bit symbols from list index `at` (any alignment)
+    uint2 v = make_uint2(0, 0);
     if (at + 4 <= e) {
-      __builtin_memcpy(&v, fl_sym + at, 4);
+      __builtin_memcpy(&v, fl_sym + at, 8);
     } else {
-      for (u32 q = 0; q < 4 && at + q < e; q++) v |= (u32)fl_sym[at + q] << (8 * q);
+      u32 t[4] = {0, 0, 0, 0};
+      for (u32 q = 0; q < 4 && at + q < e; q++) t[q] = fl_sym[at + q];
+      v.x = t[0] | (t[1] << 16);
+      v.y = t[2] | (t[3] << 16);
     }
     return v;
   };
@@ -219,17 +305,18 @@ __global__ __launch_bounds__(768) void k_fixed_chain2(const u8* __restrict__ fl_
     }
     return v;
   };
-  u32 sy1 = 0, sy2 = 0;
+  uint2 sy1 = make_uint2(0, 0), sy2 = sy1;
   uint4 po1 = make_uint4(0, 0, 0, 0), po2 = po1;
   if (s + 4u * lane < e) sy1 = ld_sym(s + 4u * lane), po1 = ld_pos(s + 4u * lane);
   if (s + 256u + 4u * lane < e) sy2 = ld_sym(s + 256u + 4u * lane), po2 = ld_pos(s + 256u + 4u * lane);
   for (u32 base = s; base < e; base += 256) {
-    const u32 sy = sy1;
+    const uint2 sy = sy1;
     const uint4 po = po1;
     sy1 = sy2, po1 = po2;
     if (base + 512u + 4u * lane < e) sy2 = ld_sym(base + 512u + 4u * lane), po2 = ld_pos(base + 512u + 4u * lane);
     const int cntm = (int)min(256u, e - base);
     const u32 pq[4] = {po.x, po.y, po.z, po.w};
+    const u32 sq[4] = {sy.x & 0xFFFFu, sy.x >> 16, sy.y & 0xFFFFu, sy.y >> 16};
     int done = 0;
     while (done < cntm) {
       const int room = (kProbScale - kStepDense - total) / kStepDense + 1;  // the room-th symbol from here brings the rebuild on
@@ -238,33 +325,34 @@ __global__ __launch_bounds__(768) void k_fixed_chain2(const u8* __restrict__ fl_
       for (int q = 0; q < 4; q++) {
         const int i = 4 * lane + q;
         if (i >= done && i < done + take) {
-          const u32 sym = (sy >> (8 * q)) & 255u;
-          entries[pq[q]] = fc[sym];
-          atomicAdd(&cnt[sym], (u32)kStepDense);
+          entries[pq[q]] = fc[sq[q]];
+          atomicAdd(&cnt[sq[q]], (u32)kStepDense);
         }
       }
       total += kStepDense * take;
       done += take;
       wave_fence();
       if (take == room) {  // counts become the frequencies (incrCnt, ans_contexts.h:1075-1090)
-        if (nsym == 256) {
-          const uint4 cq = ((const uint4*)cnt)[lane];
-          const int c0 = (int)cq.x, c1 = (int)cq.y, c2 = (int)cq.z, c3 = (int)cq.w, sum = c0 + c1 + c2 + c3;
-          const int cf = wave_incl_scan(sum) - sum;
-          ((uint4*)fc)[lane] = make_uint4((u32)c0 | ((u32)cf << 16), (u32)c1 | ((u32)(cf + c0) << 16), (u32)c2 | ((u32)(cf + c0 + c1) << 16), (u32)c3 | ((u32)(cf + c0 + c1 + c2) << 16));
-          const int h0 = c0 - (c0 >> 1), h1 = c1 - (c1 >> 1), h2 = c2 - (c2 >> 1), h3 = c3 - (c3 >> 1);
-          ((uint4*)cnt)[lane] = make_uint4((u32)h0, (u32)h1, (u32)h2, (u32)h3);
-          total = wave_sum(h0 + h1 + h2 + h3);
-        } else {
-          const int c = lane < 6 ? (int)cnt[lane] : 0;
-          const int inc = row_incl_scan(c);  // (six entries: inside the first row of sixteen lanes)
-          const int h = c - (c >> 1);
-          if (lane < 6) {
-            fc[lane] = (u32)c | ((u32)(inc - c) << 16);
-            cnt[lane] = (u32)h;
-          }
-          total = row16_sum(h);
+        int c[8], sum = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          const int j = lane * per + q;
+          c[q] = (q < per && j < nsym) ? (int)cnt[j] : 0;
+          sum += c[q];
         }
+        int cf = wave_incl_scan(sum) - sum, ns = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          const int j = lane * per + q;
+          if (q < per && j < nsym) {
+            fc[j] = (u32)c[q] | ((u32)cf << 16);
+            cf += c[q];
+            const int h = c[q] - (c[q] >> 1);
+            cnt[j] = (u32)h;
+            ns += h;
+          }
+        }
+        total = wave_sum(ns);
         wave_fence();
       }
     }

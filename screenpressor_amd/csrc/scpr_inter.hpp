@@ -902,95 +902,9 @@ __global__ __launch_bounds__(64) void k_pemit(const u8* __restrict__ planes, Geo
   });
 }
 
-// ---- misc fixed chains: one wave per (generation, context), same engine as k_fixed_chain ----
+// ---- the P-frame models' chains are in scpr_fixed.hpp (MiscItems) ----
 struct MiscRange {
   u32 begin, end;
 };
-__global__ __launch_bounds__(64) void k_misc_chain(const u32* __restrict__ misc, const u32* __restrict__ miscpos, const MiscRange* __restrict__ ranges, int ngens, int load_first,
-                                                   const FixedPersist* persist /* [MC_COUNT] */, FixedPersist* persist_out /* see k_fixed_chain */, u32* __restrict__ entries) {
-  __shared__ u32 freq[512], cum[512], cnt[512];
-  const int ctx = blockIdx.x, gen = blockIdx.y, lane = threadIdx.x;
-  const int nsym = ctx == MC_BT ? 5 : (ctx >= MC_SXY && ctx < MC_SXY + 4) ? 16 : (ctx >= MC_MX) ? 512 : 256;
-  int total;
-  if (gen == 0 && load_first && persist[ctx].valid) {
-    for (int j = lane; j < nsym; j += 64) {
-      freq[j] = persist[ctx].freq[j];
-      cum[j] = persist[ctx].cum[j];
-      cnt[j] = persist[ctx].cnt[j];
-    }
-    total = persist[ctx].total;
-  } else {
-    const int fr = kProbScale / nsym, c0 = fr - (fr >> 1);
-    for (int j = lane; j < nsym; j += 64) {
-      freq[j] = fr;
-      cum[j] = fr * j;
-      cnt[j] = c0;
-    }
-    total = c0 * nsym;
-  }
-  __syncthreads();
-  const MiscRange rg = ranges[gen];
-  for (u32 base = rg.begin; base < rg.end; base += 64) {
-    const u32 i = base + lane;
-    bool sel = false;
-    u32 sym = 0, pos = 0;
-    if (i < rg.end) {
-      const u32 v = misc[i];
-      sel = (int)(v >> 16) == ctx;
-      sym = v & 0xFFFF;
-      pos = miscpos[i];
-    }
-    const u64 m = __ballot(sel);
-    const int rank = __builtin_popcountll(m & lanemask_lt()), cntm = __builtin_popcountll(m);
-    int done = 0;
-    while (done < cntm) {
-      const int room = (kProbScale - kStepDense - total) / kStepDense + 1;
-      const int take = min(room, cntm - done);
-      if (sel && rank >= done && rank < done + take) {
-        entries[pos] = freq[sym] | (cum[sym] << 16);
-        atomicAdd(&cnt[sym], (u32)kStepDense);
-      }
-      total += kStepDense * take;
-      done += take;
-      __syncthreads();
-      if (take == room) {
-        const int per = (nsym + 63) >> 6, j0 = lane * per;
-        int s = 0;
-        for (int j = j0; j < j0 + per && j < nsym; j++) s += cnt[j];
-        int inc = s;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-          int tt = __shfl_up(inc, d);
-          if (lane >= d) inc += tt;
-        }
-        int cf = inc - s, ns = 0;
-        for (int j = j0; j < j0 + per && j < nsym; j++) {
-          int fr = cnt[j];
-          cum[j] = cf;
-          freq[j] = fr;
-          cf += fr;
-          fr -= fr >> 1;
-          cnt[j] = fr;
-          ns += fr;
-        }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) ns += __shfl_xor(ns, d);
-        total = ns;
-        __syncthreads();
-      }
-    }
-  }
-  if (gen == ngens - 1) {  // the last generation of the call is the live one
-    for (int j = lane; j < nsym; j += 64) {
-      persist_out[ctx].freq[j] = freq[j];
-      persist_out[ctx].cum[j] = cum[j];
-      persist_out[ctx].cnt[j] = cnt[j];
-    }
-    if (lane == 0) {
-      persist_out[ctx].total = total;
-      persist_out[ctx].valid = 1;
-    }
-  }
-}
 
 }  // namespace scpr

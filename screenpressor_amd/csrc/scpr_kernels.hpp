@@ -11,8 +11,8 @@
 //   k_scan_tiles / k_bases   prefix sums -> run / symbol / colour-symbol offsets
 //   k_symbols         unified run list + (context,value,position) of every colour symbol   (WritePixel/EncodeRGB, :609-643)
 //   (rocPRIM)         stable radix sort of colour symbols by (generation, plane, context)
-//   k_fixed_chain     one wave per fixed-alphabet context: epoch-parallel lookups,
-//                     LDS-resident table, wave prefix-scan rebuilds                  (FixedSizeRansCtx, ans_contexts.h:1054-1132)
+//   k_part_* / k_fixed_chain2 (scpr_fixed.hpp)  the run list partitioned by fixed-alphabet model, then one wave per model:
+//                     epoch-parallel lookups, LDS-resident table, wave prefix-scan rebuilds  (FixedSizeRansCtx, ans_contexts.h:1054-1132)
 //   k_colour_chain_w  one wave per colour context: the 7-kind state machine (scpr_wave.hpp) (Context, ans_contexts.cpp:34-50)
 //   k_rans            one lane per 131072-entry block: byte-wise rANS, reverse order (ransmt.h:116-134, rans_byte.h:59-102)
 //   k_offsets/k_gather  packet assembly
@@ -690,11 +690,7 @@ __global__ __launch_bounds__(256) void k_symbols(const u8* __restrict__ planes, 
 }
 
 // --------------------------------------------------------- fixed chains ---
-// One wave per (generation, fixed context).  The table only changes when the
-// running total crosses the scale, so all symbols up to that point are
-// independent lookups; the rebuild is a wave prefix-scan.
-// cls 0..5: pixel-type model keyed by the previous type; 6..11: run-length
-// model keyed by the type.
+// (the chains themselves are in scpr_fixed.hpp)
 struct GenRange {
   u32 run_begin, run_end;
 };
@@ -702,112 +698,6 @@ struct FixedPersist {  // one fixed-alphabet table as kept between calls (P-fram
   u32 freq[512], cum[512], cnt[512];
   int total, valid, pad0, pad1;
 };
-// persist_in / persist_out: the tables kept between calls.  They are the same array when the call has one
-// generation; with several, the first generation's workgroup reads while the last one's writes, so the
-// host hands out two arrays and swaps them.
-__global__ __launch_bounds__(768) void k_fixed_chain(const u32* __restrict__ runs, const u32* __restrict__ runpos, const GenRange* __restrict__ ranges, int ngens, int load_first,
-                                                     const FixedPersist* persist /* [12] */, FixedPersist* persist_out, u32* __restrict__ entries) {
-  // One workgroup per generation, one wave per model (cls 0..5 pixel types, 6..11 run lengths): the
-  // twelve waves walk the same run list, so it is fetched into this CU's L1 once.  Each wave owns its
-  // table; lanes of a wave talk through LDS in program order (wavefront fences only, no barriers).
-  __shared__ u32 tab[12][3][256];
-  const int cls = threadIdx.x >> 6, gen = blockIdx.x, lane = threadIdx.x & 63;
-  u32* freq = tab[cls][0];
-  u32* cum = tab[cls][1];
-  u32* cnt = tab[cls][2];
-  const bool is_n = cls >= 6;
-  const int key = is_n ? cls - 6 : cls, nsym = is_n ? 256 : 6;
-  int total;
-  if (gen == 0 && load_first && persist[cls].valid) {
-    for (int j = lane; j < nsym; j += 64) {
-      freq[j] = persist[cls].freq[j];
-      cum[j] = persist[cls].cum[j];
-      cnt[j] = persist[cls].cnt[j];
-    }
-    total = persist[cls].total;
-  } else {
-    const int fr = kProbScale / nsym, c0 = fr - (fr >> 1);
-    for (int j = lane; j < nsym; j += 64) {
-      freq[j] = fr;
-      cum[j] = fr * j;
-      cnt[j] = c0;
-    }
-    total = c0 * nsym;
-  }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  const GenRange rg = ranges[gen];
-  for (u32 base = rg.run_begin; base < rg.run_end; base += 64) {
-    const u32 i = base + lane;
-    bool sel = false;
-    u32 sym = 0, pos = 0;
-    if (i < rg.run_end) {
-      const u32 r = runs[i];
-      const int type = r & 7, lastt = (r >> 3) & 7;
-      const bool hdr = r >> 31;
-      if (is_n) {
-        sel = type == key;
-        sym = (r >> 8) & 255;
-        pos = runpos[i] + (hdr ? 3 : (type == 0 ? 4 : 1));
-      } else {
-        sel = !hdr && lastt == key;
-        sym = type;
-        pos = runpos[i];
-      }
-    }
-    const u64 m = __ballot(sel);
-    const int rank = __builtin_popcountll(m & lanemask_lt()), cntm = __builtin_popcountll(m);
-    int done = 0;
-    while (done < cntm) {
-      const int room = (kProbScale - kStepDense - total) / kStepDense + 1;
-      const int take = min(room, cntm - done);
-      if (sel && rank >= done && rank < done + take) {
-        entries[pos] = freq[sym] | (cum[sym] << 16);
-        atomicAdd(&cnt[sym], (u32)kStepDense);
-      }
-      total += kStepDense * take;
-      done += take;
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      if (take == room) {  // counts become the frequencies (incrCnt, ans_contexts.h:1075-1090)
-        const int per = (nsym + 63) >> 6, j0 = lane * per;
-        int s = 0;
-        for (int j = j0; j < j0 + per && j < nsym; j++) s += cnt[j];
-        int inc = s;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-          int t = __shfl_up(inc, d);
-          if (lane >= d) inc += t;
-        }
-        int cf = inc - s, ns = 0;
-        for (int j = j0; j < j0 + per && j < nsym; j++) {
-          int fr = cnt[j];
-          cum[j] = cf;
-          freq[j] = fr;
-          cf += fr;
-          fr -= fr >> 1;
-          cnt[j] = fr;
-          ns += fr;
-        }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) ns += __shfl_xor(ns, d);
-        total = ns;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      }
-    }
-  }
-  if (gen == ngens - 1) {  // the last generation of the call is the live one
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    for (int j = lane; j < nsym; j += 64) {
-      persist_out[cls].freq[j] = freq[j];
-      persist_out[cls].cum[j] = cum[j];
-      persist_out[cls].cnt[j] = cnt[j];
-    }
-    if (lane == 0) {
-      persist_out[cls].total = total;
-      persist_out[cls].valid = 1;
-    }
-  }
-}
-
 // -------------------------------------------------------- colour chains ---
 struct Arena {
   DenseTab* tabs;
