@@ -624,7 +624,7 @@ static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int n
   }
   stage_begin(c, ST_COLOUR);
   {
-    Arena ar{c->arena.as<DenseTab>(), c->arena_top.as<u32>(), (u32)arena_cap, c->err.as<u32>()};
+    Arena ar{c->arena.as<DenseTab>(), c->arena_top.as<u32>(), (u32)arena_cap - 1u, c->err.as<u32>()};  // (the last table allocated is the sink)
     const u32 stamp_out = (load_first && ngens == 1) ? c->live_stamp : c->next_stamp++;
     ChainPersist cp{c->colour_persist.as<ColState>() + (size_t)buf_in * NCOLCTX, c->colour_persist.as<ColState>() + (size_t)buf_out * NCOLCTX, c->live_stamp, stamp_out, load_first ? 1 : 0, ngens};
     c->live_stamp = stamp_out;
@@ -1124,9 +1124,9 @@ int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* 
       int rc = ensure_planes(c, (size_t)n);
       if (rc != SCPR_OK) return rc;
     }
-    // A chunk is decoded with a dense-table arena sized for what streams need in practice; the device reports an
-    // overflow (nothing is lost: the run scribbles on table 0, which is never a real table) and the chunk is then
-    // decoded again with the worst case (every context of every GOP dense, 12288 tables per GOP).
+    // A chunk of fresh GOPs is decoded with a dense-table arena sized from its packets (a table per 12 bytes of stream, below);
+    // should that not be enough the device reports an overflow (nothing is lost: the contexts past the end share the sink
+    // table) and the chunk is decoded again with the true bound (every context of every GOP dense, 12288 tables per GOP).
     const bool host_crashed = c->crashed, host_flat = c->last_flat;
     const u32 host_flat_rgb = c->last_flat_rgb, host_frames_done = c->frames_done;
     u32 errv[8] = {0};
@@ -1205,20 +1205,26 @@ int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* 
         c->dec_arena_used = 1;
         c->dec_live_bytes = 0;
       }
-      // Tables alive at the end of this chunk: a context goes dense once, after at least 16 of its symbols, each of which cost
-      // the stream about a byte or more (raw bytes while nothing repeats, one-slot intervals of a small table after that:
-      // ans_contexts.cpp:3-50) - counted over the whole GOP, earlier calls included - and never more than 12288 per GOP.
-      const size_t worst = v2 ? 0 : std::min<size_t>(ng * (size_t)NCOLCTX, (size_t)((c->dec_live_bytes + gop_bytes) / 12) + 8 * ng);
-      // (a chunk that continues a GOP is not decoded twice: its run changes the tables that GOP already owns)
-      const size_t budget = (attempt || cont) ? worst : std::min<size_t>(worst, ng * 1024);
-      // (the arena holds table 0 and the live GOP's tables when a chunk starts: compact_tables after every chunk with several GOPs)
-      const size_t arena_cap = std::min<size_t>(1 + ng * (size_t)NCOLCTX, c->dec_arena_used + budget) + 64;
+      // Tables alive at the end of this chunk.  The true bound is 12288 per GOP.  In practice a context goes dense once, after at
+      // least 16 of its symbols, each of which cost the stream about a byte or more (raw bytes while nothing repeats, one-slot
+      // intervals of a small table after that: ans_contexts.cpp:3-50; a table per 12 bytes of stream has never been seen
+      // exceeded) - counted over the whole GOP, earlier calls included.  The first attempt of a chunk of fresh GOPs gets that
+      // estimate (round 2 gave it a flat 1024 tables per GOP: a GOP of 300 desktop frames overflowed at frame ~220 and was decoded
+      // twice, 8.2 s instead of 4.2), the second attempt - and a chunk that continues a GOP, which cannot be decoded twice: its
+      // run changes the tables that GOP already owns - the true bound.
+      const size_t true_bound = ng * (size_t)NCOLCTX;
+      size_t estimate = std::min<size_t>(true_bound, (size_t)((c->dec_live_bytes + gop_bytes) / 12) + 8 * ng);
+      if (const char* dbg = getenv("SCPR_DEBUG_DEC_ARENA")) estimate = std::min<size_t>(estimate, (size_t)strtoull(dbg, nullptr, 0));  // (tests reach the second attempt)
+      const size_t budget = v2 ? 0 : (attempt || cont) ? true_bound : estimate;
+      // (the arena holds table 0 and the live GOP's tables when a chunk starts: compact_tables after every chunk with several GOPs;
+      // + 1: the sink of an overflow, + slack)
+      const size_t arena_cap = std::min<size_t>(1 + true_bound, c->dec_arena_used + budget) + 1 + 64;
       HIPCHK(c->dec_arena.reserve_keep(arena_cap * sizeof(DenseTab), c->dec_arena_used * sizeof(DenseTab), st));
       c->h_dec_top0 = (u32)c->dec_arena_used;  // (a member: the source of an asynchronous copy must outlive the call)
       HIPCHK(hipMemcpyAsync(c->dec_arena_top.p, &c->h_dec_top0, 4, hipMemcpyHostToDevice, st));
       HIPCHK(hipMemcpyAsync(c->decframes.p, fr.data(), fr.size() * sizeof(DecFrame), hipMemcpyHostToDevice, st));
       HIPCHK(hipMemcpyAsync(c->decgops.p, gops.data(), ng * sizeof(DecGop), hipMemcpyHostToDevice, st));
-      Arena ar{c->dec_arena.as<DenseTab>(), c->dec_arena_top.as<u32>(), (u32)arena_cap, c->err.as<u32>()};
+      Arena ar{c->dec_arena.as<DenseTab>(), c->dec_arena_top.as<u32>(), (u32)arena_cap - 1u, c->err.as<u32>()};  // (the last table allocated is the sink)
       // LDS ring of 32-bit pixels: the predictors look back one row + 1 pixel, a finished row is flushed at most
       // one run after it ends, and a run writes up to 255 pixels ahead: a power of two >= W + 512 pixels.
       // (Keeping static + dynamic LDS under 80 KiB lets two GOPs share a CU.)
@@ -1252,7 +1258,8 @@ int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* 
         // P-frame GOPs run as a workgroup: the chain's wave + helper waves for the bulk copies (scpr_wave.hpp, helper_loop) -
         // eight waves when every GOP has a CU to itself (six helpers: the wave that would share the chain's SIMD leaves at
         // once), four when CUs are shared (three helpers; two waves per SIMD at most: the chain keeps its 256 registers)
-        const unsigned threads = has_p ? (ng <= 256 ? 512u : 256u) : 64u;
+        static const bool no_helpers = getenv("SCPR_NO_HELPERS") != nullptr;  // (design aid: the chain's wave alone, for the counters of tools/decoder_pmc2.sh)
+        const unsigned threads = has_p && !no_helpers ? (ng <= 256 ? 512u : 256u) : 64u;
         hipLaunchKernelGGL(kern, dim3((unsigned)ng), dim3(threads), dyn, st, pk, pk_end, c->decframes.as<DecFrame>(), c->decgops.as<DecGop>(), c->planes.as<u8>(), g,
                            c->decstates.as<DecRec>(), ar, c->f0, c->err.as<u32>(), ring, c->decfixed.as<FixedBlob>(), (int)std::min<u32>(c->prm.high_range_x, 256),
                            (int)std::min<u32>(c->prm.high_range_y, 256), ndc, dcache_off);
@@ -1264,11 +1271,12 @@ int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* 
     if (ng) HIPCHK(hipMemcpyAsync(&atop, c->dec_arena_top.p, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));  // also covers fr / gops (host memory)
     HIPCHK(hipGetLastError());         // a kernel that could not be launched
-    if ((errv[0] & 1) && attempt == 0 && !(ng && gops[0].load)) continue;  // the arena was too small for this stream: once more with the worst case
-    // (bit 16 - a record named a table outside the arena, refused by the table cache - has only been seen in such a first
-    // attempt, in the row that is still decoded after the overflow; anywhere else it is an error of its own)
+    // A record that names a table beyond the arena's sink (bit 16; refused by the table cache, never followed) is an error of
+    // whatever attempt shows it, and always said: an overflow hands out the sink, so no state the decoder makes by itself holds
+    // such an index.
     if (errv[0] & 16) fprintf(stderr, "[scpr] decoder: a colour record named a dense table outside the arena (flags %u, attempt %d, %zu GOPs, continued %d)\n", errv[0], attempt, ng,
                               ng ? gops[0].load : 0);
+    if ((errv[0] & 1) && attempt == 0 && !(ng && gops[0].load)) continue;  // the estimate was too small for this stream: once more with the true bound
     if (ng && !(errv[0] & 5)) {
       // keep the state of the last GOP for the next call; with one GOP in the chunk its tables stay where they are
       // (top read back: the arena does not grow with the number of calls), with several the next call's first

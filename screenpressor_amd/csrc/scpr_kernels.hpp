@@ -700,7 +700,7 @@ struct FixedPersist {  // one fixed-alphabet table as kept between calls (P-fram
 };
 // -------------------------------------------------------- colour chains ---
 struct Arena {
-  DenseTab* tabs;
+  DenseTab* tabs;  // cap + 1 tables: 0 .. cap - 1 for contexts, table `cap` is the sink of an overflow (WaveModel::alloc_dense)
   u32* top;
   u32 cap;
   u32* err;

@@ -205,7 +205,7 @@ struct WaveModel {
 #ifdef SCPR_PROFILE
       dmiss++;
 #endif
-      if (SCPR_UNLIKELY(idx >= arena.cap)) {  // never a real table (a record that is not what it says): reported, not followed
+      if (SCPR_UNLIKELY(idx > arena.cap)) {  // beyond the sink: never a table (a record that is not what it says): reported, not followed
         if (lane == 0) atomicOr(arena.err, 16u);
         oom = true;
         return c;
@@ -327,12 +327,14 @@ struct WaveModel {
       }
     }
     idx = rfl(idx);
-    // From here on contexts share table 0 and overwrite each other's contents: whatever is decoded is thrown away (the host runs
-    // the chunk again with a larger arena), but it must stay harmless - a symbol looked up in such a table is kept inside 0..255
-    // (dense_hit / dense_impl), and the GOP's remaining frames are skipped.
+    // The arena is full: the context gets the SINK, table `cap` (allocated behind the usable ones, never a live context's
+    // table).  Contexts that share it overwrite each other's contents, so whatever is coded from here on is thrown away (the
+    // host runs the chunk again with the true bound, or fails the call), but it stays harmless: every record still names a
+    // table that exists, a symbol looked up in the sink is kept inside 0..255 (dense_hit / dense_impl), and the chain stops at
+    // its next check of `oom` (a row / a rect later at most).
     if (SCPR_UNLIKELY(idx >> 31)) {
       oom = true;
-      idx = 0;
+      idx = arena.cap;
     }
     return idx;
   }

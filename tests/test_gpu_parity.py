@@ -513,10 +513,12 @@ def test_a_near_window_wider_than_the_far_one_is_refused():
 
 
 def test_first_decode_attempt_overflows_its_arena_in_recycled_memory():
-    """A chunk is decoded with a small dense-table arena first and again with the worst case when that overflows (noise in all
-    channels: thousands of contexts go dense in one GOP).  After the overflow the first attempt used to decode on with
-    contexts sharing table 0, a state in which a record could name a table that does not exist - harmless in freshly mapped
-    (zero) memory, a wild address in memory that had held pictures.  The decoder now stops at the overflow."""
+    """A chunk of fresh GOPs is decoded with a dense-table arena sized from its packets and again with the true bound when that
+    overflows - never for a real stream (the estimate is a table per 12 bytes), so the first attempt is made small here
+    (SCPR_DEBUG_DEC_ARENA; noise in all channels: thousands of contexts go dense in one GOP).  After the overflow the contexts
+    past the end share the arena's sink table and the chain stops at its next check; the state in between used to be one in which
+    a record could name a table that does not exist - harmless in freshly mapped (zero) memory, a wild address in memory that
+    had held pictures."""
     import torch
     w, h, n = 400, 300, 5
     rng = np.random.default_rng(12)
@@ -531,9 +533,16 @@ def test_first_decode_attempt_overflows_its_arena_in_recycled_memory():
     pk, sizes, fts = _codec(w, h).CompressBatch(dev, [0] + [1] * (n - 1))
     assert pk.cpu().numpy().tobytes() == b"".join(p for p, _ in ref)
     dec = _codec(w, h)
-    r, out = dec.DecompressBatch(pk, sizes, fts)
+    os.environ["SCPR_DEBUG_DEC_ARENA"] = "1024"
+    try:
+        r, out = dec.DecompressBatch(pk, sizes, fts)
+    finally:
+        del os.environ["SCPR_DEBUG_DEC_ARENA"]
     assert r == n and torch.equal(out.reshape(n, -1), dev)
     assert dec.debug_arena()[1] > 1024 * 1536  # (the second attempt's arena: the first one's 1024 tables were not enough)
+    dec2 = _codec(w, h)  # (and at one go without the knob)
+    r, out = dec2.DecompressBatch(pk, sizes, fts)
+    assert r == n and torch.equal(out.reshape(n, -1), dev)
 
 
 def test_two_streams_interleaved_on_their_own_codecs():
