@@ -34,27 +34,27 @@ for sub in ("ip", "4k"):  # the I+P (configs[2]) and 4K (configs[3] share) runs
         if line:
             open(os.path.join(dst, f"{tag}_{sub}_bench_line.json"), "w").write(line[-1] + "\n")
 
-# 2. HBM traffic per kernel launch
+# 2. HBM traffic per kernel launch: the LARGEST launch of each kernel - the 300-frame batch of the timed step (the same command
+# also makes a pass with host transfers and a handful of one-frame calls for the per-frame latencies: small launches that an
+# average over dispatches would mix in)
 def pmc(d):
     f = find(d, "*counter_collection.csv")
-    acc, cnt = collections.defaultdict(float), collections.defaultdict(set)
+    per = collections.defaultdict(lambda: collections.defaultdict(float))
     if f:
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].split("(")[0].replace("void ", "")
-            acc[k] += float(r["Counter_Value"])
-            cnt[k].add(r["Dispatch_Id"])
-    return acc, cnt
+            per[k][r["Dispatch_Id"]] += float(r["Counter_Value"])
+    return {k: max(v.values()) for k, v in per.items()}, {k: len(v) for k, v in per.items()}
 fa, fc = pmc("pmc_FETCH_SIZE")
 wa, wc = pmc("pmc_WRITE_SIZE")
 ker = []
 for k in fa:
     if not k.startswith("scpr::") and "rocprim" not in k:
         continue
-    n = max(len(fc[k]), 1)
-    fkb, wkb = fa[k] / n, wa.get(k, 0.0) / max(len(wc.get(k, [1])), 1)
-    ker.append({"kernel": k, "launches": n, "FETCH_SIZE_KB_per_launch": fkb, "WRITE_SIZE_KB_per_launch": wkb, "hbm_bytes_per_launch": (2 * fkb + wkb) * 1024})
+    fkb, wkb = fa[k], wa.get(k, 0.0)
+    ker.append({"kernel": k, "launches_seen": fc[k], "FETCH_SIZE_KB_largest_launch": fkb, "WRITE_SIZE_KB_largest_launch": wkb, "hbm_bytes_per_launch": (2 * fkb + wkb) * 1024})
 json.dump({"command": "bench.py --no-others --steps 1 --warmup 0 --no-cpu (configs[1]: 300 x 1920x1080 key frames)",
-           "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and, in a separate run, --pmc WRITE_SIZE; counters are KB; FETCH_SIZE doubled (gfx950 reports half of a wide coalesced read, MI355X_MICROARCH.md HBM section); WRITE_SIZE taken as is",
+           "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and, in a separate run, --pmc WRITE_SIZE; counters are KB; FETCH_SIZE doubled (gfx950 reports half of a wide coalesced read, MI355X_MICROARCH.md HBM section); WRITE_SIZE taken as is; per kernel the largest dispatch (the 300-frame launch of the timed step)",
            "kernels": ker}, open(os.path.join(dst, f"{tag}_pmc_hbm_traffic.json"), "w"), indent=1)
 
 # 3. decoder instruction mix and waits (tools/decoder_pmc2.sh)
