@@ -53,6 +53,7 @@ def parse_args(argv=None):
     ap.add_argument("--c4-leg", action="store_true", help="run the configs[3] leg of an N > 1 run at N = 1 too (to rehearse it)")
     ap.add_argument("--c4-frames", type=int, default=None, help="frames of the configs[3] leg's stream (default 1200)")
     ap.add_argument("--no-others", action="store_true", help="N = 1: do not measure the other single-GPU configs")
+    ap.add_argument("--rehearse-one-gpu", action="store_true", help="N > 1 on a one-GPU box: every rank on GPU 0, collectives over gloo on CPU tensors (rehearses the multi-rank path with the real codecs; not a scaling measurement)")
     ap.add_argument("--selftest-launcher", action="store_true", help="no codec, no GPU: ranks exchange synthetic packets over gloo (tests the launcher, the sharding and the gather)")
     return ap.parse_args(argv)
 
@@ -263,7 +264,7 @@ def shard_seeder(env, wl, frames):
             except Exception as e:  # noqa: BLE001
                 seed.error = repr(e)
                 return np.zeros_like(mv_in)
-        mv = handover_mv_memory(env.dist, env.rank, env.world, enc.nblocks, prepass, device=env.dev) if env.world > 1 else None
+        mv = handover_mv_memory(env.dist, env.rank, env.world, enc.nblocks, prepass, device=env.cdev) if env.world > 1 else None
         if mv is not None:
             enc.ImportMvMemory(mv)
     seed.error = None
@@ -447,8 +448,9 @@ class Env:
     """what a rank runs on: one GPU + RCCL in the bench; CPU tensors + gloo + a stand-in codec in tests/test_sharding.py, which
     drives c4_leg() through the same collectives"""
 
-    def __init__(self, rank, world, dev, torch, dist, make_runner, render):
+    def __init__(self, rank, world, dev, torch, dist, make_runner, render, cdev=None):
         self.rank, self.world, self.dev, self.torch, self.dist, self.make_runner, self.render = rank, world, dev, torch, dist, make_runner, render
+        self.cdev = cdev if cdev is not None else dev  # where tensors handed to collectives live (the GPU under RCCL; the CPU under gloo)
 
     def sync(self):
         if self.dev is not None and self.dev.type == "cuda":
@@ -465,7 +467,7 @@ class Env:
             self.dist.all_reduce(t, op=op)
 
     def all_ok(self, ok):
-        t = self.torch.tensor([1 if ok else 0], device=self.dev, dtype=self.torch.int32)
+        t = self.torch.tensor([1 if ok else 0], device=self.cdev, dtype=self.torch.int32)
         self.all_reduce(t, self.dist.ReduceOp.MIN)
         return int(t.item()) == 1
 
@@ -479,7 +481,7 @@ def c4_leg(env, wl4, golden_name="stream_4k_ip_k150_1200"):
     order (a rank that skipped one would leave the others waiting, and the headline line would be lost with it).
     Returns the entry for config.others (meaningful on rank 0)."""
     from screenpressor_amd.sharding import gather_packets
-    torch, dist, rank, world, dev = env.torch, env.dist, env.rank, env.world, env.dev
+    torch, dist, rank, world, dev = env.torch, env.dist, env.rank, env.world, env.cdev
     ready, c4, f4, r4 = 1, None, None, None
     try:
         f4 = env.render(wl4)
@@ -556,7 +558,15 @@ def run_rank(args):
     sys.path.insert(0, ROOT)
     from screenpressor_amd.sharding import gather_packets
 
-    if world > 1:
+    cdev = None
+    if world > 1 and args.rehearse_one_gpu:
+        # every rank on GPU 0 (RCCL refuses two ranks on one device), the collectives over gloo on CPU tensors: the real codecs,
+        # sharding, hand-over and gather with more than one process, on a box that has one GPU
+        local_rank = 0
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        cdev = torch.device("cpu")
+    elif world > 1:
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         world = dist.get_world_size()  # the ranks RCCL actually has
@@ -565,7 +575,8 @@ def run_rank(args):
     W, H, BPP, N = wl.w, wl.h, wl.bpp, wl.n
     gop = 1 if args.workload == "keys" else (args.gop or (50 if args.workload == "ip" else 150))
     env = Env(rank, world, dev, torch, dist, lambda q: Runner(dev, local_rank, q.w, q.h, q.bpp, q.n),
-              lambda q: make_frames(q.w, q.h, q.seed, q.bpp, q.lo, q.hi, dev, world))
+              lambda q: make_frames(q.w, q.h, q.seed, q.bpp, q.lo, q.hi, dev, world), cdev)
+    cdev = env.cdev
 
     # synthetic input, resident in HBM before the timed region
     frames = env.render(wl)
@@ -576,12 +587,12 @@ def run_rank(args):
 
     def exchange(out, sizes):  # the exchange step: compressed chunks + sizes to rank 0 in frame order (RCCL over xGMI)
         if world > 1:
-            gathered["p"], gathered["s"] = gather_packets(dist, rank, world, out, sizes, device=dev)
+            gathered["p"], gathered["s"] = gather_packets(dist, rank, world, out, sizes, device=cdev)
 
     m = measure(runner, wl, frames, args.steps, args.warmup, barrier, seed, exchange)
     if seed is not None and seed.error:
         raise RuntimeError("motion pre-pass: " + seed.error)
-    tmax = torch.tensor([m["elapsed"]], device=dev, dtype=torch.float64)
+    tmax = torch.tensor([m["elapsed"]], device=cdev, dtype=torch.float64)
     env.all_reduce(tmax, dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
     ms_per_step = elapsed / args.steps * 1e3
@@ -671,7 +682,8 @@ def run_rank(args):
                    "sample": (f"the whole workload ({nf} frames)" if nf == N else f"first {nf} frames of the same workload") + ", encode+decode, oracle/libspo.so; "
                    "`value` is the faster of one thread and the all-cores two-stage shape", "host_cores": ncores, **res}
             assert parity["ok"], "the packets of the timed run differ from the oracle's"
-        config = {"workload": wl.name, "frames_per_gpu": N, "frames_total": total_frames, "parallelism": f"GOP/frame-sharded x{world}, one process per GPU",
+        config = {"workload": wl.name, **({"rehearsal": f"{world} ranks on ONE GPU, collectives over gloo on CPU tensors: not a scaling measurement"} if args.rehearse_one_gpu and world > 1 else {}),
+                  "frames_per_gpu": N, "frames_total": total_frames, "parallelism": f"GOP/frame-sharded x{world}, one process per GPU",
                   "compressed_bytes_rank0": comp_bytes,
                   "enc_MPix_s_rank0": round(N * W * H / 1e6 / m["t_enc"], 2), "dec_MPix_s_rank0": round(N * W * H / 1e6 / m["t_dec"], 2),
                   "stage_ms_per_step": {k: round(v, 3) for k, v in per_step.items()}}
