@@ -112,8 +112,8 @@ struct __attribute__((aligned(16))) WaveLds {
   u16 tmp[256];
   u32 dtag[64];        // tags of the dense-table cache (WaveModel::tab_of)
   FixedLdsP fp;
-  u32 tile[17 * 17];   // P-frame block under reconstruction, with one row above and one column to the left
-  u32 ptile[256];      // the same rect in the previous frame (row-major, w * h pixels): what "previous frame" runs copy
+  u32 tile[17 * 17 + 1];  // P-frame block under reconstruction, with one row above and one column to the left (+ a cell that takes the stores of idle lanes)
+  u32 ptile[256];      // the same rect in the previous frame (row-major, w * h pixels): what "previous frame" runs copy (must follow `tile`: decode_inter_frame reads it as cells past the tile's end)
   uint2 jobs[256];     // motion-block copies on their way to the helper waves (a ring, see hc)
   // Helper waves (P-frame GOPs: the workgroup is the chain's wave + helpers, see helper_loop): commands go out by bumping
   // `seq` after the arguments are in place, every helper adds 1 to `done` when it has finished the command it saw.
@@ -1966,17 +1966,21 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
       // tile's column 0 is the column left of the rect), "above" and "above-left" the cells one tile row up - and the row / column
       // of the next run is an addition.  One LDS read (none for a literal), one write, no multiplication: the general forms
       // below, which place every lane's pixel by a division by the rect's width, cost such a run ~650 cycles.
-      const bool slow_run = !(rem > 0 && rcol + rem <= w && pt != 4);
-      if (SCPR_LIKELY(!slow_run)) {
+      // negative: the single-row form (at least one pixel, the row holds them all, not the gradient; three sign bits, no select)
+      int slow_run = ~((rem - 1) | (w - rcol - rem) | ((pt ^ 4) - 1));
+      if (SCPR_LIKELY(slow_run < 0)) {
         const int base = (rrow + 1) * 17 + rcol + 1;
         u32 v = px;
         wave_fence();
         if (pt != 0) {
-          const int off = pt == 1 ? -1 : (pt == 2 ? -17 : -18) + lc;  // left: one cell for every lane; above (2) / above-left (5): lane by lane
-          const u32* sp = pt == 3 ? ptile + li + lc : tile + base + off;
-          v = *sp;
+          // where lane 0 reads (a cell of the tile, or - cells past the tile's end - of the previous frame's rect), and whether
+          // the lanes read side by side (above, above-left, previous frame) or all the same cell (left): scalar selects
+          const int s0 = pt == 3 ? (int)(ptile - tile) + li : base + (pt == 1 ? -1 : pt == 2 ? -17 : -18);
+          const int each = pt == 1 ? 0 : -1;
+          v = tile[s0 + (lc & each)];
         }
-        if (lane < rem) tile[base + lane] = v;
+        // (no lane mask: the lanes past the run write to a cell behind the tile)
+        tile[lane < rem ? base + lane : 17 * 17] = v;
         wave_fence();
         lastpix = rdl(v, rem - 1) & 0xFFFFFFu;
         li += rem;
@@ -1984,92 +1988,98 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
         if (rcol == w) rcol = 0, rrow++;
         rem = 0;
       }
-      // Literal (0), left (1), above (2) and previous frame (3): no pixel of the run depends on another pixel of the run that
-      // is not a plain copy of it, so the whole run is one pass - lane i takes the run's i-th pixel wherever the rect's rows
-      // wrap it to.  "Left" is the pixel left of the run's start on its first row and the column left of the rect on the rows
-      // below; "above" of a pixel further than a rect row into the run is another pixel of the run, and through it the pixel
-      // above run pixel i mod w.  (Above-left and the gradient go row by row in the loop below.)
-      if (SCPR_LIKELY(!((0x30 >> pt) & 1)) && rem > 0) {
-        const int li0 = li;
-        if (SCPR_UNLIKELY(li0 + rem > lend)) {  // the run goes on below the rect
-          D.bad = true;
-          li = lend;
-        } else {
-          const int row0 = (li0 * rcpw) >> 16, col0 = li0 - row0 * w;
-          u32 v = px;
-          for (int b = 0; b < rem; b += 64) {
-            const int i = min(b + lane, rem - 1);
-            const bool act = b + lane < rem;
-            const int li = li0 + i;
-            const int row = (li * rcpw) >> 16, col = li - row * w;
-            wave_fence();
-            if (pt == 1) {
-              v = tile[(row + 1) * 17 + (row == row0 ? col0 : 0)];
-            } else if (pt == 2) {
-              const int ls = li0 + (i - ((i * rcpw) >> 16) * w);
-              const int rs = (ls * rcpw) >> 16;
-              v = tile[rs * 17 + (ls - rs * w) + 1];
-            } else if (pt == 3) {
-              v = ptile[li];
-            }
-            if (act) tile[(row + 1) * 17 + col + 1] = v;
-          }
-          wave_fence();
-          lastpix = rdl(v, (rem - 1) & 63) & 0xFFFFFFu;
-          li = li0 + rem;
-        }
-        rem = 0;
-      }
-      while (rem > 0) {
-        if (SCPR_UNLIKELY(li >= lend)) {  // the run goes on below the rect
-          D.bad = true;
-          break;
-        }
-        const int rrow = (li * rcpw) >> 16, rcol = li - rrow * w;
-        const int seg = min(rem, w - rcol);  // pixels of this run on the current rect row (<= 16)
-        const int ty = rrow + 1, tx0 = rcol + 1;
-        const bool act = lane < seg;
-        const int tx = tx0 + lane;
-        wave_fence();
-        // literal (0): px.  Copies inside the tile - of the previous pixel (1: one word for every lane), of the pixel
-        // above (2) or above-left (5) - are one read at an index built from the type (every lane reads: the lanes past
-        // the segment stay inside the tile's rows through lc).  The copy from the previous frame (3) and the gradient
-        // (4) are rare and replace the result.
-        u32 v = px;
-        if (pt != 0) {
-          const int srow = pt == 1 ? ty : ty - 1, scol = tx0 - (pt == 2 ? 0 : 1);
-          v = tile[srow * 17 + scol + (pt == 1 ? 0 : lc)];
-        }
-        if (SCPR_UNLIKELY((0x18u >> pt) & 1u)) {
-          if (pt == 3) {
-            v = px;
-            if (act) v = ptile[li + lane];
+      D.template stamp<21>();
+      // (two plain ifs, the common one first: everything the general forms need - their tests included - stays off the path of
+      // the single-row runs)
+      if constexpr (DEC::kFastRuns && FAST) asm volatile("" : "+s"(slow_run));
+      else slow_run = (int)rfl((u32)slow_run);  // (the careful instance, and the version 2 decoder, whose symbols come off the vector unit)
+      if (SCPR_UNLIKELY(slow_run >= 0)) {
+        // Literal (0), left (1), above (2) and previous frame (3): no pixel of the run depends on another pixel of the run that
+        // is not a plain copy of it, so the whole run is one pass - lane i takes the run's i-th pixel wherever the rect's rows
+        // wrap it to.  "Left" is the pixel left of the run's start on its first row and the column left of the rect on the rows
+        // below; "above" of a pixel further than a rect row into the run is another pixel of the run, and through it the pixel
+        // above run pixel i mod w.  (Above-left and the gradient go row by row in the loop below.)
+        if (SCPR_LIKELY(!((0x30 >> pt) & 1)) && rem > 0) {
+          const int li0 = li;
+          if (SCPR_UNLIKELY(li0 + rem > lend)) {  // the run goes on below the rect
+            D.bad = true;
+            li = lend;
           } else {
-            u32 tp = 0, tl = 0;
-            if (act) {
-              tp = tile[(ty - 1) * 17 + tx];
-              tl = tile[(ty - 1) * 17 + tx - 1];
+            const int row0 = (li0 * rcpw) >> 16, col0 = li0 - row0 * w;
+            u32 v = px;
+            for (int b = 0; b < rem; b += 64) {
+              const int i = min(b + lane, rem - 1);
+              const bool act = b + lane < rem;
+              const int li = li0 + i;
+              const int row = (li * rcpw) >> 16, col = li - row * w;
+              wave_fence();
+              if (pt == 1) {
+                v = tile[(row + 1) * 17 + (row == row0 ? col0 : 0)];
+              } else if (pt == 2) {
+                const int ls = li0 + (i - ((i * rcpw) >> 16) * w);
+                const int rs = (ls * rcpw) >> 16;
+                v = tile[rs * 17 + (ls - rs * w) + 1];
+              } else if (pt == 3) {
+                v = ptile[li];
+              }
+              if (act) tile[(row + 1) * 17 + col + 1] = v;
             }
-            const u32 base = tile[ty * 17 + tx0 - 1];
-            int d0 = (int)(tp & 255) - (int)(tl & 255), d1 = (int)((tp >> 8) & 255) - (int)((tl >> 8) & 255), d2 = (int)((tp >> 16) & 255) - (int)((tl >> 16) & 255);
-            if (!act) d0 = d1 = d2 = 0;
-            d0 = row_incl_scan(d0);
-            d1 = row_incl_scan(d1);
-            d2 = row_incl_scan(d2);
-            v = (u32)(((int)(base & 255) + d0) & 255) | ((u32)(((int)((base >> 8) & 255) + d1) & 255) << 8) | ((u32)(((int)((base >> 16) & 255) + d2) & 255) << 16);
+            wave_fence();
+            lastpix = rdl(v, (rem - 1) & 63) & 0xFFFFFFu;
+            li = li0 + rem;
           }
+          rem = 0;
         }
-        if (act) tile[ty * 17 + tx] = v;
-        wave_fence();
-        lastpix = rdl(v, seg - 1) & 0xFFFFFFu;
-        rem -= seg;
-        li += seg;
-      }
-      if (SCPR_UNLIKELY(D.bad)) li = lend;
-      if (SCPR_UNLIKELY(slow_run)) {  // (the general forms move li only)
-        rrow = (li * rcpw) >> 16;
+        while (rem > 0) {
+          if (SCPR_UNLIKELY(li >= lend)) {  // the run goes on below the rect
+            D.bad = true;
+            break;
+          }
+          const int rrow = (li * rcpw) >> 16, rcol = li - rrow * w;
+          const int seg = min(rem, w - rcol);  // pixels of this run on the current rect row (<= 16)
+          const int ty = rrow + 1, tx0 = rcol + 1;
+          const bool act = lane < seg;
+          const int tx = tx0 + lane;
+          wave_fence();
+          // literal (0): px.  Copies inside the tile - of the previous pixel (1: one word for every lane), of the pixel
+          // above (2) or above-left (5) - are one read at an index built from the type (every lane reads: the lanes past
+          // the segment stay inside the tile's rows through lc).  The copy from the previous frame (3) and the gradient
+          // (4) are rare and replace the result.
+          u32 v = px;
+          if (pt != 0) {
+            const int srow = pt == 1 ? ty : ty - 1, scol = tx0 - (pt == 2 ? 0 : 1);
+            v = tile[srow * 17 + scol + (pt == 1 ? 0 : lc)];
+          }
+          if (SCPR_UNLIKELY((0x18u >> pt) & 1u)) {
+            if (pt == 3) {
+              v = px;
+              if (act) v = ptile[li + lane];
+            } else {
+              u32 tp = 0, tl = 0;
+              if (act) {
+                tp = tile[(ty - 1) * 17 + tx];
+                tl = tile[(ty - 1) * 17 + tx - 1];
+              }
+              const u32 base = tile[ty * 17 + tx0 - 1];
+              int d0 = (int)(tp & 255) - (int)(tl & 255), d1 = (int)((tp >> 8) & 255) - (int)((tl >> 8) & 255), d2 = (int)((tp >> 16) & 255) - (int)((tl >> 16) & 255);
+              if (!act) d0 = d1 = d2 = 0;
+              d0 = row_incl_scan(d0);
+              d1 = row_incl_scan(d1);
+              d2 = row_incl_scan(d2);
+              v = (u32)(((int)(base & 255) + d0) & 255) | ((u32)(((int)((base >> 8) & 255) + d1) & 255) << 8) | ((u32)(((int)((base >> 16) & 255) + d2) & 255) << 16);
+            }
+          }
+          if (act) tile[ty * 17 + tx] = v;
+          wave_fence();
+          lastpix = rdl(v, seg - 1) & 0xFFFFFFu;
+          rem -= seg;
+          li += seg;
+        }
+        if (SCPR_UNLIKELY(D.bad)) li = lend;
+        rrow = (li * rcpw) >> 16;  // (the general forms move li only)
         rcol = li - rrow * w;
       }
+      D.template stamp<22>();
     };
     while (li < lend) {
       D.tick();

@@ -57,4 +57,4 @@ for nm, x in zip(names, v):
 for nm, x in zip(["colour symbols", "record cache misses", "dense-table symbols", "raw symbols", "small-table slow path", "runs", "literal runs", "dense-table cache misses"], ev):
     print("%-50s %.0f per frame" % (nm, x / n))
 print("dense fast-path hits per frame: %.0f; small-table hits on the top entry: %.0f, in one-symbol tables: %.0f" % (ex[0] / n, ex[1] / n, ex[2] / n))
-print("P-frame, more sections (ticks/frame): rect write-back %.0f, motion blocks (symbols, hand-over) %.0f" % (ex[3] / n, ex[4] / n))
+print("P-frame, more sections (ticks/frame): rect write-back %.0f, motion blocks (symbols, hand-over) %.0f; after the run length to the end of the single-row fill %.0f, general fills %.0f ('runs' above is then the loop between runs)" % (ex[3] / n, ex[4] / n, ex[5] / n, ex[6] / n))
