@@ -28,7 +28,7 @@ struct V2Fixed {       // count tables of UseRC; rows are zero past the alphabet
 };
 struct __attribute__((aligned(16))) V2Lds {
   V2Fixed fx;
-  u32 tile[17 * 17];
+  u32 tile[17 * 17 + 1];  // (+ the spare cell of decode_inter_frame: WaveLds::tile)
   u32 ptile[256];
   uint2 jobs[256];
 };

@@ -113,7 +113,7 @@ struct __attribute__((aligned(16))) WaveLds {
   u32 dtag[64];        // tags of the dense-table cache (WaveModel::tab_of)
   FixedLdsP fp;
   u32 tile[17 * 17 + 1];  // P-frame block under reconstruction, with one row above and one column to the left (+ a cell that takes the stores of idle lanes)
-  u32 ptile[256];      // the same rect in the previous frame (row-major, w * h pixels): what "previous frame" runs copy (must follow `tile`: decode_inter_frame reads it as cells past the tile's end)
+  u32 ptile[256];      // the same rect in the previous frame (row-major, w * h pixels): what "previous frame" runs copy (decode_inter_frame reads it through the tile's pointer)
   uint2 jobs[256];     // motion-block copies on their way to the helper waves (a ring, see hc)
   // Helper waves (P-frame GOPs: the workgroup is the chain's wave + helpers, see helper_loop): commands go out by bumping
   // `seq` after the arguments are in place, every helper adds 1 to `done` when it has finished the command it saw.
@@ -1914,6 +1914,13 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
     D.template stamp<6>();
     int li = 0, pt = 0;  // position in the rect, row-major (the rect is w * h <= 256 pixels)
     int rrow = 0, rcol = 0;  // ... and as row / column (li == rrow * w + rcol)
+    // The cells of a run go to the tile when the NEXT run is placed (or the rect ends): their value is on its way from LDS
+    // until then, and nothing on the chain waits for it - a run that copies (71 % of a P-frame's runs) used to stall on that
+    // round trip twice, before its store and before handing its last pixel to the scalar unit, which only a literal that
+    // follows needs (for its contexts).  pend_at: per lane, the cell (the spare cell 17 * 17: none); pend_last: the lane
+    // whose value is the run's last pixel.
+    u32 pend_v = lastpix;
+    int pend_at = 17 * 17, pend_last = 0;
     const int lend = w * h;
     const int lc = min(lane, 15);
     const int rcpw = (int)kRcp16[w];  // ceil(65536 / w): (li * rcpw) >> 16 == li / w for li <= 256, w <= 16
@@ -1928,10 +1935,10 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
       D.template stamp<0>();
       D.template event<13>();
       if (pt == 0) D.template event<14>();
-      u32 px = lastpix;
+      u32 px = 0;
       if (pt == 0) {
+        lastpix = rdl(pend_v, pend_last) & 0xFFFFFFu;  // the last pixel of the run before (long arrived)
         u32 a = (lastpix >> 18) & 63, bb = (lastpix >> 10) & 63;
-        px = 0;
 #pragma unroll 1
         for (int plane = 0; plane < 3; plane++) {
           const u32 c = (u32)D.template colour<!FAST>(plane * 4096 + (int)(a | (bb << 6)));
@@ -1970,8 +1977,10 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
       int slow_run = ~((rem - 1) | (w - rcol - rem) | ((pt ^ 4) - 1));
       if (SCPR_LIKELY(slow_run < 0)) {
         const int base = (rrow + 1) * 17 + rcol + 1;
-        u32 v = px;
         wave_fence();
+        tile[pend_at] = pend_v;  // the run before (this run may copy from it)
+        wave_fence();
+        u32 v = px;
         if (pt != 0) {
           // where lane 0 reads (a cell of the tile, or - cells past the tile's end - of the previous frame's rect), and whether
           // the lanes read side by side (above, above-left, previous frame) or all the same cell (left): scalar selects
@@ -1979,10 +1988,10 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
           const int each = pt == 1 ? 0 : -1;
           v = tile[s0 + (lc & each)];
         }
-        // (no lane mask: the lanes past the run write to a cell behind the tile)
-        tile[lane < rem ? base + lane : 17 * 17] = v;
-        wave_fence();
-        lastpix = rdl(v, rem - 1) & 0xFFFFFFu;
+        // (no lane mask: the lanes past the run will write to the spare cell)
+        pend_v = v;
+        pend_at = lane < rem ? base + lane : 17 * 17;
+        pend_last = rem - 1;
         li += rem;
         rcol += rem;
         if (rcol == w) rcol = 0, rrow++;
@@ -1994,6 +2003,10 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
       if constexpr (DEC::kFastRuns && FAST) asm volatile("" : "+s"(slow_run));
       else slow_run = (int)rfl((u32)slow_run);  // (the careful instance, and the version 2 decoder, whose symbols come off the vector unit)
       if (SCPR_UNLIKELY(slow_run >= 0)) {
+        wave_fence();
+        tile[pend_at] = pend_v;  // (the general forms work on the tile as it is and hand the last pixel over at once)
+        wave_fence();
+        lastpix = rdl(pend_v, pend_last) & 0xFFFFFFu;
         // Literal (0), left (1), above (2) and previous frame (3): no pixel of the run depends on another pixel of the run that
         // is not a plain copy of it, so the whole run is one pass - lane i takes the run's i-th pixel wherever the rect's rows
         // wrap it to.  "Left" is the pixel left of the run's start on its first row and the column left of the rect on the rows
@@ -2078,6 +2091,9 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
         if (SCPR_UNLIKELY(D.bad)) li = lend;
         rrow = (li * rcpw) >> 16;  // (the general forms move li only)
         rcol = li - rrow * w;
+        pend_v = lastpix;
+        pend_at = 17 * 17;
+        pend_last = 0;
       }
       D.template stamp<22>();
     };
@@ -2087,6 +2103,9 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
       while (SCPR_LIKELY((int)((u32)(li - lend) & (u32)(D.ndec - (kBlockEntries - 5))) < 0)) prun(std::true_type{});
     }
     D.template stamp<7>();
+    wave_fence();
+    tile[pend_at] = pend_v;  // the last run's cells
+    lastpix = rdl(pend_v, pend_last) & 0xFFFFFFu;
     wave_fence();
     for (int i = lane; i < w * h; i += 64) {  // the finished rect goes to the plane
       const int yy = (i * rcpw) >> 16, xq = i - yy * w;
