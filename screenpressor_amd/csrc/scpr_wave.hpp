@@ -1217,14 +1217,25 @@ struct WaveDec : WaveModel {
   // --------------------------------------------------------------- colour ---
   // The record of a context in the LDS cache: header + tag (one broadcast read) and the small
   // table (one word per lane, lanes 16.. mirror lanes 0..15) come back from one wait.
-  __device__ __forceinline__ u32* record(int ctxid, ColHdr& h, u32& w, u32& ra, u32& ea, u32& h0, u32& hz) {
+  // PIPE: the coder step of the symbol before (pcf, pfr, pv: advance + count) runs between asking for the record and using
+  // it - the step needs nothing of the record and the record nothing of the step, and the LDS round trip (68+ cycles in which a
+  // lone wave issues nothing) is as long as the step (colour<CHK, MODE>).
+  template <bool CHK, bool PIPE>
+  __device__ __forceinline__ u32* record(int ctxid, ColHdr& h, u32& w, u32& ra, u32& ea, u32& h0, u32& hz, u32 pcf = 0, u32 pfr = 0, u32 pv = 0) {
     wave_fence();
     const int slot = (ctxid ^ (ctxid >> 7)) & (CACHE_N - 1);
     u32* r = L.crec[slot];
     ra = (u32)(size_t)r;
     ea = ra + 16u + 4u * (u32)l15;
     u32x4 hw;
-    asm volatile("ds_read_b128 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=v"(hw), "=v"(w) : "v"(ra), "v"(ea) : "memory");
+    if constexpr (PIPE) {
+      asm volatile("ds_read_b128 %0, %2\n\tds_read_b32 %1, %3" : "=v"(hw), "=v"(w) : "v"(ra), "v"(ea) : "memory");
+      advance(pcf, pfr, pv);
+      count<CHK>();
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(hw), "+v"(w) : : "memory");  // (ties what was read to the wait: nothing that uses it moves above)
+    } else {
+      asm volatile("ds_read_b128 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=v"(hw), "=v"(w) : "v"(ra), "v"(ea) : "memory");
+    }
     const u32 tag = rfl(hw.w);  // the context the slot holds (kNoCtx: none)
     if (SCPR_UNLIKELY(tag != (u32)ctxid)) {
       event<9>();
@@ -1298,12 +1309,15 @@ struct WaveDec : WaveModel {
     }
     return tst;
   }
-  // decodeC (screencap.h:318-333)
-  template <bool CHK = true>
-  __device__ __forceinline__ int colour(int ctxid) {
+  // decodeC (screencap.h:318-333).  MODE 0: the whole symbol.  MODE 1 / 2 (the three colour symbols of a key frame's literal):
+  // the symbol's coder step is NOT taken here but handed to the caller in (pcf, pfr, pv), who passes it to the next symbol -
+  // MODE 2 takes the step it is handed while its own record is on its way from LDS (record<CHK, true>) - and takes the last
+  // one itself (advance + count).
+  template <bool CHK = true, int MODE = 0>
+  __device__ __forceinline__ int colour(int ctxid, u32* pend = nullptr) {
     ColHdr h;
     u32 w, ra, ea, h0, hz;
-    u32* r = record(ctxid, h, w, ra, ea, h0, hz);
+    u32* r = MODE == 2 ? record<CHK, true>(ctxid, h, w, ra, ea, h0, hz, pend[0], pend[1], pend[2]) : record<CHK, false>(ctxid, h, w, ra, ea, h0, hz);
     event<8>();
     const int maxpos0 = h.maxpos;
     // Plain ifs, the common case first (an else costs it a taken branch): a raw symbol leaves the coder alone,
@@ -1372,7 +1386,8 @@ struct WaveDec : WaveModel {
         }
       }
     }
-    advance(cf, fr, v);
+    if constexpr (MODE == 0) advance(cf, fr, v);
+    else pend[0] = cf, pend[1] = fr, pend[2] = v;
     wave_fence();
     {  // the header: the word that changes with every symbol from all lanes alike (same address, same value), the other one when it changes
       const u32 h1 = (u32)h.total | ((u32)h.fmax << 16);
@@ -1383,7 +1398,7 @@ struct WaveDec : WaveModel {
       }
     }
     wave_fence();
-    count<CHK>();
+    if constexpr (MODE == 0) count<CHK>();
     return c;
   }
 };
@@ -1472,14 +1487,28 @@ __device__ __forceinline__ void decode_intra_frame(DEC& D, const Geom& g, u8* __
     if (t == 0) {  // DecodeRGB, screencap.cpp:662-679: contexts are the two previous bytes >> 2 (MAKECX1, screencap.h:35-36)
       u32 a = (lastpix >> 18) & 63, b = (lastpix >> 10) & 63;
       px = 0;
-#pragma unroll
-      for (int plane = 0; plane < 3; plane++) {
-        u32 c;
-        if constexpr (FAST) c = (u32)D.template colour<false>(plane * 4096 + (int)(a | (b << 6)));
-        else c = (u32)D.colour(plane * 4096 + (int)(a | (b << 6)));
-        px |= c << (8 * plane);
+      if constexpr (DEC::kFastRuns) {  // (the wave decoder of versions 3 / 4: the coder step of a symbol under the next one's record fetch)
+        u32 pend[3];
+        u32 c = (u32)D.template colour<!FAST, 1>((int)(a | (b << 6)), pend);
+        px = c;
         b = a;
         a = c >> 2;
+        c = (u32)D.template colour<!FAST, 2>(4096 + (int)(a | (b << 6)), pend);
+        px |= c << 8;
+        b = a;
+        a = c >> 2;
+        c = (u32)D.template colour<!FAST, 2>(8192 + (int)(a | (b << 6)), pend);
+        px |= c << 16;
+        D.advance(pend[0], pend[1], pend[2]);
+        D.template count<!FAST>();
+      } else {
+#pragma unroll
+        for (int plane = 0; plane < 3; plane++) {
+          const u32 c = (u32)D.colour(plane * 4096 + (int)(a | (b << 6)));
+          px |= c << (8 * plane);
+          b = a;
+          a = c >> 2;
+        }
       }
       D.template stamp<1>();
     }
