@@ -210,17 +210,19 @@ struct WaveDecV2 {
     return sym;
   }
 
-  template <bool CHK = true>  // (the parameter only exists to match WaveDec, see decode_intra_frame)
-  __device__ __forceinline__ int fixed_n(int t) { return dec_lds<4>(L.fx.n[t], 256, 400); }   // SC_NSTEP
-  template <bool CHK = true>  // (the parameter only exists to match WaveDec, see decode_intra_frame)
-  __device__ __forceinline__ int fixed_p(int t) { return dec_lds<1>(L.fx.p[t], 6, 1000); }    // SC_UNSTEP
+  // (the template parameters and the second argument only exist to match WaveDec - its symbols hand their coder step on to
+  // the next one, decode_intra_frame - and are never used with this coder)
+  template <bool CHK = true, bool PIPE = false>
+  __device__ __forceinline__ int fixed_n(int t, const u32* = nullptr) { return dec_lds<4>(L.fx.n[t], 256, 400); }   // SC_NSTEP
+  template <bool CHK = true, bool DEFER = false>
+  __device__ __forceinline__ int fixed_p(int t, u32* = nullptr) { return dec_lds<1>(L.fx.p[t], 6, 1000); }    // SC_UNSTEP
   __device__ __forceinline__ int fixed_x(int k) { return k == 0 ? dec_lds<4>(L.fx.x, 256, 1) : dec_lds<4>(L.fx.bn, 256, 20); }  // SC_XXSTEP / SC_BTNSTEP
   __device__ __forceinline__ int fixed_bt() { return dec_lds<1>(L.fx.bt, 5, 10); }            // SC_BTSTEP
   __device__ __forceinline__ int fixed_sxy(int k) { return dec_lds<1>(L.fx.sxy[k], 16, 100); }  // SC_SXYSTEP
   __device__ __forceinline__ int fixed_mv(int k) { return dec_lds<8>(L.fx.m[k], k ? my2 : mx2, 100); }  // SC_MSTEP
   __device__ __forceinline__ bool get_bool() { return false; }                                // canEncodeBool = false
-  template <bool CHK = true>  // (the parameter only exists to match WaveDec, see decode_intra_frame)
-  __device__ __forceinline__ int colour(int ctxid) { return dec_global(gtabs + (size_t)ctxid * V2_COLTAB, 400); }  // SC_STEP
+  template <bool CHK = true, int MODE = 0>
+  __device__ __forceinline__ int colour(int ctxid, u32* = nullptr) { return dec_global(gtabs + (size_t)ctxid * V2_COLTAB, 400); }  // SC_STEP
 
   // RenewI with the renew* of UseRC (screencap.h:146-260): every count 1
   __device__ __forceinline__ void fixed_init() {

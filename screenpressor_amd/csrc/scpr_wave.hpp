@@ -1003,14 +1003,23 @@ struct WaveDec : WaveModel {
   // Symbol j of a table is LDS word j: the first 64 symbols (almost every run) are one per lane and
   // are found with one compare and a population count; word 64 tells whether that is enough, word
   // 256 is the running total.  The three words come back from one wait.
-  template <bool CHK = true>
-  __device__ __forceinline__ int fixed_n(int t) {
+  // PIPE: the coder step of the symbol before (pend: advance + count) is taken while the table's words are on their way
+  // from LDS (see record<CHK, PIPE>).
+  template <bool CHK = true, bool PIPE = false>
+  __device__ __forceinline__ int fixed_n(int t, const u32* pend = nullptr) {
     wave_fence();
-    const u32 v = x & (kProbScale - 1), lim = (v + 1) << 16;  // cum <= v  <=>  (freq | cum << 16) < lim
     u32* tab = L.fx.ntab[t];
     const u32 addr = (u32)(size_t)tab + 4u * (u32)lane;  // LDS offset = low 32 bits of the flat address
     u32 e0, e1, et;
-    asm volatile("ds_read_b32 %0, %3\n\tds_read_b32 %1, %3 offset:256\n\tds_read_b32 %2, %3 offset:1024\n\ts_waitcnt lgkmcnt(0)" : "=v"(e0), "=v"(e1), "=v"(et) : "v"(addr) : "memory");
+    if constexpr (PIPE) {
+      asm volatile("ds_read_b32 %0, %3\n\tds_read_b32 %1, %3 offset:256\n\tds_read_b32 %2, %3 offset:1024" : "=v"(e0), "=v"(e1), "=v"(et) : "v"(addr) : "memory");
+      advance(pend[0], pend[1], pend[2]);
+      count<CHK>();
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(e0), "+v"(e1), "+v"(et) : : "memory");
+    } else {
+      asm volatile("ds_read_b32 %0, %3\n\tds_read_b32 %1, %3 offset:256\n\tds_read_b32 %2, %3 offset:1024\n\ts_waitcnt lgkmcnt(0)" : "=v"(e0), "=v"(e1), "=v"(et) : "v"(addr) : "memory");
+    }
+    const u32 v = x & (kProbScale - 1), lim = (v + 1) << 16;  // cum <= v  <=>  (freq | cum << 16) < lim
     const int tot0 = (int)rfl(et);
     // (plain ifs only: an else on this path costs the common case a taken branch)
     int sym = __builtin_popcountll(__ballot(e0 < lim)) - 1;
@@ -1055,8 +1064,9 @@ struct WaveDec : WaveModel {
     return sym;
   }
   // Pixel type after a pixel of type t: all six tables are searched by the same compare
-  template <bool CHK = true>
-  __device__ __forceinline__ int fixed_p(int t) {
+  // DEFER: the coder step (advance + count) is left to the next symbol, which takes it while its own table is on its way
+  template <bool CHK = true, bool DEFER = false>
+  __device__ __forceinline__ int fixed_p(int t, u32* pend = nullptr) {
     const u32 v = x & (kProbScale - 1), lim = (v + 1) << 16;
     const u64 m = __ballot(pfc < lim);
     const u32 mt = (u32)(m >> (8 * t)) & 0xFFu;  // never 0: the first cum is 0
@@ -1065,7 +1075,8 @@ struct WaveDec : WaveModel {
     const u32 s = rdl(pfc, own);
     const int tot = (int)rdl(pcnt, tl) + kStepDense;
     pcnt += (lane == own || lane == tl) ? (u32)kStepDense : 0u;
-    advance(s >> 16, s & 0xFFFF, v);
+    if constexpr (DEFER) pend[0] = s >> 16, pend[1] = s & 0xFFFF, pend[2] = v;
+    else advance(s >> 16, s & 0xFFFF, v);
     if (SCPR_UNLIKELY(tot + kStepDense > kProbScale)) {
       const bool in = (lane >> 3) == t && (lane & 7) < 6;
       const int c = in ? (int)pcnt : 0;
@@ -1078,7 +1089,7 @@ struct WaveDec : WaveModel {
       }
       if (lane == tl) pcnt = (u32)nt;
     }
-    count<CHK>();
+    if constexpr (!DEFER) count<CHK>();
     return j;
   }
 
@@ -1478,7 +1489,10 @@ __device__ __forceinline__ void decode_intra_frame(DEC& D, const Geom& g, u8* __
   auto run = [&](auto fast_tag) __attribute__((always_inline)) {
     constexpr bool FAST = decltype(fast_tag)::value;
     D.template stamp<4>();
-    if constexpr (FAST) t = D.template fixed_p<false>(t);
+    u32 pend[3];  // the fast instance (wave decoder): every symbol's coder step is taken by the next symbol, under its table fetch
+    constexpr bool CHAIN = FAST && DEC::kFastRuns;
+    if constexpr (CHAIN) t = D.template fixed_p<false, true>(t, pend);
+    else if constexpr (FAST) t = D.template fixed_p<false>(t);
     else if (lim == NP) t = D.fixed_p(t);
     D.template stamp<0>();
     D.template event<13>();
@@ -1488,8 +1502,7 @@ __device__ __forceinline__ void decode_intra_frame(DEC& D, const Geom& g, u8* __
       u32 a = (lastpix >> 18) & 63, b = (lastpix >> 10) & 63;
       px = 0;
       if constexpr (DEC::kFastRuns) {  // (the wave decoder of versions 3 / 4: the coder step of a symbol under the next one's record fetch)
-        u32 pend[3];
-        u32 c = (u32)D.template colour<!FAST, 1>((int)(a | (b << 6)), pend);
+        u32 c = (u32)D.template colour<!FAST, CHAIN ? 2 : 1>((int)(a | (b << 6)), pend);
         px = c;
         b = a;
         a = c >> 2;
@@ -1499,8 +1512,10 @@ __device__ __forceinline__ void decode_intra_frame(DEC& D, const Geom& g, u8* __
         a = c >> 2;
         c = (u32)D.template colour<!FAST, 2>(8192 + (int)(a | (b << 6)), pend);
         px |= c << 16;
-        D.advance(pend[0], pend[1], pend[2]);
-        D.template count<!FAST>();
+        if constexpr (!CHAIN) {  // (the fast instance hands the last step on to the run length)
+          D.advance(pend[0], pend[1], pend[2]);
+          D.template count<!FAST>();
+        }
       } else {
 #pragma unroll
         for (int plane = 0; plane < 3; plane++) {
@@ -1513,9 +1528,12 @@ __device__ __forceinline__ void decode_intra_frame(DEC& D, const Geom& g, u8* __
       D.template stamp<1>();
     }
     int n;
-    if constexpr (FAST) {
-      n = D.template fixed_n<false>(t);
+    if constexpr (CHAIN) {
+      n = D.template fixed_n<false, true>(t, pend);
       D.ndec += t == 0 ? 5 : 2;  // the symbols of this run (type, three colour bytes of a literal, length)
+    } else if constexpr (FAST) {
+      n = D.template fixed_n<false>(t);
+      D.ndec += t == 0 ? 5 : 2;
     } else {
       n = D.fixed_n(t);
       // (the careful instance runs once per row: the place to notice that the arena is full - alloc_dense -, at most a row late:
