@@ -1978,7 +1978,10 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
       constexpr bool FAST = decltype(fast_tag)::value;
       const int last_t = pt;
       D.template stamp<7>();
-      pt = D.template fixed_p<!FAST>(last_t);
+      u32 pend[3];  // the fast instance (wave decoder): every symbol's coder step is taken by the next symbol, under its table fetch
+      constexpr bool CHAIN = FAST && DEC::kFastRuns;
+      if constexpr (CHAIN) pt = D.template fixed_p<false, true>(last_t, pend);
+      else pt = D.template fixed_p<!FAST>(last_t);
       D.template stamp<0>();
       D.template event<13>();
       if (pt == 0) D.template event<14>();
@@ -1988,14 +1991,18 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
         u32 a = (lastpix >> 18) & 63, bb = (lastpix >> 10) & 63;
 #pragma unroll 1
         for (int plane = 0; plane < 3; plane++) {
-          const u32 c = (u32)D.template colour<!FAST>(plane * 4096 + (int)(a | (bb << 6)));
+          u32 c;
+          if constexpr (CHAIN) c = (u32)D.template colour<false, 2>(plane * 4096 + (int)(a | (bb << 6)), pend);
+          else c = (u32)D.template colour<!FAST>(plane * 4096 + (int)(a | (bb << 6)));
           px |= c << (8 * plane);
           bb = a;
           a = c >> 2;
         }
       }
       D.template stamp<1>();
-      int rem = D.template fixed_n<!FAST>(pt);
+      int rem;
+      if constexpr (CHAIN) rem = D.template fixed_n<false, true>(pt, pend);
+      else rem = D.template fixed_n<!FAST>(pt);
       D.template stamp<2>();
       if constexpr (!FAST) {  // (a rect always starts in this instance)
         if (SCPR_UNLIKELY(D.oom)) D.bad = true;  // the arena is full (alloc_dense): nothing more is decoded, at most a rect late
