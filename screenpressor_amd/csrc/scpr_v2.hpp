@@ -104,6 +104,7 @@ struct WaveDecV2 {
     range = range / tot;
     return code / range;
   }
+  __device__ __forceinline__ void advance(u32, u32, u32) {}  // (WaveDec's form: named by decode_intra_frame in a branch this coder never takes)
   __device__ __forceinline__ void advance(u32 cum, u32 freq) {
     code -= cum * range;
     range *= freq;
@@ -212,8 +213,8 @@ struct WaveDecV2 {
 
   // (the template parameters and the second argument only exist to match WaveDec - its symbols hand their coder step on to
   // the next one, decode_intra_frame - and are never used with this coder)
-  template <bool CHK = true, bool PIPE = false>
-  __device__ __forceinline__ int fixed_n(int t, const u32* = nullptr) { return dec_lds<4>(L.fx.n[t], 256, 400); }   // SC_NSTEP
+  template <bool CHK = true, bool PIPE = false, bool DOUT = false>
+  __device__ __forceinline__ int fixed_n(int t, u32* = nullptr) { return dec_lds<4>(L.fx.n[t], 256, 400); }   // SC_NSTEP
   template <bool CHK = true, bool DEFER = false>
   __device__ __forceinline__ int fixed_p(int t, u32* = nullptr) { return dec_lds<1>(L.fx.p[t], 6, 1000); }    // SC_UNSTEP
   __device__ __forceinline__ int fixed_x(int k) { return k == 0 ? dec_lds<4>(L.fx.x, 256, 1) : dec_lds<4>(L.fx.bn, 256, 20); }  // SC_XXSTEP / SC_BTNSTEP

@@ -1005,8 +1005,9 @@ struct WaveDec : WaveModel {
   // 256 is the running total.  The three words come back from one wait.
   // PIPE: the coder step of the symbol before (pend: advance + count) is taken while the table's words are on their way
   // from LDS (see record<CHK, PIPE>).
-  template <bool CHK = true, bool PIPE = false>
-  __device__ __forceinline__ int fixed_n(int t, const u32* pend = nullptr) {
+  // DOUT: its own coder step is left in `pend` for the caller (the key-frame loop takes it under the run's ring read).
+  template <bool CHK = true, bool PIPE = false, bool DOUT = false>
+  __device__ __forceinline__ int fixed_n(int t, u32* pend = nullptr) {
     wave_fence();
     u32* tab = L.fx.ntab[t];
     const u32 addr = (u32)(size_t)tab + 4u * (u32)lane;  // LDS offset = low 32 bits of the flat address
@@ -1041,7 +1042,8 @@ struct WaveDec : WaveModel {
       const u32 dc = lane == sym ? (u32)kStepDense : 0u, dt = lane == 0 ? (u32)kStepDense : 0u;
       asm volatile("ds_add_u32 %0, %1 offset:%3\n\tds_add_u32 %0, %2 offset:1024" ::"v"(addr), "v"(dc), "v"(dt), "n"(4 * NTAB_CNT) : "memory");
     }
-    advance(s >> 16, s & 0xFFFF, v);
+    if constexpr (DOUT) pend[0] = s >> 16, pend[1] = s & 0xFFFF, pend[2] = v;
+    else advance(s >> 16, s & 0xFFFF, v);
     if (SCPR_UNLIKELY(tot0 + 2 * kStepDense > kProbScale)) {  // rebuild from the counts, ans_contexts.h:1075-1090
       wave_fence();
       u32* cnt = tab + NTAB_CNT;
@@ -1060,7 +1062,7 @@ struct WaveDec : WaveModel {
       if (lane == 0) tab[256] = (u32)ns;
       wave_fence();
     }
-    count<CHK>();
+    if constexpr (!DOUT) count<CHK>();
     return sym;
   }
   // Pixel type after a pixel of type t: all six tables are searched by the same compare
@@ -1529,7 +1531,7 @@ __device__ __forceinline__ void decode_intra_frame(DEC& D, const Geom& g, u8* __
     }
     int n;
     if constexpr (CHAIN) {
-      n = D.template fixed_n<false, true>(t, pend);
+      n = D.template fixed_n<false, true, true>(t, pend);  // (its own step: under the run's ring read, below)
       D.ndec += t == 0 ? 5 : 2;  // the symbols of this run (type, three colour bytes of a literal, length)
     } else if constexpr (FAST) {
       n = D.template fixed_n<false>(t);
@@ -1556,6 +1558,7 @@ __device__ __forceinline__ void decode_intra_frame(DEC& D, const Geom& g, u8* __
     u32 pq = (u32)(p + lane);
     wave_fence();  // pixels written by other lanes are read here
     if (t >= 2) v = ring[(pq - back) & pm];
+    if constexpr (CHAIN) D.advance(pend[0], pend[1], pend[2]);  // the run length's coder step, while the row above is on its way
     ring[pq & pm] = v;
     wave_fence();
     lastpix = rdl(v, m - 1);
