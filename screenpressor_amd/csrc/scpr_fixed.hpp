@@ -139,11 +139,17 @@ __global__ __launch_bounds__(256) void k_part_scan(const u32* __restrict__ blkcn
 }
 
 // Stable: a model's list holds its items in list (= stream) order.  fl_sym / fl_pos: the models' lists back to back.
+// A block's items are first laid out in LDS, model after model (a model's share of the block is one contiguous piece of its
+// list), and then written out side by side: a thread's own items go to a dozen places two and four bytes at a time, which left
+// the L2 as one 32-byte write per store (PMC: 6.0 GB for 1.4 GB of lists on the headline).
 template <class SRC>
 __global__ __launch_bounds__(256) void k_part_scatter(const u32* __restrict__ el, const u32* __restrict__ elpos, u32 n, const u32* __restrict__ blkoff, u32 nblk,
                                                       const u32* __restrict__ ctotal, u16* __restrict__ fl_sym, u32* __restrict__ fl_pos) {
   constexpr int NC = SRC::NCLS, NW = (NC + 2) / 3;
-  __shared__ u32 wtot[4][NW], wb[4][NC];
+  constexpr int CAP = 2 * PART_B;  // items of a block at most (two per element)
+  __shared__ u32 wtot[4][NW], wb[4][NC], lstart[NC + 1], gbase[NC];
+  __shared__ u32 spos[CAP];
+  __shared__ u16 ssym[CAP];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const u32 i0 = blockIdx.x * PART_B + threadIdx.x * 8;
   u32 v[8], ps[8];
@@ -178,17 +184,25 @@ __global__ __launch_bounds__(256) void k_part_scatter(const u32* __restrict__ el
     if (lane == 63) wtot[wv][q] = inc;
   }
   __syncthreads();
-  if (threadIdx.x < NC) {  // where each wave's items of model c begin: the model's place in the lists + the blocks before + the waves before
-    const int c = threadIdx.x;
-    u32 at = blkoff[(size_t)c * (nblk + 1) + blockIdx.x];
-    for (int k = 0; k < c; k++) at += ctotal[k];
-    for (int q = 0; q < 4; q++) {
-      wb[q][c] = at;
-      u32 t[NW];
+  if (threadIdx.x == 0) {  // where each model's share of the block begins in LDS, and each wave's share of that
+    u32 at = 0;
+    for (int c = 0; c < NC; c++) {
+      lstart[c] = at;
+      for (int q = 0; q < 4; q++) {
+        wb[q][c] = at;
+        u32 t[NW];
 #pragma unroll
-      for (int z = 0; z < NW; z++) t[z] = wtot[q][z];
-      at += fld_get<NW>(t, c);
+        for (int z = 0; z < NW; z++) t[z] = wtot[q][z];
+        at += fld_get<NW>(t, c);
+      }
     }
+    lstart[NC] = at;
+  }
+  if (threadIdx.x < NC) {  // ... and in the lists: the model's place + the blocks before
+    const int c = threadIdx.x;
+    u32 g = blkoff[(size_t)c * (nblk + 1) + blockIdx.x];
+    for (int k = 0; k < c; k++) g += ctotal[k];
+    gbase[c] = g;
   }
   __syncthreads();
 #pragma unroll
@@ -199,17 +213,27 @@ __global__ __launch_bounds__(256) void k_part_scatter(const u32* __restrict__ el
       SRC::get(v[q], ps[q], c0, s0, p0, c1, s1, p1);
       if (c0 >= 0) {
         const u32 d = wb[wv][c0] + fld_get<NW>(pre, c0);
-        fl_sym[d] = (u16)s0;
-        fl_pos[d] = p0;
+        ssym[d] = (u16)s0;
+        spos[d] = p0;
         fld_add<NW>(pre, c0);
       }
       if (c1 >= 0) {
         const u32 d = wb[wv][c1] + fld_get<NW>(pre, c1);
-        fl_sym[d] = (u16)s1;
-        fl_pos[d] = p1;
+        ssym[d] = (u16)s1;
+        spos[d] = p1;
         fld_add<NW>(pre, c1);
       }
     }
+  __syncthreads();
+  const u32 total = lstart[NC];
+  for (u32 i = threadIdx.x; i < total; i += 256) {  // neighbouring threads, neighbouring items of (mostly) the same list
+    int c = 0;
+#pragma unroll
+    for (int k = 1; k < NC; k++) c += i >= lstart[k] ? 1 : 0;
+    const u32 d = gbase[c] + (i - lstart[c]);
+    fl_sym[d] = ssym[i];
+    fl_pos[d] = spos[i];
+  }
 }
 
 // gstart[(c * ngens + g) * 2 + {0, 1}]: first and one-past-last index of generation g's items in model c's part of the lists.
