@@ -1249,7 +1249,13 @@ struct WaveDec : WaveModel {
     } else {
       asm volatile("ds_read_b128 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=v"(hw), "=v"(w) : "v"(ra), "v"(ea) : "memory");
     }
+    // all four words go to the scalar unit BEFORE the tag is tested (the empty asm wants them): a lane read takes ~30 cycles to
+    // reach a scalar consumer, and behind the test the header's reads would start that wait a second time
     const u32 tag = rfl(hw.w);  // the context the slot holds (kNoCtx: none)
+    h0 = rfl(hw.x);
+    u32 h1 = rfl(hw.y);
+    u32 h2 = rfl(hw.z);
+    asm volatile("" : "+s"(h0), "+s"(h1), "+s"(h2));
     if (SCPR_UNLIKELY(tag != (u32)ctxid)) {
       event<9>();
       if (lane < DECREC_WORDS) {
@@ -1258,9 +1264,10 @@ struct WaveDec : WaveModel {
       }
       wave_fence();
       asm volatile("ds_read_b128 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=v"(hw), "=v"(w) : "v"(ra), "v"(ea) : "memory");
+      h0 = rfl(hw.x);
+      h1 = rfl(hw.y);
+      h2 = rfl(hw.z);
     }
-    h0 = rfl(hw.x);
-    const u32 h1 = rfl(hw.y);
     h.kind = h0 & 255;
     h.maxpos = (h0 >> 8) & 255;
     h.fshift = 0;  // a small table has none; colour() fills in this and the dense index for the other kinds
@@ -1269,7 +1276,7 @@ struct WaveDec : WaveModel {
     h.fmax = h1 >> 16;
     h.dirty = 0;
     h.dense = 0;
-    hz = hw.z;
+    hz = h2;  // (wave-uniform already)
     return r;
   }
   static __device__ __forceinline__ u32 dec_pack0(const ColHdr& h) {
@@ -1340,7 +1347,7 @@ struct WaveDec : WaveModel {
     const u32 v = x & (kProbScale - 1);
     int small0 = (int)h0;  // sign bit: a small table (kind 4 or 5)
     if (SCPR_LIKELY(small0 < 0)) {
-      h.top = rfl(hz);
+      h.top = hz;
       int tt = top_hit<true, true>(h, w, (int)v, c, fr, cf);  // (a hit changes the header only: nothing of the table is stored)
       asm volatile("" : "+s"(tt));  // (keeps the test inside top_hit and this one apart)
       if (SCPR_UNLIKELY(tt >= 0)) {  // another entry, an unmet symbol, or a rescale is due
@@ -1367,7 +1374,7 @@ struct WaveDec : WaveModel {
     asm volatile("" : "+s"(small0));  // keeps the two tests apart (merged, they come back as if/else)
     if (SCPR_UNLIKELY(small0 >= 0)) {
       h.fshift = (int)((h0 >> 16) & 15u);
-      h.dense = rfl(hz);
+      h.dense = hz;
 #ifdef SCPR_PROFILE
       if (h.kind >= 6 && h.dense >= arena.cap && !prof[18]) {  // design aid: the first record that names a table outside the arena
         prof[18] = 0x100000000ull | (u32)ctxid;
