@@ -780,7 +780,7 @@ __device__ __forceinline__ void rans_emit(u8* const base, u32& off, const uint2 
   __builtin_memcpy(base + (size_t)off - 2, &o16, 2);                    // just below the write position
   off -= n - rawmask;                                                   // n bytes, or one raw byte
 }
-constexpr int RANS_TRIP = 16;
+constexpr int RANS_TRIP = 32;  // entries per hand-over between the four waves (a barrier each: 16 -> 32 took the stage from 8.65 to 7.5 ms; 40 is slower again, the unrolled trip outgrows its registers)
 __global__ __launch_bounds__(256) void k_rans(const u32* __restrict__ entries, const RansBlock* __restrict__ blocks, int nblocks, const RansRcp* __restrict__ rcp_g,
                                               u8* __restrict__ scratch, u32* __restrict__ blksize) {
   __shared__ RansRcp lrcp[kProbScale + 1];          // reciprocals in LDS: the lookup is off the HBM path
