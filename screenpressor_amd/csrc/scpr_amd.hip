@@ -102,6 +102,8 @@ struct scpr_codec {
   int slots = 0;   // frames per encode chunk (bounded by the per-frame scratch the encoder needs)
   int dslots = 0;  // frames per decode chunk (the decoder needs planes only: a long stream keeps all its GOPs in flight)
   size_t plane_slots = 0;  // planes allocated for frames; the previous frame of the stream lives in slot `pslot` == plane_slots
+  u32 planes_stride = 0;   // geometry the planes were last cleared for (plane stride, row stride)
+  int planes_S = 0;
   int pslot = 0;
   // per-slot worst-case buffers
   DevBuf planes, exitmap, entry, runrec, tilecnt, tileoff, hdrrec, hdrcnt, frametot, tnmap;
@@ -263,7 +265,13 @@ static int ensure_codec(scpr_codec* c, int version) {  // CreateCodec + CScreenC
   if (c->planes.p && c->planes.cap >= 2 * (size_t)g.plane_stride) {  // the planes of an earlier Init are kept (Deinit / Init per stream is cheap)
     c->plane_slots = std::min<size_t>(c->planes.cap / g.plane_stride - 1, (size_t)std::max(c->slots, c->dslots));
     c->pslot = (int)c->plane_slots;
-    HIPCHK(hipMemsetAsync(c->planes.p, 0, (c->plane_slots + 1) * (size_t)g.plane_stride, c->stream));
+    // Only the previous-frame slot is cleared: a stream starts with a key frame, which reads no previous frame, and every frame
+    // written to a slot (pack kernels, decoder) writes its rows whole, padding included - clearing all planes was 1.9 GB per Init
+    // for a codec that had held 300 frames of 1080p.  A new geometry clears them all: the slack between rows and planes sits
+    // elsewhere.
+    const bool same_geom = c->planes_stride == g.plane_stride && c->planes_S == g.S;
+    HIPCHK(hipMemsetAsync(c->planes.as<u8>() + (same_geom ? c->plane_slots * (size_t)g.plane_stride : 0), 0,
+                          (same_geom ? 1 : c->plane_slots + 1) * (size_t)g.plane_stride, c->stream));
   } else {
     c->planes.release();
     c->plane_slots = 0;
@@ -305,6 +313,8 @@ static int ensure_codec(scpr_codec* c, int version) {  // CreateCodec + CScreenC
   HIPCHK(hipMemcpyAsync(c->rcp.p, tab.data(), tab.size() * sizeof(RansRcp), hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   setup_loss(c, (int)p.loss);
+  c->planes_stride = g.plane_stride;
+  c->planes_S = g.S;
   c->have_codec = true;
   return SCPR_OK;
 }
@@ -599,7 +609,9 @@ static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int n
   HIPCHK(hipMemcpyAsync(c->ranges.p, rg.data(), ngens * sizeof(GenRange), hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(c->miscranges.p, mr.data(), ngens * sizeof(MiscRange), hipMemcpyHostToDevice, st));
   // The fixed-model chains (run lengths, pixel types, P-frame symbols) and the colour chains read the same lists
-  // and write disjoint coder entries: they run side by side on two streams and join before the coder.
+  // and write disjoint coder entries: they run side by side on two streams and join before the coder.  (Forking before the sort -
+  // the fixed models need the run list only - was tried again with round 3's partition kernels: the sort beside them still takes
+  // twice as long, 3.7 -> 7.2 ms at 4K, and the encode gains nothing.)
   const int buf_in = c->live_buf, buf_out = ngens > 1 ? 1 - c->live_buf : c->live_buf;
   {
     hipStream_t s2 = getenv("SCPR_SERIAL_CHAINS") ? st : c->stream2;  // (design aid: the two chain stages one after the other, to time each alone)
