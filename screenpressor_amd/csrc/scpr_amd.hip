@@ -398,7 +398,7 @@ static int fixed_chains(scpr_codec* c, hipStream_t s2, FixBufs& fb, const u32* e
   HIPCHK(fb.pos.reserve((2 * n + 16) * 4));
   HIPCHK(fb.gen.reserve((size_t)NC * ngens * 2 * 4));
   if (nblk) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_part_count<SRC>), dim3(nblk), dim3(256), 0, s2, el, (u32)n, fb.cnt.as<u32>(), nblk);
-  hipLaunchKernelGGL(k_part_scan, dim3(NC), dim3(256), 0, s2, fb.cnt.as<u32>(), fb.off.as<u32>(), nblk, fb.tot.as<u32>());
+  hipLaunchKernelGGL(k_part_scan, dim3(NC), dim3(SCAN_T), 0, s2, fb.cnt.as<u32>(), fb.off.as<u32>(), nblk, fb.tot.as<u32>());
   if (nblk) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_part_scatter<SRC>), dim3(nblk), dim3(256), 0, s2, el, elpos, (u32)n, fb.off.as<u32>(), nblk, fb.tot.as<u32>(), fb.sym.as<u16>(), fb.pos.as<u32>());
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_part_genstart<SRC>), dim3(ngens), dim3(64), 0, s2, el, (u32)n, ranges, ngens, fb.off.as<u32>(), nblk, fb.tot.as<u32>(), fb.gen.as<u32>());
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fixed_chain2<SRC, MAXSYM>), dim3(ngens), dim3(64 * NC), (size_t)NC * 2 * MAXSYM * 4, s2, fb.sym.as<u16>(), fb.pos.as<u32>(), fb.gen.as<u32>(), ngens,

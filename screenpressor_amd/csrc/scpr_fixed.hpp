@@ -110,17 +110,18 @@ __global__ __launch_bounds__(256) void k_part_count(const u32* __restrict__ el, 
 }
 
 // blkoff[c][b] = items of model c before block b (b = nblk: the model's total, also written to ctotal[c])
-__global__ __launch_bounds__(256) void k_part_scan(const u32* __restrict__ blkcnt, u32* __restrict__ blkoff, u32 nblk, u32* __restrict__ ctotal) {
-  __shared__ u32 part[256];
+constexpr int SCAN_T = 1024;
+__global__ __launch_bounds__(SCAN_T) void k_part_scan(const u32* __restrict__ blkcnt, u32* __restrict__ blkoff, u32 nblk, u32* __restrict__ ctotal) {
+  __shared__ u32 part[SCAN_T];
   const int c = blockIdx.x, t = threadIdx.x;
   const u32* in = blkcnt + (size_t)c * (nblk + 1);
   u32* out = blkoff + (size_t)c * (nblk + 1);
-  const u32 per = (nblk + 255) / 256, a = min(nblk, t * per), b = min(nblk, a + per);
+  const u32 per = (nblk + SCAN_T - 1) / SCAN_T, a = min(nblk, t * per), b = min(nblk, a + per);
   u32 s = 0;
   for (u32 i = a; i < b; i++) s += in[i];
   part[t] = s;
   __syncthreads();
-  for (int d = 1; d < 256; d <<= 1) {
+  for (int d = 1; d < SCAN_T; d <<= 1) {
     const u32 v = t >= d ? part[t - d] : 0;
     __syncthreads();
     part[t] += v;
@@ -132,9 +133,9 @@ __global__ __launch_bounds__(256) void k_part_scan(const u32* __restrict__ blkcn
     out[i] = run;
     run += v;
   }
-  if (t == 255) {
-    out[nblk] = part[255];
-    ctotal[c] = part[255];
+  if (t == SCAN_T - 1) {
+    out[nblk] = part[SCAN_T - 1];
+    ctotal[c] = part[SCAN_T - 1];
   }
 }
 
