@@ -637,8 +637,8 @@ def run_rank(args):
             recs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")))
             rec = json.load(open(recs[-1]))
             if args.workload == "keys" and N == 300 and (W, H, BPP) == (1920, 1080, 32):
-                for kq in rec["kernels"]:
-                    if kernel_of.get(dom, "?") in kq["kernel"]:
+                for kq in rec["kernels"]:  # (a kernel template has one row per instance: the timed launch is the big one)
+                    if kernel_of.get(dom, "?") in kq["kernel"] and round(kq["hbm_bytes_per_launch"]) > (traffic or 0):
                         traffic, traffic_src = round(kq["hbm_bytes_per_launch"]), os.path.relpath(recs[-1], ROOT) + " (recorded rocprofv3 --pmc passes of this command)"
         except Exception:
             traffic = None
