@@ -2402,37 +2402,54 @@ __global__ __launch_bounds__(64) void k_colour_chain_w(const u32* __restrict__ s
         // costs a lone wave ~470 cycles: chains of 10^5 symbols through contexts with a handful of colours - text on a
         // background - were the critical path of the stage, 40 ms of a one-GOP encode.)
         if ((h.kind | 1) == 5 && m - j >= 3) {
-          const bool act = lane >= j && lane < m;
           const int d = h.d, mp = h.maxpos;
-          int pe = -1;            // this lane's symbol is entry pe of the table (-1: not in it)
+          const int i = lane - j;
+          const int tot_i = h.total + kStepSmall * i;
+          // the lanes of the batch: from j up to the symbol after which the rescale is due (the totals are known beforehand)
+          const bool act = lane >= j && lane < m && tot_i + 2 * kStepSmall <= kProbScale;
+          int pe = -1;            // this lane's symbol is entry pe of the table (-1: not in it, or not looked at)
           u32 wp = 0, ceq = 0, clt = 0, hmp = 0;  // its packed entry; earlier symbols of the batch on the same entry / on lower entries / on the top entry
-          for (int e = 0; e < d; e++) {
-            const u32 we = rdl(T, e), se = we & 255u;
-            const bool eq = act && (u32)cl == se;
+          // One turn per DIFFERENT symbol of the batch, in the order they first occur (a batch has two to four as a rule, whatever
+          // the size of the table): the lanes that carry it, their rank among themselves, its entry.  A symbol the table does not
+          // hold ends the batch at its first lane - every lane before that has been through a turn of its own.
+          u64 rem = __ballot(act);
+          for (int turn = 0; rem && turn < 8; turn++) {
+            const int f = (int)__builtin_ctzll(rem);
+            const u32 sy = rdl((u32)cl, f);
+            const u32 tm = (u32)__ballot(sm_sym(T) == sy) & ((1u << d) - 1u);  // (the table sits in lanes 0 .. d - 1)
+            const bool eq = act && (u32)cl == sy;
             const u64 me = __ballot(eq);
+            rem &= ~me;
+            if (SCPR_UNLIKELY(!tm)) break;
+            const int e = (int)__builtin_ctz(tm);
+            const u32 we = rdl(T, e);
             const u32 below = __builtin_amdgcn_mbcnt_hi((u32)(me >> 32), __builtin_amdgcn_mbcnt_lo((u32)me, 0u));
             pe = eq ? e : pe;
             wp = eq ? we : wp;
             ceq = eq ? below : ceq;
-            clt += (u32)cl > se ? below : 0u;  // (entries are sorted by symbol)
+            clt += (u32)cl > sy ? below : 0u;  // (entries are sorted by symbol: a lower entry is a smaller symbol)
             hmp = e == mp ? below : hmp;
           }
-          const int i = lane - j;
-          const int tot_i = h.total + kStepSmall * i;
           const int fq = (int)sm_fq(wp) + kStepSmall * (int)ceq, pp = (int)sm_p(wp) + kStepSmall * (int)clt;
           const int sh = __builtin_clz((u32)(tot_i - 1)) - 20, bonus = (kProbScale >> sh) - tot_i;
           const int ap = (int)sm_sym(wp) + pp - pe + (pe > mp ? bonus : 0), width = fq + (pe == mp ? bonus : 0);
-          const bool bad = act && (pe < 0 || tot_i + 2 * kStepSmall > kProbScale || (pe != mp && fq + kStepSmall > h.fmax + kStepSmall * (int)hmp));
+          // the batch ends before the first lane that is not a plain hit: not looked up (not in the table, past the rescale, a ninth
+          // symbol), or a hit that makes another entry the top one
+          const bool bad = lane >= j && lane < m && (pe < 0 || (pe != mp && fq + kStepSmall > h.fmax + kStepSmall * (int)hmp));
           const u64 bm = __ballot(bad);
           const int cut = bm ? (int)__builtin_ctzll(bm) : m;
           const int take = cut - j;
           if (SCPR_LIKELY(take > 0)) {
-            const bool taken = act && lane < cut;
+            const bool taken = lane >= j && lane < cut;
             if (taken) mine = ((u32)width << sh) | (((u32)ap << sh) << 16);
-            // the table after the batch: every entry's count + 50 per symbol that hit it, the sums before the entries rebuilt
+            // the table after the batch: every entry's count + 50 per symbol that hit it (one turn per different symbol again), the
+            // sums before the entries rebuilt
             int addv = 0, nmp = 0;
-            for (int e = 0; e < d; e++) {
-              const int ne = __builtin_popcountll(__ballot(taken && pe == e));
+            for (u64 r2 = __ballot(taken); r2;) {
+              const int f = (int)__builtin_ctzll(r2);
+              const u64 me = __ballot(taken && cl == (int)rdl((u32)cl, f));
+              const int ne = __builtin_popcountll(me), e = (int)rdl((u32)pe, f);
+              r2 &= ~me;
               addv = M.l15 == e ? ne : addv;
               nmp = e == mp ? ne : nmp;
             }
