@@ -224,22 +224,32 @@ class Runner:
 
     def step(self, frames, ftypes, seed=None, after=None, reset=True):
         """one pass of the hot path: fresh codecs, `seed(enc)` (a shard that does not start the stream: what crosses key
-        frames, sharding.py), compress, decompress, `after(packets, sizes)` (the exchange step)"""
+        frames, sharding.py), compress, decompress, and the exchange step: `after(packets, sizes)` once both are done, or - a
+        pair (begin, end) - `begin(packets, sizes)` as soon as the packets exist and `end()` after the decode, so that the
+        transfers run beside the decode"""
         if reset:
             self.reset()
             if seed:
                 seed(self.enc)
+        begin, end = after if isinstance(after, tuple) else (None, None)
         t0 = time.perf_counter()
         out, sizes, ft = self.enc.CompressBatch(frames, ftypes, out=self.packets)
         t1 = time.perf_counter()
         _, se = self.enc.last_timing()
+        if begin:
+            begin(out, sizes)
+            t1b = time.perf_counter()
+        else:
+            t1b = t1
         r, dec = self.dec.DecompressBatch(out, sizes, ft, out=self.decoded)
         t2 = time.perf_counter()
         _, sd = self.dec.last_timing()
         assert r == len(ftypes)
-        if after:
+        if end:
+            end()
+        elif after:
             after(out, sizes)
-        return out, sizes, ft, dec, t1 - t0, t2 - t1, {k: v for k, v in list(se.items()) + list(sd.items()) if v > 0}
+        return out, sizes, ft, dec, t1 - t0, t2 - t1b, {k: v for k, v in list(se.items()) + list(sd.items()) if v > 0}
 
 
 def shard_seeder(env, wl, frames):
@@ -417,7 +427,7 @@ def selftest_rank(args, rank, world):
     import numpy as np
     import torch.distributed as dist
     sys.path.insert(0, ROOT)
-    from screenpressor_amd.sharding import gather_packets, shard_gops
+    from screenpressor_amd.sharding import gather_packets_begin, gather_packets_end, shard_gops
     if os.environ.get("SCPR_SELFTEST_DIE_RANK") == str(rank):  # (tests: a rank that is gone before the first collective)
         sys.stderr.write("selftest: this rank gives up before the rendezvous\n")
         sys.exit(3)
@@ -429,8 +439,11 @@ def selftest_rank(args, rank, world):
     pk = [bytes([(7 * t + j) & 255 for j in range(5 + t % 3)]) for t in range(lo, hi)]
     payload = np.frombuffer(b"".join(pk), dtype=np.uint8).copy()
     sizes = [len(p) for p in pk]
-    if world > 1:
-        out_p, out_s = gather_packets(dist, rank, world, payload, sizes)
+    if world > 1:  # (in two halves, as the timed step does it: the transfers run beside the work in between)
+        h = gather_packets_begin(dist, rank, world, payload, sizes)
+        local_sum = int(payload.sum())
+        out_p, out_s = gather_packets_end(h)
+        assert local_sum == int(payload.sum())
     else:
         out_p, out_s = payload, sizes
     if rank == 0:
@@ -556,7 +569,7 @@ def run_rank(args):
     import torch
     import torch.distributed as dist
     sys.path.insert(0, ROOT)
-    from screenpressor_amd.sharding import gather_packets
+    from screenpressor_amd.sharding import gather_packets_begin, gather_packets_end
 
     cdev = None
     if world > 1 and args.rehearse_one_gpu:
@@ -585,11 +598,17 @@ def run_rank(args):
     barrier = env.barrier
     gathered = {}
 
-    def exchange(out, sizes):  # the exchange step: compressed chunks + sizes to rank 0 in frame order (RCCL over xGMI)
+    # the exchange step: compressed chunks + sizes to rank 0 in frame order (RCCL over xGMI), started when the encoder has
+    # returned and waited for after the decode of the same step - the chunks travel while the decoder's chains run
+    def exchange_begin(out, sizes):
         if world > 1:
-            gathered["p"], gathered["s"] = gather_packets(dist, rank, world, out, sizes, device=cdev)
+            gathered["h"] = gather_packets_begin(dist, rank, world, out, sizes, device=cdev)
 
-    m = measure(runner, wl, frames, args.steps, args.warmup, barrier, seed, exchange)
+    def exchange_end():
+        if world > 1:
+            gathered["p"], gathered["s"] = gather_packets_end(gathered.pop("h"))
+
+    m = measure(runner, wl, frames, args.steps, args.warmup, barrier, seed, (exchange_begin, exchange_end))
     if seed is not None and seed.error:
         raise RuntimeError("motion pre-pass: " + seed.error)
     tmax = torch.tensor([m["elapsed"]], device=cdev, dtype=torch.float64)

@@ -93,9 +93,10 @@ def handover_mv_memory(dist, rank: int, world: int, nblocks: int, prepass, devic
     return mine
 
 
-def gather_packets(dist, rank: int, world: int, payload: np.ndarray, sizes: np.ndarray, device=None):
-    """Rank 0 receives every rank's packets and per-frame sizes, in rank (= frame) order.
-    `payload` is a uint8 array (numpy on CPU/gloo, or a torch tensor on the GPU for RCCL)."""
+def gather_packets_begin(dist, rank: int, world: int, payload: np.ndarray, sizes: np.ndarray, device=None):
+    """Starts the gather of gather_packets() and returns a handle for gather_packets_end(): the transfers run beside whatever
+    the caller does in between (bench.py: the decode of the same step - the packets are final once the encoder returns).
+    `payload` must stay untouched until the end call."""
     import torch
     t_payload = payload if isinstance(payload, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(payload))
     t_sizes = torch.as_tensor(np.asarray(sizes, dtype=np.int64))
@@ -104,8 +105,9 @@ def gather_packets(dist, rank: int, world: int, payload: np.ndarray, sizes: np.n
     meta = torch.tensor([t_payload.numel(), t_sizes.numel()], dtype=torch.int64, device=t_payload.device)
     metas = [torch.zeros_like(meta) for _ in range(world)]
     dist.all_gather(metas, meta)  # every rank learns every rank's byte and frame count (16 bytes each) ...
-    max_bytes = int(max(int(m[0]) for m in metas))
-    max_frames = int(max(int(m[1]) for m in metas))
+    counts = [(int(m[0]), int(m[1])) for m in metas]
+    max_bytes = max(c[0] for c in counts)
+    max_frames = max(c[1] for c in counts)
     pad_p = torch.zeros(max_bytes, dtype=torch.uint8, device=t_payload.device)
     pad_p[: t_payload.numel()] = t_payload
     pad_s = torch.zeros(max_frames, dtype=torch.int64, device=t_payload.device)
@@ -113,10 +115,25 @@ def gather_packets(dist, rank: int, world: int, payload: np.ndarray, sizes: np.n
     # ... and the packets themselves travel to rank 0 only (sizes, then a gather of the chunks to rank 0)
     gp = [torch.empty_like(pad_p) for _ in range(world)] if rank == 0 else None
     gs = [torch.empty_like(pad_s) for _ in range(world)] if rank == 0 else None
-    dist.gather(pad_p, gather_list=gp, dst=0)
-    dist.gather(pad_s, gather_list=gs, dst=0)
-    if rank != 0:
+    works = [dist.gather(pad_p, gather_list=gp, dst=0, async_op=True), dist.gather(pad_s, gather_list=gs, dst=0, async_op=True)]
+    return {"rank": rank, "world": world, "counts": counts, "gp": gp, "gs": gs, "works": works, "keep": (pad_p, pad_s, t_payload, t_sizes)}
+
+
+def gather_packets_end(handle):
+    """Waits for the transfers of gather_packets_begin(); rank 0 gets (packets, sizes) in rank (= frame) order, the others
+    (None, None)."""
+    import torch
+    for w in handle["works"]:
+        w.wait()
+    if handle["rank"] != 0:
         return None, None
-    out_p = torch.cat([gp[r][: int(metas[r][0])] for r in range(world)])
-    out_s = torch.cat([gs[r][: int(metas[r][1])] for r in range(world)])
+    counts, gp, gs = handle["counts"], handle["gp"], handle["gs"]
+    out_p = torch.cat([gp[r][: counts[r][0]] for r in range(handle["world"])])
+    out_s = torch.cat([gs[r][: counts[r][1]] for r in range(handle["world"])])
     return out_p, out_s
+
+
+def gather_packets(dist, rank: int, world: int, payload: np.ndarray, sizes: np.ndarray, device=None):
+    """Rank 0 receives every rank's packets and per-frame sizes, in rank (= frame) order.
+    `payload` is a uint8 array (numpy on CPU/gloo, or a torch tensor on the GPU for RCCL)."""
+    return gather_packets_end(gather_packets_begin(dist, rank, world, payload, sizes, device=device))
