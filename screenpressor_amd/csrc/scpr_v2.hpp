@@ -222,7 +222,7 @@ struct WaveDecV2 {
   __device__ __forceinline__ int fixed_sxy(int k) { return dec_lds<1>(L.fx.sxy[k], 16, 100); }  // SC_SXYSTEP
   __device__ __forceinline__ int fixed_mv(int k) { return dec_lds<8>(L.fx.m[k], k ? my2 : mx2, 100); }  // SC_MSTEP
   __device__ __forceinline__ bool get_bool() { return false; }                                // canEncodeBool = false
-  template <bool CHK = true, int MODE = 0>
+  template <bool CHK = true, int MODE = 0, bool PF = false>
   __device__ __forceinline__ int colour(int ctxid, u32* = nullptr) { return dec_global(gtabs + (size_t)ctxid * V2_COLTAB, 400); }  // SC_STEP
 
   // RenewI with the renew* of UseRC (screencap.h:146-260): every count 1
