@@ -38,6 +38,43 @@ __device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_A
 __device__ __forceinline__ u32 rfl(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ u64 rfl64(u64 v) { return (u64)rfl((u32)v) | ((u64)rfl((u32)(v >> 32)) << 32); }
 __device__ __forceinline__ u32 rdl(u32 v, int lane) { return (u32)__builtin_amdgcn_readlane((int)v, lane); }
+// ---- memory operations by SOME lanes, without a branch ------------------------------------------------------------------
+// The compiler structurises a loop's control flow as soon as one lane-divergent branch sits anywhere inside it - the loop's own
+// wave-uniform branches included, which then come back as flag registers and exec tests on the common path.
+// "if (lane == 0) store" is such a branch.  These do the same with exec narrowed around ONE instruction and put back: the
+// compiler sees a call, not control flow.  (exec may be empty for the instruction: it then does nothing.)  The global forms
+// wait for their own completion - they are for the rare ways - and the LDS forms need no wait: a wave's DS operations
+// execute in order.  `p` of the LDS forms is any pointer into LDS (its low 32 bits are the LDS offset).
+__device__ __forceinline__ void lds_st_if(const void* p, u32 v, bool on) {
+  u64 keep;
+  asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %1\n\tds_write_b32 %2, %3\n\ts_mov_b64 exec, %0" : "=&s"(keep) : "s"(__ballot(on)), "v"((u32)(size_t)p), "v"(v) : "memory", "scc");
+}
+__device__ __forceinline__ void lds_st16_if(const void* p, u32 v, bool on) {
+  u64 keep;
+  asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %1\n\tds_write_b16 %2, %3\n\ts_mov_b64 exec, %0" : "=&s"(keep) : "s"(__ballot(on)), "v"((u32)(size_t)p), "v"(v) : "memory", "scc");
+}
+__device__ __forceinline__ void lds_or_if(const void* p, u32 v, bool on) {
+  u64 keep;
+  asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %1\n\tds_or_b32 %2, %3\n\ts_mov_b64 exec, %0" : "=&s"(keep) : "s"(__ballot(on)), "v"((u32)(size_t)p), "v"(v) : "memory", "scc");
+}
+__device__ __forceinline__ void lds_add_if(const void* p, u32 v, bool on) {
+  u64 keep;
+  asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %1\n\tds_add_u32 %2, %3\n\ts_mov_b64 exec, %0" : "=&s"(keep) : "s"(__ballot(on)), "v"((u32)(size_t)p), "v"(v) : "memory", "scc");
+}
+__device__ __forceinline__ void glb_st_if(u32* p, u32 v, bool on) {
+  u64 keep;
+  asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %1\n\tglobal_store_dword %2, %3, off\n\ts_mov_b64 exec, %0\n\ts_waitcnt vmcnt(0)" : "=&s"(keep) : "s"(__ballot(on)), "v"(p), "v"(v) : "memory", "scc");
+}
+__device__ __forceinline__ void glb_or_lane0(u32* p, u32 v) {  // agent scope, nothing returned (error flags)
+  u64 keep;
+  asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_or %1, %2, off\n\ts_mov_b64 exec, %0\n\ts_waitcnt vmcnt(0)" : "=&s"(keep) : "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ u32 glb_add_lane0(u32* p, u32 v) {  // returns what was there before, in every lane
+  u64 keep;
+  u32 old = 0;
+  asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_add %1, %2, %3, off sc0\n\ts_mov_b64 exec, %0\n\ts_waitcnt vmcnt(0)" : "=&s"(keep), "+v"(old) : "v"(p), "v"(v) : "memory");
+  return rfl(old);
+}
 // inclusive scan inside each row of 16 lanes: four DPP row_shr adds (no LDS traffic)
 __device__ __forceinline__ int row_incl_scan(int v) {
   v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
@@ -207,13 +244,13 @@ struct WaveModel {
       dmiss++;
 #endif
       if (SCPR_UNLIKELY(idx > arena.cap)) {  // beyond the sink: never a table (a record that is not what it says): reported, not followed
-        if (lane == 0) atomicOr(arena.err, 16u);
+        glb_or_lane0(arena.err, 16u);
         oom = true;
         return c;
       }
       if (tag) copy_tab<false>(arena.tabs + (tag - 1u), c, lane);
       if (!fresh) copy_tab<true>(c, arena.tabs + idx, lane);
-      if (lane == 0) dtag[slot] = idx + 1u;
+      dtag[slot] = idx + 1u;  // (every lane the same word: no lane mask, no branch)
       wave_fence();
     }
     return c;
@@ -259,7 +296,10 @@ struct WaveModel {
   // the table brought up to date with the top-entry hits that top_hit<DEC, true> only counted in the header
   __device__ __forceinline__ void small_settle(const ColHdr& h, u32& w) {
     const u32 delta = (u32)h.fmax - (h.top >> 20);
-    w += l15 == h.maxpos ? delta << 8 : ((u32)(l15 - h.maxpos - 1) < (u32)(h.d - h.maxpos - 1) ? delta << 20 : 0u);
+    // (masks, not a nested choice: the optimiser turns that one back into a branch on the lane number; the two conditions
+    // exclude each other)
+    const u32 is_top = 0u - (u32)(l15 == h.maxpos), is_above = 0u - (u32)((u32)(l15 - h.maxpos - 1) < (u32)(h.d - h.maxpos - 1));
+    w += (is_top & (delta << 8)) | (is_above & (delta << 20));
   }
   // A symbol that is the top entry of a small table, no rescale due after it.  DEC: `in` is the coder value, else the symbol.
   // Returns a negative number and has applied the symbol (w, h.total, h.fmax updated; c, ofr, ocf set) - or a non-negative one
@@ -319,15 +359,11 @@ struct WaveModel {
     }
   }
   __device__ __forceinline__ u32 alloc_dense() {
-    u32 idx = 0;
-    if (lane == 0) {
-      idx = atomicAdd(arena.top, 1u);
-      if (idx >= arena.cap) {
-        atomicOr(arena.err, 1u);
-        idx = 0x80000000u;
-      }
+    u32 idx = glb_add_lane0(arena.top, 1u);
+    if (SCPR_UNLIKELY(idx >= arena.cap)) {  // (wave-uniform)
+      glb_or_lane0(arena.err, 1u);
+      idx = 0x80000000u;
     }
-    idx = rfl(idx);
     // The arena is full: the context gets the SINK, table `cap` (allocated behind the usable ones, never a live context's
     // table).  Contexts that share it overwrite each other's contents, so whatever is coded from here on is thrown away (the
     // host runs the chunk again with the true bound, or fails the call), but it stays harmless: every record still names a
@@ -359,14 +395,14 @@ struct WaveModel {
   __device__ __forceinline__ void note_raw(u32* r, ColHdr& h, int c, u32& w) {
     wave_fence();
     if (h.kind == 0) {
-      if (lane < 8) r[4 + lane] = (lane == (c >> 5)) ? (1u << (c & 31)) : 0u;
+      lds_st_if(&r[4 + lane], (lane == (c >> 5)) ? (1u << (c & 31)) : 0u, lane < 8);
       h.kind = 1;
       h.d = 1;
       return;
     }
     const u32 sw = rfl(r[4 + (c >> 5)]);
     if (!((sw >> (c & 31)) & 1u)) {
-      if (lane == 0) r[4 + (c >> 5)] = sw | (1u << (c & 31));
+      r[4 + (c >> 5)] = sw | (1u << (c & 31));  // (every lane the same word)
       h.d++;
       if (h.kind == 1 && h.d == 15) h.kind = 2;
       else if (h.kind == 2 && h.d == 65) h.kind = 3;
@@ -380,10 +416,11 @@ struct WaveModel {
       const int lc = c >> 2;
       h.maxpos = (int)rdl((u32)base, lc) + __builtin_popcount(rdl(bits, lc) & ((1u << (c & 3)) - 1u));
       // rank -> lane: scatter through the LDS scratch (at most 14 symbols)
-      for (int q = 0; q < 4; q++)
-        if ((bits >> q) & 1u) tmp[base + __builtin_popcount(bits & ((1u << q) - 1u))] = (u16)(lane * 4 + q);
+#pragma unroll
+      for (int q = 0; q < 4; q++) lds_st16_if(&tmp[base + __builtin_popcount(bits & ((1u << q) - 1u))], (u32)(lane * 4 + q), (bits >> q) & 1u);
       wave_fence();
-      const int sym = l15 < d ? (int)tmp[l15] : 0;
+      const int sym0 = (int)tmp[l15 < d ? l15 : 0];  // (read by every lane, chosen afterwards: no branch on the lane)
+      const int sym = l15 < d ? sym0 : 0;
       wave_fence();
       h.kind = d <= 4 ? 4 : 5;
       h.total = small_pack(w, sym, sym == c ? 2 * kStepSmall : kStepSmall, d);
@@ -391,20 +428,18 @@ struct WaveModel {
       return;
     }
     h.dense = alloc_dense();
-    if (lane == 0) r[2] = h.dense;  // the table index only changes here: the per-symbol header store leaves word 2 alone
+    r[2] = h.dense;  // (every lane the same word)  the table index only changes here: the per-symbol header store leaves word 2 alone
     DenseTab* t = tab_of(h.dense, true);
     int fr[4], cn[4];
     if (h.kind == 2) {  // Cx6::create23, ans_contexts.h:491-531
       const int tot = 256 - d + d * f0 + f0, sh = shift_for(tot), wdt = 1 << sh;
-      for (int q = 0; q < 4; q++) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) {  // (choices, not branches, on what differs from lane to lane)
         const int j = lane * 4 + q;
-        if ((bits >> q) & 1u) {
-          fr[q] = (((j == c) ? 2 * f0 : f0) << sh) & 0xFFFF;
-          cn[q] = fr[q] - (fr[q] >> 1);
-        } else {
-          fr[q] = wdt;
-          cn[q] = 0;
-        }
+        const bool met = (bits >> q) & 1u;
+        const int fm = (((j == c) ? 2 * f0 : f0) << sh) & 0xFFFF;
+        fr[q] = met ? fm : wdt;
+        cn[q] = met ? fm - (fm >> 1) : 0;
       }
       const int sum = write_dense(t, fr, cn);
       h.kind = 6;
@@ -412,14 +447,11 @@ struct WaveModel {
       h.total = ((256 - d) << (sh > 0 ? sh - 1 : 0)) + sum;
     } else {  // Cx7::create(Cx3&), :917-951
       const int g0 = (kProbScale - (256 - d)) / (d + 1), c0 = g0 - (g0 >> 1);
+#pragma unroll
       for (int q = 0; q < 4; q++) {
         const int j = lane * 4 + q;
-        fr[q] = ((bits >> q) & 1u) ? g0 : 1;
-        cn[q] = ((bits >> q) & 1u) ? c0 : 1;
-        if (j == c) {
-          fr[q] += g0;
-          cn[q] += kStepDense;
-        }
+        fr[q] = (((bits >> q) & 1u) ? g0 : 1) + (j == c ? g0 : 0);
+        cn[q] = (((bits >> q) & 1u) ? c0 : 1) + (j == c ? kStepDense : 0);
       }
       h.kind = 7;
       h.total = write_dense(t, fr, cn);
@@ -493,8 +525,8 @@ struct WaveModel {
     if (SCPR_LIKELY(over < 0)) {
       ofr = (u32)(endp - ap) << sh;
       ocf = (u32)ap << sh;
-      const u32 add = l15 == p ? (u32)kStepSmall << 8 : ((u32)(l15 - p - 1) < (u32)(d - p - 1) ? (u32)kStepSmall << 20 : 0u);  // the count of p, the P of p+1 .. d-1
-      w += add;
+      // the count of p, the P of p+1 .. d-1 (masks: see small_settle)
+      w += ((0u - (u32)(l15 == p)) & ((u32)kStepSmall << 8)) | ((0u - (u32)((u32)(l15 - p - 1) < (u32)(d - p - 1))) & ((u32)kStepSmall << 20));
       tot += kStepSmall;
       if (fpr + kStepSmall > h.fmax) {  // p is the top entry already, or becomes it (:181)
         h.maxpos = p;
@@ -520,8 +552,10 @@ struct WaveModel {
     const int cap = h.kind == 4 ? 4 : 16;
     if (d < cap || h.kind == 4) {  // addSymb (:174-184), or Cx5::create(Cx4&, c) (:350-369) when the 4-table is full
       const u32 up = (u32)dpp_row_shr1((int)w);
-      if (l15 > pos && l15 <= d) w = up + ((u32)kStepSmall << 20);
-      else if (l15 == pos) w = (u32)c | ((u32)kStepSmall << 8) | ((u32)(pp + fpr) << 20);
+      {  // (selects by masks: no branch on the lane number)
+        const u32 mv = 0u - (u32)(l15 > pos && l15 <= d), me = 0u - (u32)(l15 == pos);
+        w = (mv & (up + ((u32)kStepSmall << 20))) | (me & ((u32)c | ((u32)kStepSmall << 8) | ((u32)(pp + fpr) << 20))) | (~(mv | me) & w);
+      }
       const bool grow = d == cap;  // kind 4 -> 5: maxpos restarts at 0 (value-initialised in the reference)
       d++;
       if (grow) {
@@ -548,35 +582,29 @@ struct WaveModel {
     const bool act = l15 < d;
     const int fqv = act ? (int)sm_fq(w) : 0;
     wave_fence();
+#pragma unroll
     for (int q = 0; q < 4; q++) tmp[lane * 4 + q] = 0;
     wave_fence();
-    if (act) tmp[sm_sym(w)] = (u16)fqv;
+    lds_st16_if(&tmp[sm_sym(w) & 255u], (u32)fqv, act);
     wave_fence();
     const int tex = 256 - d + row16_sum(fqv), s2 = shift_for(tex), wdt = 1 << s2, base = wdt - (wdt >> 1);
     int fr[4], cn[4];
     u32 bits = 0;
-    for (int q = 0; q < 4; q++) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {  // (choices, not branches, on what differs from lane to lane)
       const int j = lane * 4 + q, pf = tmp[j];
-      if (pf) {
-        fr[q] = (pf << s2) & 0xFFFF;
-        cn[q] = fr[q] - (fr[q] >> 1);
-        bits |= 1u << q;
-      } else {
-        fr[q] = wdt;
-        cn[q] = 0;
-      }
-      if (j == c) {
-        cn[q] = base + (kStepHash << s2);
-        bits |= 1u << q;
-      }
+      const int fm = (pf << s2) & 0xFFFF;
+      fr[q] = pf ? fm : wdt;
+      cn[q] = j == c ? base + (kStepHash << s2) : pf ? fm - (fm >> 1) : 0;
+      bits |= (pf || j == c) ? 1u << q : 0u;
     }
     wave_fence();
-    if (lane < 8) r[4 + lane] = 0;
+    lds_st_if(&r[4 + lane], 0u, lane < 8);
     wave_fence();
-    atomicOr(&r[4 + (lane >> 3)], bits << ((lane & 7) * 4));
+    lds_or_if(&r[4 + (lane >> 3)], bits << ((lane & 7) * 4), true);
     wave_fence();
     h.dense = alloc_dense();
-    if (lane == 0) r[2] = h.dense;  // the table index only changes here: the per-symbol header store leaves word 2 alone
+    r[2] = h.dense;  // (every lane the same word)  the table index only changes here: the per-symbol header store leaves word 2 alone
     const int sum = write_dense(tab_of(h.dense, true), fr, cn);
     h.kind = 6;
     h.fshift = s2;
@@ -626,8 +654,9 @@ struct WaveModel {
     const u64 m = DEC ? __ballot(c0 <= v) : 0;
     const int own = DEC ? 63 - __builtin_clzll(m) : in >> 2;
     const int k = DEC ? (c1 <= v) + (c2 <= v) + (c3 <= v) : (in & 3);
-    const u32 selc = k == 0 ? c0 : k == 1 ? c1 : k == 2 ? c2 : c3;
-    const u32 self = k == 0 ? (fq.x & 0xFFFF) : k == 1 ? (fq.x >> 16) : k == 2 ? (fq.y & 0xFFFF) : (fq.y >> 16);
+    // (a word by bit 1 of k, a half by bit 0: a chain of choices comes back as branches on the lane)
+    const u32 selc = (((k & 2) ? cu.y : cu.x) >> (16 * (k & 1))) & 0xFFFFu;
+    const u32 self = (((k & 2) ? fq.y : fq.x) >> (16 * (k & 1))) & 0xFFFFu;
     const int kk = (int)rdl((u32)k, own);
     const int j = own * 4 + kk;
     ofr = rdl(self, own);
@@ -643,28 +672,28 @@ struct WaveModel {
       if (SCPR_UNLIKELY(!present)) {
         if (h.d >= kHashMaxSyms) {  // 41st symbol: becomes kind 7, uncounted (:631, Cx7::create(const Cx6&) :868-915)
           const int wdt = 1 << h.fshift, base = wdt - (wdt >> 1);
-          for (int q = 0; q < 4; q++)
-            if (!((bits >> q) & 1u)) cn[q] = base;
+#pragma unroll
+          for (int q = 0; q < 4; q++) cn[q] = ((bits >> q) & 1u) ? cn[q] : base;
           tab_st<LDS>(t->cnt, lane, u32x2{(u32)cn[0] | ((u32)cn[1] << 16), (u32)cn[2] | ((u32)cn[3] << 16)});
           h.kind = 7;
           return DEC ? (j & 255) : j;
         }
-        if (lane == own) {  // placeSymbol, :621-638
-          nbits |= 1u << kk;
+        {  // placeSymbol, :621-638 (the owning lane's doing, by selects and a one-lane LDS operation: no branch on the lane)
+          const bool mine = lane == own;
+          nbits |= mine ? 1u << kk : 0u;
 #pragma unroll
-          for (int q = 0; q < 4; q++)
-            if (q == kk) cn[q] = (int)ofr - ((int)ofr >> 1);
-          atomicOr(&r[4 + (lane >> 3)], (1u << kk) << ((lane & 7) * 4));
+          for (int q = 0; q < 4; q++) cn[q] = (mine && q == kk) ? (int)ofr - ((int)ofr >> 1) : cn[q];
+          lds_or_if(&r[4 + (lane >> 3)], (1u << kk) << ((lane & 7) * 4), mine);
         }
         h.d++;
       }
     }
 #pragma unroll
-    for (int q = 0; q < 4; q++)
-      if (lane == own && q == kk) cn[q] += step;
+    for (int q = 0; q < 4; q++) cn[q] += (lane == own && q == kk) ? step : 0;
     h.total += step;
     if (SCPR_UNLIKELY(h.total + step > kProbScale)) {
       if (h.kind == 7) {  // Cx7::incrCnt rebuild, :963-980
+#pragma unroll
         for (int q = 0; q < 4; q++) {
           fr[q] = cn[q];
           cn[q] -= cn[q] >> 1;
@@ -673,19 +702,16 @@ struct WaveModel {
       } else {  // Cx6::rescale, :742-796
         const int wdt = 1 << (h.fshift > 0 ? h.fshift - 1 : 0);
         if (h.fshift > 0) h.fshift--;
+#pragma unroll
         for (int q = 0; q < 4; q++) {
-          if ((nbits >> q) & 1u) {
-            fr[q] = cn[q];
-            cn[q] -= cn[q] >> 1;
-          } else {
-            fr[q] = wdt;
-            cn[q] = 0;
-          }
+          const bool met = (nbits >> q) & 1u;
+          fr[q] = met ? cn[q] : wdt;
+          cn[q] = met ? cn[q] - (cn[q] >> 1) : 0;
         }
         const int sum = write_dense<LDS>(t, fr, cn);
         h.total = ((256 - h.d) << (h.fshift > 0 ? h.fshift - 1 : 0)) + sum;
       }
-    } else if (lane == own) {
+    } else {  // (the counts go back from all lanes alike - only the owner's have changed: no branch on the lane)
       tab_st<LDS>(t->cnt, lane, u32x2{(u32)cn[0] | ((u32)cn[1] << 16), (u32)cn[2] | ((u32)cn[3] << 16)});
     }
     return DEC ? (j & 255) : j;  // (a table that other contexts have scribbled on after an arena overflow may match no lane: own = -1)
@@ -1032,10 +1058,7 @@ struct WaveDec : WaveModel {
       sym = 63 + __builtin_popcountll(__ballot(e1 < lim)) + __builtin_popcountll(__ballot(e2 < lim)) + __builtin_popcountll(__ballot(e3 < lim));
       const int q = sym >> 6, l = sym & 63;
       s = q == 1 ? rdl(e1, l) : q == 2 ? rdl(e2, l) : rdl(e3, l);
-      if (lane == 0) {
-        const u32 a1 = (u32)(size_t)&tab[NTAB_CNT + sym];
-        asm volatile("ds_add_u32 %0, %1" ::"v"(a1), "v"((u32)kStepDense) : "memory");
-      }
+      lds_add_if(&tab[NTAB_CNT + sym], (u32)kStepDense, lane == 0);
     }
     {
       // the count of the symbol (from the lane that holds it: none for a symbol above 63, counted above) and the
@@ -1060,7 +1083,7 @@ struct WaveDec : WaveModel {
         ns += h;
       }
       ns = wave_sum(ns);
-      if (lane == 0) tab[256] = (u32)ns;
+      tab[256] = (u32)ns;  // (every lane the same word)
       wave_fence();
     }
     if constexpr (!DOUT) count<CHK>();
@@ -1086,11 +1109,9 @@ struct WaveDec : WaveModel {
       const int inc = wave_incl_scan(c);
       const int h = c - (c >> 1);
       const int nt = wave_sum(h);
-      if (in) {
-        pfc = (u32)c | ((u32)(inc - c) << 16);
-        pcnt = (u32)h;
-      }
-      if (lane == tl) pcnt = (u32)nt;
+      pfc = in ? (u32)c | ((u32)(inc - c) << 16) : pfc;
+      pcnt = in ? (u32)h : pcnt;
+      pcnt = lane == tl ? (u32)nt : pcnt;
     }
     if constexpr (!DEFER) count<CHK>();
     return j;
@@ -1259,9 +1280,12 @@ struct WaveDec : WaveModel {
     asm volatile("" : "+s"(h0), "+s"(h1), "+s"(h2));
     if (SCPR_UNLIKELY(tag != (u32)ctxid)) {
       event<9>();
-      if (lane < DECREC_WORDS) {
-        if (tag != kNoCtx) gstates[tag].w[lane] = r[lane];
-        r[lane] = lane == 3 ? (u32)ctxid : gstates[ctxid].w[lane];
+      {  // (the record's words by its first lanes, without a branch on the lane: masked stores, a load every lane can make)
+        const int wl = min(lane, DECREC_WORDS - 1);
+        const bool in = lane < DECREC_WORDS;
+        glb_st_if(&gstates[tag != kNoCtx ? tag : (u32)ctxid].w[wl], r[wl], in && tag != kNoCtx);
+        const u32 nw = gstates[ctxid].w[wl];
+        lds_st_if(&r[wl], lane == 3 ? (u32)ctxid : nw, in);
       }
       wave_fence();
       asm volatile("ds_read_b128 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=v"(hw), "=v"(w) : "v"(ra), "v"(ea) : "memory");
@@ -1439,9 +1463,9 @@ struct WaveDec : WaveModel {
         note_raw(r, h, c, w);
         wave_fence();
         if (h.kind == 4 || h.kind == 5) {  // promoted to a small table
-          if (lane < 16) r[4 + lane] = w;
+          r[4 + l15] = w;  // (every row of 16 lanes holds the table alike: no lane mask)
           const u32 nt = small_top(h, w) | ((u32)h.fmax << 20);
-          if (lane == 0) r[2] = nt;
+          r[2] = nt;  // (every lane the same word)
         }
         wave_fence();
         scalar_hdr(h);
@@ -1645,23 +1669,22 @@ __device__ __forceinline__ void decode_intra_frame(DEC& D, const Geom& g, u8* __
         u32 tl = ring[(pq - W - 1) & pm];
         if (pad) {  // in column 0 "above-left" is the bytes just before the row above in memory: the tail of the
                     // last pixel two rows up followed by that row's padding (screencap.cpp:881)
-          int xq = (int)pq - rowbase;
-          while (xq >= W) xq -= W;
-          if (xq == 0) tl >>= 8 * pad;
+          const int xq = ((int)pq - rowbase) % W;  // (not a loop: its trip count would differ from lane to lane)
+          tl >>= xq == 0 ? 8 * pad : 0;
         }
         if (t == 5) {
           v = tl;
         } else {  // gradient: previous + top - topleft, a running sum along the run (mod 256 per channel)
           const u32 tp = ring[(pq - W) & pm];
           int d0 = (int)(tp & 255) - (int)(tl & 255), d1 = (int)((tp >> 8) & 255) - (int)((tl >> 8) & 255), d2 = (int)((tp >> 16) & 255) - (int)((tl >> 16) & 255);
-          if (lane >= m) d0 = d1 = d2 = 0;
+          d0 = lane >= m ? 0 : d0, d1 = lane >= m ? 0 : d1, d2 = lane >= m ? 0 : d2;
           d0 = wave_incl_scan(d0);
           d1 = wave_incl_scan(d1);
           d2 = wave_incl_scan(d2);
           v = (u32)(((int)(lastpix & 255) + d0) & 255) | ((u32)(((int)((lastpix >> 8) & 255) + d1) & 255) << 8) | ((u32)(((int)((lastpix >> 16) & 255) + d2) & 255) << 16);
           lastpix = rdl(v, m - 1);
         }
-        if (lane < m) ring[pq & pm] = v;
+        lds_st_if(&ring[pq & pm], v, lane < m);
       }
       wave_fence();
       lastpix = rdl(v, m - 1);
