@@ -30,8 +30,14 @@ def build_hip(force: bool = False) -> str:
         # it takes most of the layout luck out of comparing small changes.
         # -enable-post-misched=false: the post-RA scheduler's reordering costs the same kernel 3 % (measured; the other
         # kernels do not move).
+        # -structurizecfg-skip-uniform-regions: the back end structurises every region of control flow, wave-uniform ones
+        # included, unless told otherwise - a uniform if/else then comes back as flag registers and exec tests on the common
+        # path.  With the switch a region is left alone when it and everything inside it branch on wave-uniform conditions
+        # only, which is why the chains' and the decoder's loops hold no branch on the lane number (scpr_wave.hpp: lds_st_if &
+        # co., choices instead of branches): their scalar branches stay scalar branches.
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-strict-aliasing", "-fPIC", "-shared", "-Wno-unused-result",
-               "-mllvm", "-align-all-nofallthru-blocks=6", "-mllvm", "-enable-post-misched=false", "-o", LIB, HIP_SRC] + HOST_SRC
+               "-mllvm", "-align-all-nofallthru-blocks=6", "-mllvm", "-enable-post-misched=false",
+               "-mllvm", "-structurizecfg-skip-uniform-regions=true", "-o", LIB, HIP_SRC] + HOST_SRC
         subprocess.check_call(cmd)
     return LIB
 

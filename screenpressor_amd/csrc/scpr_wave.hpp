@@ -234,7 +234,7 @@ struct WaveModel {
   }
   // where table idx is to be read and written (fresh: it is about to be written whole, its old contents do not matter)
   __device__ __forceinline__ DenseTab* tab_of(u32 idx, bool fresh = false) {
-    if (!dcache) return arena.tabs + idx;
+    if (dc_lds == 0u) return arena.tabs + idx;  // (the number, not the pointer: a generic pointer's null test reads the aperture register)
     wave_fence();
     const u32 slot = idx & dmask;
     const u32 tag = rfl(dtag[slot]);
@@ -256,7 +256,7 @@ struct WaveModel {
     return c;
   }
   __device__ __forceinline__ void flush_tabs() {
-    if (!dcache) return;
+    if (dc_lds == 0u) return;
     wave_fence();
     for (u32 slot = 0; slot <= dmask; slot++) {
       const u32 tag = rfl(dtag[slot]);
@@ -330,6 +330,23 @@ struct WaveModel {
       c = ts;
     }
     return t;
+  }
+  // top_hit<true, true> in two halves for a caller that branches on the test itself (the decoder's colour()): the test, with
+  // nothing touched, and what a hit does
+  __device__ __forceinline__ int top_test(const ColHdr& h, int in, int& sh, int& ap, int& width) const {
+    const int tot = h.total;
+    sh = __builtin_clz((u32)(tot - 1)) - 20;
+    const int bonus = (kProbScale >> sh) - tot;
+    ap = (int)(h.top & 255u) + (int)((h.top >> 8) & 0xFFFu) - h.maxpos, width = h.fmax + bonus;
+    const int vv = in >> sh;
+    return (vv - ap - width) & (ap - vv - 1) & (tot + 2 * kStepSmall - kProbScale - 1);  // each negative when fine
+  }
+  __device__ __forceinline__ void top_apply(ColHdr& h, int sh, int ap, int width, int& c, u32& ofr, u32& ocf) const {
+    ofr = (u32)width << sh;
+    ocf = (u32)ap << sh;
+    h.total += kStepSmall;
+    h.fmax += kStepSmall;
+    c = (int)(h.top & 255u);
   }
   static __device__ __forceinline__ u32 pack0(const ColHdr& h) { return (u32)h.kind | ((u32)h.maxpos << 8) | ((u32)h.fshift << 16); }
   static __device__ __forceinline__ u32 pack1(const ColHdr& h) { return (u32)h.d | ((u32)h.total << 16); }
@@ -643,7 +660,7 @@ struct WaveModel {
   __device__ __forceinline__ int dense_op(u32* r, ColHdr& h, int in, u32& ofr, u32& ocf) {
     wave_fence();
     DenseTab* t = tab_of(h.dense);
-    if (dcache) return dense_impl<DEC, true>(t, r, h, in, ofr, ocf);
+    if (dc_lds != 0u) return dense_impl<DEC, true>(t, r, h, in, ofr, ocf);
     return dense_impl<DEC, false>(t, r, h, in, ofr, ocf);
   }
   template <bool DEC, bool LDS>
@@ -1322,7 +1339,7 @@ struct WaveDec : WaveModel {
   // met-symbol set (lanes 0..7 of w, read with the record) are taken out with lane reads, so everything after the table read
   // is scalar; the counts go back from all lanes alike (no lane mask).
   __device__ __forceinline__ int dense_hit(ColHdr& h, u32 w, int v, int& c, u32& ofr, u32& ocf) {
-    if (!dcache) return 0;
+    if (dc_lds == 0u) return 0;
     DenseTab* t = tab_of(h.dense);
     const u32 ta = (u32)(size_t)t + 8u * (u32)lane;  // LDS offset of this lane's four symbols (freq at +0, cum at +512, cnt at +1024)
     u32x2 fq, cu, cq;
@@ -1413,20 +1430,42 @@ struct WaveDec : WaveModel {
     u32* r = MODE == 2 ? record<CHK, true>(ctxid, h, w, ra, ea, h0, hz, pend[0], pend[1], pend[2]) : record<CHK, false>(ctxid, h, w, ra, ea, h0, hz);
     event<8>();
     const int maxpos0 = h.maxpos;
-    // Plain ifs, the common case first (an else costs it a taken branch): a raw symbol leaves the coder alone,
-    // which is an advance over the whole range.
+    // The three ways of a symbol - the top entry of a small table, anything else of a small table, the other kinds - each
+    // END with the tail (coder step, header words) written out for it: a top-entry hit cannot change the header's first word
+    // and does not test for it.  All conditions are wave-uniform scalars, nothing below holds a branch on the lane number,
+    // and the build leaves uniform regions unstructurised (build.py), so these are plain scalar branches with the unlikely
+    // ways out of line.
     int c = 0;
     u32 fr, cf;
     const u32 v = x & (kProbScale - 1);
-    int small0 = (int)h0;  // sign bit: a small table (kind 4 or 5)
-    if (SCPR_LIKELY(small0 < 0)) {
+    auto tail = [&](auto first_word_tag) __attribute__((always_inline)) {
+      if constexpr (MODE == 0) advance(cf, fr, v);
+      else pend[0] = cf, pend[1] = fr, pend[2] = v;
+      wave_fence();
+      // the header: the word that changes with every symbol from all lanes alike (same address, same value), the other one when it changes
+      const u32 h1 = (u32)h.total | ((u32)h.fmax << 16);
+      asm volatile("ds_write_b32 %0, %1 offset:4" ::"v"(ra), "v"(h1) : "memory");
+      if constexpr (decltype(first_word_tag)::value) {
+        if (SCPR_UNLIKELY(h.dirty | (h.maxpos ^ maxpos0))) {
+          const u32 n0 = dec_pack0(h);
+          asm volatile("ds_write_b32 %0, %1" ::"v"(ra), "v"(n0) : "memory");
+        }
+      }
+      wave_fence();
+      if constexpr (MODE == 0) count<CHK>();
+    };
+    if (SCPR_LIKELY((int)h0 < 0)) {  // sign bit: a small table (kind 4 or 5)
       h.top = hz;
-      int tt = top_hit<true, true>(h, w, (int)v, c, fr, cf);  // (a hit changes the header only: nothing of the table is stored)
-      asm volatile("" : "+s"(tt));  // (keeps the test inside top_hit and this one apart)
-      if (SCPR_UNLIKELY(tt >= 0)) {  // another entry, an unmet symbol, or a rescale is due
+      int tsh, tap, twd;
+      const int tt = top_test(h, (int)v, tsh, tap, twd);
+      if (SCPR_LIKELY(tt < 0)) {
+        top_apply(h, tsh, tap, twd, c, fr, cf);  // (a hit changes the header only: nothing of the table is stored)
+        event<17>();
+        wave_fence();
+        tail(std::false_type{});  // (kind, maxpos, fshift, d: as they were)
+      } else {  // another entry, an unmet symbol, or a rescale is due
         small_settle(h, w);
-        int t = small_hit(h, w, (int)v, c, fr, cf);
-        asm volatile("" : "+s"(t));
+        const int t = small_hit(h, w, (int)v, c, fr, cf);
         if (SCPR_UNLIKELY(t >= 0)) {
           event<12>();
           c = small_op<true>(r, h, w, (int)v, fr, cf);
@@ -1439,13 +1478,10 @@ struct WaveDec : WaveModel {
         // the entries go back from every row of 16 lanes alike: no lane mask (a full table has just become a dense
         // one: then w holds what is there already)
         asm volatile("ds_write_b32 %0, %1" ::"v"(ea), "v"(w) : "memory");
-      } else {
-        event<17>();
+        wave_fence();
+        tail(std::true_type{});
       }
-      wave_fence();
-    }
-    asm volatile("" : "+s"(small0));  // keeps the two tests apart (merged, they come back as if/else)
-    if (SCPR_UNLIKELY(small0 >= 0)) {
+    } else {
       h.fshift = (int)((h0 >> 16) & 15u);
       h.dense = hz;
 #ifdef SCPR_PROFILE
@@ -1456,7 +1492,7 @@ struct WaveDec : WaveModel {
         prof[23] = ((u64)(oom ? 1u : 0u) << 32) | (u32)ndec;
       }
 #endif
-      if (h.kind < 4) {
+      if (h.kind < 4) {  // a raw symbol leaves the coder alone, which is an advance over the whole range
         event<11>();
         fr = kProbScale, cf = 0;
         c = (int)take_byte();
@@ -1471,27 +1507,14 @@ struct WaveDec : WaveModel {
         scalar_hdr(h);
       } else {
         event<10>();
-        int t = PF ? dense_hit_p(h, w, (int)v, c, fr, cf) : dense_hit(h, w, (int)v, c, fr, cf);
-        asm volatile("" : "+s"(t));
+        const int t = PF ? dense_hit_p(h, w, (int)v, c, fr, cf) : dense_hit(h, w, (int)v, c, fr, cf);
         if (SCPR_UNLIKELY(t >= 0)) {
           c = dense_op<true>(r, h, (int)v, fr, cf);
           scalar_hdr(h);
         }
       }
+      tail(std::true_type{});
     }
-    if constexpr (MODE == 0) advance(cf, fr, v);
-    else pend[0] = cf, pend[1] = fr, pend[2] = v;
-    wave_fence();
-    {  // the header: the word that changes with every symbol from all lanes alike (same address, same value), the other one when it changes
-      const u32 h1 = (u32)h.total | ((u32)h.fmax << 16);
-      asm volatile("ds_write_b32 %0, %1 offset:4" ::"v"(ra), "v"(h1) : "memory");
-      if (SCPR_UNLIKELY(h.dirty | (h.maxpos ^ maxpos0))) {
-        const u32 n0 = dec_pack0(h);
-        asm volatile("ds_write_b32 %0, %1" ::"v"(ra), "v"(n0) : "memory");
-      }
-    }
-    wave_fence();
-    if constexpr (MODE == 0) count<CHK>();
     return c;
   }
 };
