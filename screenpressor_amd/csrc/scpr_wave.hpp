@@ -238,7 +238,9 @@ struct WaveModel {
     wave_fence();
     const u32 slot = idx & dmask;
     const u32 tag = rfl(dtag[slot]);
-    DenseTab* c = (DenseTab*)(dcache + (size_t)slot * sizeof(DenseTab));
+    // (the slot as a bare LDS offset in a pointer's clothes: everything that takes a cached table goes through tab_ld / tab_st<true>,
+    // which use the low 32 bits only - a real generic pointer into LDS drags its aperture and null tests along)
+    DenseTab* c = (DenseTab*)(size_t)(dc_lds + slot * (u32)sizeof(DenseTab));
     if (SCPR_UNLIKELY(tag != idx + 1u)) {
 #ifdef SCPR_PROFILE
       dmiss++;
@@ -260,7 +262,7 @@ struct WaveModel {
     wave_fence();
     for (u32 slot = 0; slot <= dmask; slot++) {
       const u32 tag = rfl(dtag[slot]);
-      if (tag) copy_tab<false>(arena.tabs + (tag - 1u), (const DenseTab*)(dcache + (size_t)slot * sizeof(DenseTab)), lane);
+      if (tag) copy_tab<false>(arena.tabs + (tag - 1u), (const DenseTab*)(size_t)(dc_lds + slot * (u32)sizeof(DenseTab)), lane);
     }
   }
   __device__ __forceinline__ int small_fmax(const ColHdr& h, u32 w) { return (int)sm_fq(rdl(w, h.maxpos)); }
@@ -407,6 +409,12 @@ struct WaveModel {
     return wave_sum(cn[0] + cn[1] + cn[2] + cn[3]);
   }
 
+  // write_dense() on what tab_of() returned: a slot of the LDS cache where there is one (NOT a pointer that can be followed,
+  // see tab_of), the table in the arena otherwise
+  __device__ __forceinline__ int write_table(DenseTab* t, const int fr[4], const int cn[4]) {
+    return dc_lds != 0u ? write_dense<true>(t, fr, cn) : write_dense<false>(t, fr, cn);
+  }
+
   // Context::update for kinds 0-3 (ans_contexts.cpp:3-31, :52-59): c arrived raw.
   // On promotion to a small table (kind 4/5) the packed entries are returned in w.
   __device__ __forceinline__ void note_raw(u32* r, ColHdr& h, int c, u32& w) {
@@ -458,7 +466,7 @@ struct WaveModel {
         fr[q] = met ? fm : wdt;
         cn[q] = met ? fm - (fm >> 1) : 0;
       }
-      const int sum = write_dense(t, fr, cn);
+      const int sum = write_table(t, fr, cn);
       h.kind = 6;
       h.fshift = sh;
       h.total = ((256 - d) << (sh > 0 ? sh - 1 : 0)) + sum;
@@ -471,7 +479,7 @@ struct WaveModel {
         cn[q] = (((bits >> q) & 1u) ? c0 : 1) + (j == c ? kStepDense : 0);
       }
       h.kind = 7;
-      h.total = write_dense(t, fr, cn);
+      h.total = write_table(t, fr, cn);
     }
   }
 
@@ -622,7 +630,7 @@ struct WaveModel {
     wave_fence();
     h.dense = alloc_dense();
     r[2] = h.dense;  // (every lane the same word)  the table index only changes here: the per-symbol header store leaves word 2 alone
-    const int sum = write_dense(tab_of(h.dense, true), fr, cn);
+    const int sum = write_table(tab_of(h.dense, true), fr, cn);
     h.kind = 6;
     h.fshift = s2;
     h.d = d + 1;
@@ -2113,10 +2121,10 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
         if (SCPR_UNLIKELY(D.oom)) D.bad = true;  // the arena is full (alloc_dense): nothing more is decoded, at most a rect late
         if (border_due) {
           wave_fence();
-          if (lane < 33) tile[border_at] = border;
+          lds_st_if(&tile[border_at], border, lane < 33);
 #pragma unroll
           for (int k = 0; k < 4; k++)
-            if (prow < h && pcol + k < w) ptile[prow * w + pcol + k] = pv[k];
+            lds_st_if(&ptile[prow * w + pcol + k], pv[k], prow < h && pcol + k < w);
           wave_fence();
           border_due = false;
         }
@@ -2194,7 +2202,7 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
               } else if (pt == 3) {
                 v = ptile[li];
               }
-              if (act) tile[(row + 1) * 17 + col + 1] = v;
+              lds_st_if(&tile[(row + 1) * 17 + col + 1], v, act);
             }
             wave_fence();
             lastpix = rdl(v, (rem - 1) & 63) & 0xFFFFFFu;
@@ -2224,24 +2232,23 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
           }
           if (SCPR_UNLIKELY((0x18u >> pt) & 1u)) {
             if (pt == 3) {
-              v = px;
-              if (act) v = ptile[li + lane];
-            } else {
-              u32 tp = 0, tl = 0;
-              if (act) {
-                tp = tile[(ty - 1) * 17 + tx];
-                tl = tile[(ty - 1) * 17 + tx - 1];
+              {  // (read by every lane - the lanes past the segment read the segment's first pixel -, chosen afterwards)
+                const u32 pvv = ptile[li + (act ? lane : 0)];
+                v = act ? pvv : px;
               }
+            } else {
+              // (read by every lane, inside the tile's row through lc; the lanes past the segment count as 0 below)
+              const u32 tp = tile[(ty - 1) * 17 + tx0 + lc], tl = tile[(ty - 1) * 17 + tx0 + lc - 1];
               const u32 base = tile[ty * 17 + tx0 - 1];
               int d0 = (int)(tp & 255) - (int)(tl & 255), d1 = (int)((tp >> 8) & 255) - (int)((tl >> 8) & 255), d2 = (int)((tp >> 16) & 255) - (int)((tl >> 16) & 255);
-              if (!act) d0 = d1 = d2 = 0;
+              d0 = act ? d0 : 0, d1 = act ? d1 : 0, d2 = act ? d2 : 0;
               d0 = row_incl_scan(d0);
               d1 = row_incl_scan(d1);
               d2 = row_incl_scan(d2);
               v = (u32)(((int)(base & 255) + d0) & 255) | ((u32)(((int)((base >> 8) & 255) + d1) & 255) << 8) | ((u32)(((int)((base >> 16) & 255) + d2) & 255) << 16);
             }
           }
-          if (act) tile[ty * 17 + tx] = v;
+          lds_st_if(&tile[ty * 17 + tx], v, act);
           wave_fence();
           lastpix = rdl(v, seg - 1) & 0xFFFFFFu;
           rem -= seg;
