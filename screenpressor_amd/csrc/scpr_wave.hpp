@@ -293,7 +293,7 @@ struct WaveModel {
   // They change only when a symbol takes another path, and every such path ends with this refresh.
   __device__ __forceinline__ u32 small_top(const ColHdr& h, u32 w) {
     const u32 wt = rdl(w, h.maxpos);
-    return sm_sym(wt) | (sm_p(wt) << 8);
+    return sm_sym(wt) | ((sm_p(wt) + sm_sym(wt) - (u32)h.maxpos) << 8);  // symbol | start of its interval in counts (below the total: 12 bits)
   }
   // the table brought up to date with the top-entry hits that top_hit<DEC, true> only counted in the header
   __device__ __forceinline__ void small_settle(const ColHdr& h, u32& w) {
@@ -314,7 +314,7 @@ struct WaveModel {
     const int tot = h.total, mp = h.maxpos;
     const int sh = __builtin_clz((u32)(tot - 1)) - 20, bonus = (kProbScale >> sh) - tot;  // == (kProbScale - (tot << sh)) >> sh
     const int ts = (int)(h.top & 255u);
-    const int ap = ts + (int)((h.top >> 8) & 0xFFFu) - mp, width = h.fmax + bonus;
+    const int ap = (int)((h.top >> 8) & 0xFFFu), width = h.fmax + bonus;
     const int norescale = tot + 2 * kStepSmall - kProbScale - 1;  // negative: no rescale after this symbol
     int t;
     if (DEC) {
@@ -333,22 +333,20 @@ struct WaveModel {
     }
     return t;
   }
-  // top_hit<true, true> in two halves for a caller that branches on the test itself (the decoder's colour()): the test, with
-  // nothing touched, and what a hit does
-  __device__ __forceinline__ int top_test(const ColHdr& h, int in, int& sh, int& ap, int& width) const {
-    const int tot = h.total;
-    sh = __builtin_clz((u32)(tot - 1)) - 20;
-    const int bonus = (kProbScale >> sh) - tot;
-    ap = (int)(h.top & 255u) + (int)((h.top >> 8) & 0xFFFu) - h.maxpos, width = h.fmax + bonus;
-    const int vv = in >> sh;
-    return (vv - ap - width) & (ap - vv - 1) & (tot + 2 * kStepSmall - kProbScale - 1);  // each negative when fine
-  }
-  __device__ __forceinline__ void top_apply(ColHdr& h, int sh, int ap, int width, int& c, u32& ofr, u32& ocf) const {
+  // top_hit<true, true> for a caller that branches on the test itself (the decoder's colour()): from the record's words as they
+  // are read (h1 = total | count of the top entry << 16, top = small_top() | ...), nothing touched.  The interval comes first
+  // (ocf = start << sh, ofr = width << sh: what the coder step wants anyway) and the test is on d = v - ocf, which is the
+  // coder step's own `v - cf`: inside iff 0 <= d < ofr (the same as start <= v >> sh < start + width: both ends are
+  // multiples of 1 << sh).  Negative: a hit, and no rescale is due after it.
+  static __device__ __forceinline__ int top_test(u32 h1, u32 top, int v, u32& ofr, u32& ocf, u32& od) {
+    const int tot = (int)(h1 & 0xFFFFu);
+    const int sh = __builtin_clz((u32)(tot - 1)) - 20;
+    const int width = (int)(h1 >> 16) + (kProbScale >> sh) - tot;
+    ocf = ((top >> 8) & 0xFFFu) << sh;
     ofr = (u32)width << sh;
-    ocf = (u32)ap << sh;
-    h.total += kStepSmall;
-    h.fmax += kStepSmall;
-    c = (int)(h.top & 255u);
+    const int d = v - (int)ocf;
+    od = (u32)d;
+    return (d - (int)ofr) & ~d & (tot + 2 * kStepSmall - kProbScale - 1);  // each negative when fine
   }
   static __device__ __forceinline__ u32 pack0(const ColHdr& h) { return (u32)h.kind | ((u32)h.maxpos << 8) | ((u32)h.fshift << 16); }
   static __device__ __forceinline__ u32 pack1(const ColHdr& h) { return (u32)h.d | ((u32)h.total << 16); }
@@ -804,12 +802,19 @@ struct WaveDec : WaveModel {
   // block type): the widest symbol of each as start | (width - 1) << 12 and its number, and the table's running total.  Motion
   // vectors repeat from block to block: the widest symbol takes almost every lookup, with one compare and nothing read.
   u32 qtopA = 0, qtopB = 0, qtot = 0;
+  u32 crec_ea = 0;  // LDS offset of the record cache + 4 * (lane & 15): a slot's `ea` is this + 80 * slot
+  // what a hit on a small table's top entry adds to the record's second word (total | top count << 16), in lane 0; nothing elsewhere
+  u32 ktop = 0;
   // models
   DecRec* gstates;
   bool bad = false;
   bool has_p = true;  // false: the workgroup's LDS ends before the P-frame tables (WaveLds::fp on)
 
-  __device__ __forceinline__ WaveDec(WaveLds& l, const u8* s, const u8* e, DecRec* gs, Arena a, int f0_) : WaveModel(l.tmp, a, f0_), L(l), src(s), src_end(e), gstates(gs) {}
+  __device__ __forceinline__ WaveDec(WaveLds& l, const u8* s, const u8* e, DecRec* gs, Arena a, int f0_) : WaveModel(l.tmp, a, f0_), L(l), src(s), src_end(e), gstates(gs) {
+    ktop = lane_id() == 0 ? (u32)kStepSmall * 0x10001u : 0u;
+    crec_ea = (u32)(size_t)&l.crec[0][0] + 4u * (u32)(lane_id() & 15);
+    asm volatile("" : "+v"(ktop), "+v"(crec_ea));  // (kept in registers: not made afresh for every symbol)
+  }
 
   // ---------------------------------------------------------------- input ---
   // The packet is read 256 bytes at a time: one load gives every lane one 4-byte word of the block and the
@@ -1091,7 +1096,7 @@ struct WaveDec : WaveModel {
       const u32 dc = lane == sym ? (u32)kStepDense : 0u, dt = lane == 0 ? (u32)kStepDense : 0u;
       asm volatile("ds_add_u32 %0, %1 offset:%3\n\tds_add_u32 %0, %2 offset:1024" ::"v"(addr), "v"(dc), "v"(dt), "n"(4 * NTAB_CNT) : "memory");
     }
-    if constexpr (DOUT) pend[0] = s >> 16, pend[1] = s & 0xFFFF, pend[2] = v;
+    if constexpr (DOUT) pend[0] = 0u, pend[1] = s & 0xFFFF, pend[2] = v - (s >> 16);  // (handed on as the difference: every producer the same shape)
     else advance(s >> 16, s & 0xFFFF, v);
     if (SCPR_UNLIKELY(tot0 + 2 * kStepDense > kProbScale)) {  // rebuild from the counts, ans_contexts.h:1075-1090
       wave_fence();
@@ -1126,7 +1131,7 @@ struct WaveDec : WaveModel {
     const u32 s = rdl(pfc, own);
     const int tot = (int)rdl(pcnt, tl) + kStepDense;
     pcnt += (lane == own || lane == tl) ? (u32)kStepDense : 0u;
-    if constexpr (DEFER) pend[0] = s >> 16, pend[1] = s & 0xFFFF, pend[2] = v;
+    if constexpr (DEFER) pend[0] = 0u, pend[1] = s & 0xFFFF, pend[2] = v - (s >> 16);
     else advance(s >> 16, s & 0xFFFF, v);
     if (SCPR_UNLIKELY(tot + kStepDense > kProbScale)) {
       const bool in = (lane >> 3) == t && (lane & 7) < 6;
@@ -1280,31 +1285,35 @@ struct WaveDec : WaveModel {
   // PIPE: the coder step of the symbol before (pcf, pfr, pv: advance + count) runs between asking for the record and using
   // it - the step needs nothing of the record and the record nothing of the step, and the LDS round trip (68+ cycles in which a
   // lone wave issues nothing) is as long as the step (colour<CHK, MODE>).
+  static __device__ __forceinline__ int slot_of(int ctxid) { return (ctxid ^ (ctxid >> 7)) & (CACHE_N - 1); }
+  // Two address registers: `ea` = the slot + 4 * (lane & 15) - this lane's table entry is at ea + 16, and lane 0's ea is the
+  // record itself, which is where colour()'s ds_add goes - and the slot's own address in every lane for the header's four
+  // words (ONE address for all lanes: a 16-byte read per lane at 4-byte steps is 132 cycles instead of 73, tools/lds_bench.hip).
   template <bool CHK, bool PIPE>
-  __device__ __forceinline__ u32* record(int ctxid, ColHdr& h, u32& w, u32& ra, u32& ea, u32& h0, u32& hz, u32 pcf = 0, u32 pfr = 0, u32 pv = 0) {
+  __device__ __forceinline__ void record(int ctxid, u32& w, u32& ea, u32& h0, u32& h1, u32& hz, u32 pcf = 0, u32 pfr = 0, u32 pv = 0) {
     wave_fence();
-    const int slot = (ctxid ^ (ctxid >> 7)) & (CACHE_N - 1);
-    u32* r = L.crec[slot];
-    ra = (u32)(size_t)r;
-    ea = ra + 16u + 4u * (u32)l15;
     u32x4 hw;
+    const u32 sa = (u32)(4 * DECREC_WORDS) * (u32)slot_of(ctxid);
+    const u32 ha = (u32)(size_t)&L.crec[0][0] + sa;
+    ea = crec_ea + sa;
     if constexpr (PIPE) {
-      asm volatile("ds_read_b128 %0, %2\n\tds_read_b32 %1, %3" : "=v"(hw), "=v"(w) : "v"(ra), "v"(ea) : "memory");
+      asm volatile("ds_read_b128 %0, %3\n\tds_read_b32 %1, %2 offset:16" : "=v"(hw), "=v"(w) : "v"(ea), "v"(ha) : "memory");
       advance(pcf, pfr, pv);
       count<CHK>();
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(hw), "+v"(w) : : "memory");  // (ties what was read to the wait: nothing that uses it moves above)
     } else {
-      asm volatile("ds_read_b128 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=v"(hw), "=v"(w) : "v"(ra), "v"(ea) : "memory");
+      asm volatile("ds_read_b128 %0, %3\n\tds_read_b32 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)" : "=v"(hw), "=v"(w) : "v"(ea), "v"(ha) : "memory");
     }
     // all four words go to the scalar unit BEFORE the tag is tested (the empty asm wants them): a lane read takes ~30 cycles to
     // reach a scalar consumer, and behind the test the header's reads would start that wait a second time
     const u32 tag = rfl(hw.w);  // the context the slot holds (kNoCtx: none)
     h0 = rfl(hw.x);
-    u32 h1 = rfl(hw.y);
+    h1 = rfl(hw.y);
     u32 h2 = rfl(hw.z);
     asm volatile("" : "+s"(h0), "+s"(h1), "+s"(h2));
     if (SCPR_UNLIKELY(tag != (u32)ctxid)) {
       event<9>();
+      u32* r = L.crec[slot_of(ctxid)];
       {  // (the record's words by its first lanes, without a branch on the lane: masked stores, a load every lane can make)
         const int wl = min(lane, DECREC_WORDS - 1);
         const bool in = lane < DECREC_WORDS;
@@ -1313,21 +1322,23 @@ struct WaveDec : WaveModel {
         lds_st_if(&r[wl], lane == 3 ? (u32)ctxid : nw, in);
       }
       wave_fence();
-      asm volatile("ds_read_b128 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=v"(hw), "=v"(w) : "v"(ra), "v"(ea) : "memory");
+      asm volatile("ds_read_b128 %0, %3\n\tds_read_b32 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)" : "=v"(hw), "=v"(w) : "v"(ea), "v"(ha) : "memory");
       h0 = rfl(hw.x);
       h1 = rfl(hw.y);
       h2 = rfl(hw.z);
     }
+    hz = h2;  // (wave-uniform already)
+  }
+  // the header's fields from the record's first two words (fshift and the dense index: colour() fills them in for the kinds that have them)
+  static __device__ __forceinline__ void hdr_of(ColHdr& h, u32 h0, u32 h1) {
     h.kind = h0 & 255;
     h.maxpos = (h0 >> 8) & 255;
-    h.fshift = 0;  // a small table has none; colour() fills in this and the dense index for the other kinds
+    h.fshift = 0;
     h.d = (h0 >> 20) & 0x7FF;
     h.total = h1 & 0xFFFF;
     h.fmax = h1 >> 16;
     h.dirty = 0;
     h.dense = 0;
-    hz = h2;  // (wave-uniform already)
-    return r;
   }
   static __device__ __forceinline__ u32 dec_pack0(const ColHdr& h) {
     return (u32)h.kind | ((u32)h.maxpos << 8) | ((u32)h.fshift << 16) | ((u32)h.d << 20) | ((h.kind | 1) == 5 ? 0x80000000u : 0u);
@@ -1434,44 +1445,64 @@ struct WaveDec : WaveModel {
   template <bool CHK = true, int MODE = 0, bool PF = false>
   __device__ __forceinline__ int colour(int ctxid, u32* pend = nullptr) {
     ColHdr h;
-    u32 w, ra, ea, h0, hz;
-    u32* r = MODE == 2 ? record<CHK, true>(ctxid, h, w, ra, ea, h0, hz, pend[0], pend[1], pend[2]) : record<CHK, false>(ctxid, h, w, ra, ea, h0, hz);
+    u32 w, ra = 0, ea, h0, h1, hz;
+    u32* r = nullptr;
+    if constexpr (MODE == 2) record<CHK, true>(ctxid, w, ea, h0, h1, hz, pend[0], pend[1], pend[2]);
+    else record<CHK, false>(ctxid, w, ea, h0, h1, hz);
     event<8>();
-    const int maxpos0 = h.maxpos;
     // The three ways of a symbol - the top entry of a small table, anything else of a small table, the other kinds - each
-    // END with the tail (coder step, header words) written out for it: a top-entry hit cannot change the header's first word
-    // and does not test for it.  All conditions are wave-uniform scalars, nothing below holds a branch on the lane number,
-    // and the build leaves uniform regions unstructurised (build.py), so these are plain scalar branches with the unlikely
-    // ways out of line.
+    // END with the tail (coder step, header words) written out for it.  All conditions are wave-uniform scalars, nothing below
+    // holds a branch on the lane number, and the build leaves uniform regions unstructurised (build.py), so these are plain
+    // scalar branches with the unlikely ways out of line.
     int c = 0;
     u32 fr, cf;
     const u32 v = x & (kProbScale - 1);
-    auto tail = [&](auto first_word_tag) __attribute__((always_inline)) {
+    int maxpos0 = 0;
+    // the header's fields, for the two ways that want them: from copies of the words the optimiser cannot see through, or it
+    // computes every field in front of the first branch, on the top-entry hit's path too
+    auto header = [&]() __attribute__((always_inline)) {
+      u32 q0 = h0, q1 = h1;
+      int qc = ctxid;
+      asm volatile("" : "+s"(q0), "+s"(q1), "+s"(qc));
+      hdr_of(h, q0, q1);
+      maxpos0 = h.maxpos;
+      r = L.crec[slot_of(qc)];  // (the record's address as a pointer and as an LDS offset: only these ways want them)
+      ra = (u32)(size_t)r;
+    };
+    auto tail = [&]() __attribute__((always_inline)) {
       if constexpr (MODE == 0) advance(cf, fr, v);
-      else pend[0] = cf, pend[1] = fr, pend[2] = v;
+      else pend[0] = 0u, pend[1] = fr, pend[2] = v - cf;
       wave_fence();
       // the header: the word that changes with every symbol from all lanes alike (same address, same value), the other one when it changes
-      const u32 h1 = (u32)h.total | ((u32)h.fmax << 16);
-      asm volatile("ds_write_b32 %0, %1 offset:4" ::"v"(ra), "v"(h1) : "memory");
-      if constexpr (decltype(first_word_tag)::value) {
-        if (SCPR_UNLIKELY(h.dirty | (h.maxpos ^ maxpos0))) {
-          const u32 n0 = dec_pack0(h);
-          asm volatile("ds_write_b32 %0, %1" ::"v"(ra), "v"(n0) : "memory");
-        }
+      const u32 n1 = (u32)h.total | ((u32)h.fmax << 16);
+      asm volatile("ds_write_b32 %0, %1 offset:4" ::"v"(ra), "v"(n1) : "memory");
+      if (SCPR_UNLIKELY(h.dirty | (h.maxpos ^ maxpos0))) {
+        const u32 n0 = dec_pack0(h);
+        asm volatile("ds_write_b32 %0, %1" ::"v"(ra), "v"(n0) : "memory");
       }
       wave_fence();
       if constexpr (MODE == 0) count<CHK>();
     };
     if (SCPR_LIKELY((int)h0 < 0)) {  // sign bit: a small table (kind 4 or 5)
-      h.top = hz;
-      int tsh, tap, twd;
-      const int tt = top_test(h, (int)v, tsh, tap, twd);
+      u32 dd;
+      const int tt = top_test(h1, hz, (int)v, fr, cf, dd);
       if (SCPR_LIKELY(tt < 0)) {
-        top_apply(h, tsh, tap, twd, c, fr, cf);  // (a hit changes the header only: nothing of the table is stored)
+        // A hit on the top entry changes two numbers, both in the header's second word: the total and the top entry's count
+        // go up by the same step (the table itself hears of it later: small_settle).  One LDS add, nothing unpacked, nothing
+        // packed: lane 0's address is the record (its ea), the other lanes add nothing to words further on.
+        c = (int)(hz & 255u);
         event<17>();
+        if constexpr (MODE == 0) advance(0u, fr, dd);  // (dd = v - cf: the test has it already)
+        else pend[0] = 0u, pend[1] = fr, pend[2] = dd;
         wave_fence();
-        tail(std::false_type{});  // (kind, maxpos, fshift, d: as they were)
+        // (an add by all lanes, four to a word, in front of the next read costs 5 cycles more than a plain write - and
+        // 9 less than switching exec for lane 0 alone, tools/lds_bench.hip)
+asm volatile("ds_add_u32 %0, %1 offset:4" ::"v"(ea), "v"(ktop) : "memory");
+        wave_fence();
+        if constexpr (MODE == 0) count<CHK>();
       } else {  // another entry, an unmet symbol, or a rescale is due
+        header();
+        h.top = hz;
         small_settle(h, w);
         const int t = small_hit(h, w, (int)v, c, fr, cf);
         if (SCPR_UNLIKELY(t >= 0)) {
@@ -1485,11 +1516,12 @@ struct WaveDec : WaveModel {
         wave_fence();
         // the entries go back from every row of 16 lanes alike: no lane mask (a full table has just become a dense
         // one: then w holds what is there already)
-        asm volatile("ds_write_b32 %0, %1" ::"v"(ea), "v"(w) : "memory");
+        asm volatile("ds_write_b32 %0, %1 offset:16" ::"v"(ea), "v"(w) : "memory");
         wave_fence();
-        tail(std::true_type{});
+        tail();
       }
     } else {
+      header();
       h.fshift = (int)((h0 >> 16) & 15u);
       h.dense = hz;
 #ifdef SCPR_PROFILE
@@ -1521,7 +1553,7 @@ struct WaveDec : WaveModel {
           scalar_hdr(h);
         }
       }
-      tail(std::true_type{});
+      tail();
     }
     return c;
   }

@@ -10,7 +10,7 @@ sys.path.insert(0, ROOT)
 LIB = os.path.join(ROOT, "screenpressor_amd", "libscpr_amd_prof.so")
 src = os.path.join(ROOT, "screenpressor_amd", "csrc", "scpr_amd.hip")
 if "--build" in sys.argv or not os.path.exists(LIB):
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-strict-aliasing", "-fPIC", "-shared", "-DSCPR_PROFILE", "-mllvm", "-align-all-nofallthru-blocks=6", "-mllvm", "-enable-post-misched=false",
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-strict-aliasing", "-fPIC", "-shared", "-DSCPR_PROFILE", "-mllvm", "-align-all-nofallthru-blocks=6", "-mllvm", "-enable-post-misched=false", "-mllvm", "-structurizecfg-skip-uniform-regions=true",
                            "-Wno-unused-result", "-o", LIB, src])
     if "--build" in sys.argv:
         sys.exit(0)
