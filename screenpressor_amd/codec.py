@@ -179,7 +179,9 @@ class ScreenCodec:
         return r, out
 
     # batch entry points: torch uint8 CUDA tensors in, out
-    def CompressBatch(self, frames, ftypes, loss: int | None = None, out=None):
+    def CompressBatch(self, frames, ftypes, loss: int | None = None, out=None, sync: bool = True):
+        """sync=False: the caller vouches that `frames` is complete (the C side works on the codec's own stream and waits for
+        nothing else); the default waits for the whole device, which also waits for another codec's call in another thread"""
         import torch
         n = frames.shape[0]
         assert frames.is_cuda and frames.dtype == torch.uint8 and frames.is_contiguous() and frames.numel() == n * self.frame_bytes
@@ -195,13 +197,14 @@ class ScreenCodec:
             out = self._out
         ft = (C.c_int * n)(*[int(x) for x in ftypes])
         sizes = (C.c_uint32 * n)()
-        torch.cuda.synchronize(frames.device)
+        if sync:
+            torch.cuda.synchronize(frames.device)
         total = self._check(self._L.scpr_compress_batch(self._h, C.c_void_p(frames.data_ptr()), n, ft, self.loss if loss is None else loss,
                                                         C.c_void_p(out.data_ptr()), out.numel(), sizes))
         # (from the object's own buffer the packets are copied out - they are ~1 % of it - so that the next call cannot change them)
         return (out[:total].clone() if own else out[:total]), np.frombuffer(sizes, dtype=np.uint32).copy(), list(ft)
 
-    def DecompressBatch(self, packets, sizes, ftypes, pitch: int | None = None, out=None):
+    def DecompressBatch(self, packets, sizes, ftypes, pitch: int | None = None, out=None, sync: bool = True):
         import torch
         n = len(sizes)
         pitch = self.pitch if pitch is None else pitch
@@ -211,7 +214,8 @@ class ScreenCodec:
             out = torch.empty(n * pitch * self.height, dtype=torch.uint8, device=packets.device)
         sz = (C.c_uint32 * n)(*[int(x) for x in sizes])
         ft = (C.c_int * n)(*[int(x) for x in ftypes])
-        torch.cuda.synchronize(packets.device)
+        if sync:  # (see CompressBatch)
+            torch.cuda.synchronize(packets.device)
         r = self._check(self._L.scpr_decompress_batch(self._h, C.c_void_p(packets.data_ptr()), sz, ft, n, C.c_void_p(out.data_ptr()), pitch))
         return r, out
 

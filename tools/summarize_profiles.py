@@ -62,7 +62,7 @@ summ = os.path.join(src, "dec", "summary.json")
 if os.path.exists(summ):
     d = json.load(open(summ))
     d["note"] = ("SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* count in units of 4 cycles; ACTIVE_INST_ANY == INSTS: every instruction is 'active' for one unit, "
-                 "WAIT_ANY is everything else of the wave's life - for this lone wave mostly the second half of the ~8-cycle issue-to-issue time of DEPENDENT instructions "
-                 "(tools/lonewave_bench.hip), not memory: see DESIGN.md")
+                 "WAIT_ANY is everything else of the wave's life - for this lone wave the fifth cycle of every instruction (tools/fetch_bench.hip: 5.0 cycles per "
+                 "instruction, dependent or not), LDS round trips, values crossing between the vector and the scalar unit, branches: see DESIGN.md 3")
     json.dump(d, open(os.path.join(dst, f"{tag}_pmc_decoder.json"), "w"), indent=1)
 print("written", sorted(f for f in os.listdir(dst) if f.startswith(tag)))
