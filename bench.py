@@ -253,7 +253,7 @@ class Runner:
         return out, sizes, ft, dec, t1 - t0, t2 - t1b, {k: v for k, v in list(se.items()) + list(sd.items()) if v > 0}
 
 
-def overlapped_steps(runner, frames, ftypes, steps):
+def overlapped_steps(runner, frames, ftypes, steps, cus=None, local_rank=0):
     """`steps` passes of the hot path back to back with the encoder of pass i + 1 running beside the decoder of pass i (two
     host threads - the C ABI's calls return when their work is done -, the codecs' own HIP streams, two packet buffers).  The
     decoder's chains are one wave per GOP and leave most of the card idle; a caller with a queue of batches would run it this
@@ -262,24 +262,29 @@ def overlapped_steps(runner, frames, ftypes, steps):
     import threading
     torch = runner.torch
     W, H, BPP = runner.w, runner.h, runner.bpp
+    enc, dec = runner.enc, runner.dec
+    if cus is not None:  # (encoder CUs, decoder CUs): a codec pair of its own, each confined to its share of the card (scpr_set_cu_mask)
+        from screenpressor_amd.codec import ScreenCodec
+        enc = ScreenCodec(local_rank).Init(W, H, BPP).SetCuMask(cus[0])
+        dec = ScreenCodec(local_rank).Init(W, H, BPP).SetCuMask(cus[1])
     bufs = [runner.packets, torch.empty_like(runner.packets)]
     decs = [runner.decoded, torch.empty_like(runner.decoded)]
     errs, ok, last = [], [], [None]
 
     def decode(i, out, sizes, ft):
         try:
-            runner.dec.Deinit(); runner.dec.Init(W, H, BPP)
-            r, dec = runner.dec.DecompressBatch(out, sizes, ft, out=decs[i & 1], sync=False)  # (the packets are complete: the encoder's call has returned)
+            dec.Deinit(); dec.Init(W, H, BPP)
+            r, got = dec.DecompressBatch(out, sizes, ft, out=decs[i & 1], sync=False)  # (the packets are complete: the encoder's call has returned)
             ok.append(r == len(ftypes))
-            last[0] = dec
+            last[0] = got
         except Exception as e:  # noqa: BLE001
             errs.append(repr(e))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     th = None
     for i in range(steps):
-        runner.enc.Deinit(); runner.enc.Init(W, H, BPP)
-        out, sizes, ft = runner.enc.CompressBatch(frames, ftypes, out=bufs[i & 1], sync=False)  # (no device-wide wait: the decoder of the pass before is running)
+        enc.Deinit(); enc.Init(W, H, BPP)
+        out, sizes, ft = enc.CompressBatch(frames, ftypes, out=bufs[i & 1], sync=False)  # (no device-wide wait: the decoder of the pass before is running)
         if th is not None:
             th.join()  # (the decoder is one codec: pass i waits for pass i - 1; buffer i & 1 is free again after pass i - 2)
         th = threading.Thread(target=decode, args=(i, out, sizes, ft))
@@ -776,7 +781,17 @@ def run_rank(args):
                 try:  # (extra to the contract's sequential step: what a queue of batches gets out of the card)
                     k = max(3, min(args.steps, 8))
                     per = overlapped_steps(runner, frames, wl.ftypes, k)
-                    config["overlapped_steps"] = {"ms_per_step": round(per * 1e3, 3), "value": round(N * W * H / 1e6 / per, 2), "unit": "MPix/s", "steps": k,
+                    ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+                    split = {}
+                    for name, e_cus in (("encoder_on_the_last_3_of_8", [q for q in range(ncu) if q % 8 >= 5]), ("encoder_on_the_last_quarter", list(range(ncu * 3 // 4, ncu)))):
+                        d_cus = sorted(set(range(ncu)) - set(e_cus))
+                        try:
+                            overlapped_steps(runner, frames, wl.ftypes, 2, (e_cus, d_cus), local_rank)  # (warm-up: the pair's buffers)
+                            pm = overlapped_steps(runner, frames, wl.ftypes, k, (e_cus, d_cus), local_rank)
+                            split[name] = {"ms_per_step": round(pm * 1e3, 3), "value": round(N * W * H / 1e6 / pm, 2), "encoder_cus": len(e_cus), "decoder_cus": len(d_cus)}
+                        except Exception as e:  # noqa: BLE001
+                            split[name] = f"not measured: {e}"
+                    config["overlapped_steps"] = {"ms_per_step": round(per * 1e3, 3), "value": round(N * W * H / 1e6 / per, 2), "unit": "MPix/s", "steps": k, "with_disjoint_cu_masks": split,
                                                   "note": "NOT the headline: the encoder of pass i+1 beside the decoder of pass i (two host threads, the codecs' own streams, fresh codecs "
                                                           "per pass, the last pass compared with its input); `value` above is the sequential step"}
                 except Exception as e:  # noqa: BLE001

@@ -125,6 +125,16 @@ int scpr_import_mv_memory(scpr_codec* c, const int32_t* mx, const int32_t* my);
 int scpr_motion_prepass(scpr_codec* c, const void* d_frames, int nframes, const int* ftypes, int loss,
                         int32_t* mx, int32_t* my);
 
+/* ---- placement (addition) -------------------------------------------------- */
+/* Confines the codec's kernels to the compute units whose bits are set in
+ * `mask` (`words` 32-bit words, bit i = compute unit i as the HIP runtime
+ * numbers them; hipExtStreamCreateWithCUMask).  The codec's streams are made
+ * again; call it between calls, not during one.  words = 0 lifts the limit.
+ * For running two codecs side by side on one card - a decoder's chains (one
+ * wave per GOP) beside another codec's encoder - without either taking the
+ * other's LDS and issue slots.  Returns 0 or < 0. */
+int scpr_set_cu_mask(scpr_codec* c, const uint32_t* mask, int words);
+
 /* ---- instrumentation ------------------------------------------------------ */
 /* Kernel time of the last batch call, measured with HIP events on the codec's
  * own stream: total milliseconds and, per stage, milliseconds in `stage_ms`

@@ -735,6 +735,35 @@ void scpr_destroy(scpr_codec* c) {
   delete c;
 }
 
+int scpr_set_cu_mask(scpr_codec* c, const uint32_t* mask, int words) {
+  if (!c || words < 0 || (words > 0 && !mask)) return SCPR_E_PARAM;
+  if (hipSetDevice(c->device) != hipSuccess) return SCPR_E_DEVICE;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream2));
+  hipStream_t a = nullptr, b = nullptr;
+  if (words > 0) {
+    u32 any = 0;
+    for (int i = 0; i < words; i++) any |= mask[i];
+    if (!any) return SCPR_E_PARAM;
+    if (hipExtStreamCreateWithCUMask(&a, (uint32_t)words, mask) != hipSuccess) return SCPR_E_DEVICE;
+    if (hipExtStreamCreateWithCUMask(&b, (uint32_t)words, mask) != hipSuccess) {
+      (void)hipStreamDestroy(a);
+      return SCPR_E_DEVICE;
+    }
+  } else {
+    if (hipStreamCreateWithFlags(&a, hipStreamNonBlocking) != hipSuccess) return SCPR_E_DEVICE;
+    if (hipStreamCreateWithFlags(&b, hipStreamNonBlocking) != hipSuccess) {
+      (void)hipStreamDestroy(a);
+      return SCPR_E_DEVICE;
+    }
+  }
+  (void)hipStreamDestroy(c->stream);
+  (void)hipStreamDestroy(c->stream2);
+  c->stream = a;
+  c->stream2 = b;
+  return SCPR_OK;
+}
+
 void scpr_crash_happened(scpr_codec* c) {
   if (c) c->crashed = true;
 }
