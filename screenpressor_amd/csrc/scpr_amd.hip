@@ -135,6 +135,21 @@ struct scpr_codec {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   std::vector<GenRange> h_ranges;      // host images of the per-generation ranges (uploaded asynchronously: they must outlive the call)
   std::vector<MiscRange> h_miscranges;
+  // Pinned staging for the small host <-> device copies of the batch calls (frame lists, totals, sizes, error words).  A copy
+  // between the device and PAGEABLE host memory is carried out inside the runtime, under its own locks and waits: measured with
+  // two codecs in two host threads, one codec's 8-byte read-back did not return until the OTHER codec's 118 ms kernel had finished
+  // (rocprofv3 --hip-trace).  Through pinned memory a copy is a DMA on the codec's own stream and a wait is a
+  // wait for that stream.  h2d(): the source is copied here first (it may die right after the call).  d2h(): lands here, and
+  // sync_out() hands it to where it was meant to go after the stream has been waited for.  A request the pool cannot hold
+  // falls back to the direct copy.
+  u8* pin = nullptr;
+  size_t pin_cap = 0, pin_used = 0;
+  struct PendingOut {
+    void* dst;
+    const void* src;
+    size_t bytes;
+  };
+  std::vector<PendingOut> pin_out;
   // timing
   hipEvent_t ev[ST_COUNT + 1][2];
   bool ev_used[ST_COUNT];
@@ -170,6 +185,54 @@ static void timing_collect(scpr_codec* c) {
     }
 }
 
+static void* pin_take(scpr_codec* c, size_t bytes) {
+  if (!c->pin) {
+    static const size_t cap = getenv("SCPR_PIN_BYTES") ? (size_t)strtoull(getenv("SCPR_PIN_BYTES"), nullptr, 0) : (size_t)8 << 20;
+    if (cap == 0 || hipHostMalloc((void**)&c->pin, cap, hipHostMallocDefault) != hipSuccess) {
+      c->pin = nullptr;
+      return nullptr;
+    }
+    c->pin_cap = cap;
+  }
+  const size_t at = (c->pin_used + 63) & ~(size_t)63;
+  if (at + bytes > c->pin_cap) return nullptr;
+  c->pin_used = at + bytes;
+  return c->pin + at;
+}
+static hipError_t h2d(scpr_codec* c, void* dst, const void* src, size_t bytes, hipStream_t st) {
+  if (bytes == 0) return hipSuccess;
+  void* q = st == c->stream ? pin_take(c, bytes) : nullptr;
+  if (!q) return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
+  memcpy(q, src, bytes);
+  return hipMemcpyAsync(dst, q, bytes, hipMemcpyHostToDevice, st);
+}
+static hipError_t d2h(scpr_codec* c, void* dst, const void* src, size_t bytes, hipStream_t st) {
+  if (bytes == 0) return hipSuccess;
+  void* q = st == c->stream ? pin_take(c, bytes) : nullptr;
+  if (!q) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st);
+  c->pin_out.push_back({dst, q, bytes});
+  return hipMemcpyAsync(q, src, bytes, hipMemcpyDeviceToHost, st);
+}
+// waits for the stream; what d2h() has fetched goes to its destinations, and the pool is free again (every copy queued on the
+// codec's stream has been carried out)
+static hipError_t sync_out(scpr_codec* c, hipStream_t st) {
+  hipError_t e = hipStreamSynchronize(st);
+  if (st == c->stream) {
+    if (e == hipSuccess)
+      for (const auto& o : c->pin_out) memcpy(o.dst, o.src, o.bytes);
+    c->pin_out.clear();
+    c->pin_used = 0;
+  }
+  return e;
+}
+
+// at the start of an entry point: whatever a call that ended in an error left pending is dropped (its destinations are gone)
+static void pin_reset(scpr_codec* c) {
+  if (!c->pin_out.empty() || c->pin_used) (void)hipStreamSynchronize(c->stream);
+  c->pin_out.clear();
+  c->pin_used = 0;
+}
+
 static void setup_loss(scpr_codec* c, int loss) {  // SetupLossMask, screencap.cpp:127-139
   u32 mask = 0;
   for (int i = 0; i < loss; i++) mask = (mask << 1) | 1;
@@ -194,7 +257,7 @@ static int ensure_planes(scpr_codec* c, size_t n) {
   HIPCHK(hipMemsetAsync(np, 0, (want + 1) * (size_t)g.plane_stride, c->stream));  // (row padding stays zero: RGB24 output copies whole rows)
   if (c->planes.p)
     HIPCHK(hipMemcpyAsync((u8*)np + want * (size_t)g.plane_stride, c->planes.as<u8>() + c->plane_slots * (size_t)g.plane_stride, g.plane_stride, hipMemcpyDeviceToDevice, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(sync_out(c, c->stream));
   c->planes.release();
   c->planes.p = np;
   c->planes.cap = (want + 1) * (size_t)g.plane_stride;
@@ -310,8 +373,8 @@ static int ensure_codec(scpr_codec* c, int version) {  // CreateCodec + CScreenC
   std::vector<RansRcp> tab(kProbScale + 1);
   for (u32 f = 0; f <= (u32)kProbScale; f++) tab[f] = rans_rcp(f ? f : 1);
   HIPCHK(c->rcp.reserve(tab.size() * sizeof(RansRcp)));
-  HIPCHK(hipMemcpyAsync(c->rcp.p, tab.data(), tab.size() * sizeof(RansRcp), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(h2d(c, c->rcp.p, tab.data(), tab.size() * sizeof(RansRcp), c->stream));
+  HIPCHK(sync_out(c, c->stream));
   setup_loss(c, (int)p.loss);
   c->planes_stride = g.plane_stride;
   c->planes_S = g.S;
@@ -334,10 +397,10 @@ static int compact_tables(scpr_codec* c, DevBuf& arena, DevBuf& other, DevBuf& t
   hipStream_t st = c->stream;
   const size_t most = std::min<size_t>(old_top, (size_t)NCOLCTX + first) + 64;
   HIPCHK(other.reserve(most * sizeof(DenseTab)));
-  HIPCHK(hipMemcpyAsync(topbuf.p, &first, 4, hipMemcpyHostToDevice, st));
+  HIPCHK(h2d(c, topbuf.p, &first, 4, st));
   hipLaunchKernelGGL(k_compact_tables, dim3(NCOLCTX), dim3(64), 0, st, (u32*)recs, words, (int)NCOLCTX, stamp_word, stamp, arena.as<DenseTab>(), other.as<DenseTab>(), topbuf.as<u32>());
-  HIPCHK(hipMemcpyAsync(top, topbuf.p, 4, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));  // (`first` and `top` are the caller's)
+  HIPCHK(d2h(c, top, topbuf.p, 4, st));
+  HIPCHK(sync_out(c, st));  // (`first` and `top` are the caller's)
   // ... and back to the bottom of the arena itself (at most 19 MB; swapping the buffers instead would leave the small one as
   // the arena and make the next call allocate gigabytes again)
   if (*top > first) HIPCHK(hipMemcpyAsync(arena.as<DenseTab>() + first, other.as<DenseTab>() + first, (size_t)(*top - first) * sizeof(DenseTab), hipMemcpyDeviceToDevice, st));
@@ -357,7 +420,7 @@ static int motion_stage(scpr_codec* c, const std::vector<PFrame>& pfr) {
   HIPCHK(c->smv.reserve(pb * 4));
   HIPCHK(c->btype.reserve(pb));
   HIPCHK(c->bmv.reserve(pb * 4));
-  HIPCHK(hipMemcpyAsync(c->pframes.p, pfr.data(), np * sizeof(PFrame), hipMemcpyHostToDevice, st));
+  HIPCHK(h2d(c, c->pframes.p, pfr.data(), np * sizeof(PFrame), st));
   HIPCHK(hipMemsetAsync(c->pflag.p, 0, (size_t)np * 4, st));
   const int grp = std::min(64, nbx), ngrp = (nblocks + grp - 1) / grp;
   HIPCHK(c->gmask.reserve((size_t)np * ngrp * 8));
@@ -441,19 +504,19 @@ static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int n
   hb.assign(n, FrameBase{});
   pchanged.assign(np, 0);
   if (ni + np == 0) return SCPR_OK;
-  HIPCHK(hipMemcpyAsync(c->kinds.p, kinds.data(), n * 4, hipMemcpyHostToDevice, st));
-  HIPCHK(hipMemcpyAsync(c->pidx.p, pidx.data(), n * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(h2d(c, c->kinds.p, kinds.data(), n * 4, st));
+  HIPCHK(h2d(c, c->pidx.p, pidx.data(), n * 4, st));
   if (c->loss_mask != 0xFFFFFFFFu) {  // DoLoss: coded frames only (flat frames keep the source bytes, screencap.cpp:1488-1499)
-    HIPCHK(hipMemcpyAsync(c->slotlist.p, lossslots.data(), lossslots.size() * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(h2d(c, c->slotlist.p, lossslots.data(), lossslots.size() * 4, st));
     dim3 gl((g.H * (g.S >> 2) + 255) / 256, (unsigned)lossslots.size());
     hipLaunchKernelGGL(k_loss, gl, dim3(256), 0, st, c->planes.as<u8>(), g, c->slotlist.as<int>(), c->loss_mask, c->corr_mask);
-    HIPCHK(hipStreamSynchronize(st));  // slotlist is reused below
+    HIPCHK(sync_out(c, st));  // slotlist is reused below
   }
   const int* d_slots = c->slotlist.as<int>();
   if (ni) {
-    HIPCHK(hipMemcpyAsync(c->slotlist.p, islots.data(), ni * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(c->genlist.p, igens.data(), ni * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(c->fidx.p, ifidx.data(), ni * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(h2d(c, c->slotlist.p, islots.data(), ni * 4, st));
+    HIPCHK(h2d(c, c->genlist.p, igens.data(), ni * 4, st));
+    HIPCHK(h2d(c, c->fidx.p, ifidx.data(), ni * 4, st));
     stage_begin(c, ST_CLASSIFY);
     hipLaunchKernelGGL(k_tiles, dim3(g.ntiles, ni), dim3(256), 0, st, planes, g, d_slots, c->exitmap.as<u8>(), c->tnmap.as<u8>(), c->tnmap.as<u8>() + (size_t)c->tn_half);
     hipLaunchKernelGGL(k_entries, dim3(ni), dim3(64), 0, st, c->exitmap.as<u8>(), c->entry.as<u8>(), g, d_slots);
@@ -487,10 +550,10 @@ static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int n
   hipLaunchKernelGGL(k_bases, dim3(1), dim3(64), 0, st, c->kinds.as<int>(), c->pidx.as<int>(), n, c->frametot.as<u32>(),
                      c->hdrcnt.as<u32>(), c->ptot.as<u32>(), c->bases.as<FrameBase>(), c->totals.as<u32>(), chunk_total_limit());
   u32 tot[5];
-  HIPCHK(hipMemcpyAsync(hb.data(), c->bases.p, n * sizeof(FrameBase), hipMemcpyDeviceToHost, st));
-  HIPCHK(hipMemcpyAsync(tot, c->totals.p, sizeof tot, hipMemcpyDeviceToHost, st));
-  if (np) HIPCHK(hipMemcpyAsync(pchanged.data(), c->pflag.p, (size_t)np * 4, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(d2h(c, hb.data(), c->bases.p, n * sizeof(FrameBase), st));
+  HIPCHK(d2h(c, tot, c->totals.p, sizeof tot, st));
+  if (np) HIPCHK(d2h(c, pchanged.data(), c->pflag.p, (size_t)np * 4, st));
+  HIPCHK(sync_out(c, st));
   *nfit = (int)tot[4];
   if (*nfit < n) return kRecut;  // (the 32-bit bases of the frames past *nfit have wrapped: the caller cuts the chunk there)
   const size_t Rtot = tot[0], Ttot = tot[1], Ctot = tot[2], Mtot = tot[3];
@@ -532,18 +595,18 @@ static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int n
       const FrameBase& b = hb[pfidx[k]];
       pbv[k] = PBase{b.run_base, b.sym_base, b.col_base, b.misc_base, b.nbt, (u32)pgen[k], 0, 0};
     }
-    HIPCHK(hipMemcpyAsync(c->pbase.p, pbv.data(), np * sizeof(PBase), hipMemcpyHostToDevice, st));
+    HIPCHK(h2d(c, c->pbase.p, pbv.data(), np * sizeof(PBase), st));
     hipLaunchKernelGGL(k_pemit, dim3((nblocks + 63) / 64 + 1, np), dim3(64), 0, st, planes, g, c->pframes.as<PFrame>(), c->pbase.as<PBase>(), c->binfo.as<u32>(), c->btype.as<u8>(),
                        c->bmv.as<u32>(), c->boff.as<BOff>(), c->bflag.as<u32>(), c->pinfo.as<int>(), mp, c->runs.as<u32>(), c->runpos.as<u32>(), c->keys[0].as<u32>(),
                        c->vals[0].as<u32>(), c->misc.as<u32>(), c->miscpos.as<u32>(), c->entries.as<u32>());
-    HIPCHK(hipStreamSynchronize(st));  // pbv is host memory
+    HIPCHK(sync_out(c, st));  // pbv is host memory
   }
   stage_end(c, ST_SYMBOLS);
 
   if (getenv("SCPR_DEBUG_KEYS") && Ctot) {  // design aid: every colour key must name a generation of this chunk and a context below NCOLCTX
     std::vector<u32> hk(Ctot);
-    HIPCHK(hipMemcpyAsync(hk.data(), c->keys[0].p, Ctot * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(d2h(c, hk.data(), c->keys[0].p, Ctot * 4, st));
+    HIPCHK(sync_out(c, st));
     size_t bad = 0, first = 0;
     for (size_t i = 0; i < Ctot; i++)
       if ((hk[i] >> 22) >= (u32)ngens || ((hk[i] >> 8) & 0x3FFFu) >= (u32)NCOLCTX) {
@@ -568,9 +631,9 @@ static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int n
   stage_end(c, ST_SORT);
   if (getenv("SCPR_DEBUG_KEYS") && Ctot) {
     std::vector<u32> hk(Ctot), hc(nchains + 1);
-    HIPCHK(hipMemcpyAsync(hk.data(), c->keys[1].p, Ctot * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(hc.data(), c->cstart.p, (nchains + 1) * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(d2h(c, hk.data(), c->keys[1].p, Ctot * 4, st));
+    HIPCHK(d2h(c, hc.data(), c->cstart.p, (nchains + 1) * 4, st));
+    HIPCHK(sync_out(c, st));
     size_t unsorted = 0, firstu = 0, badc = 0, firstc = 0;
     for (size_t i = 1; i < Ctot; i++)
       if ((hk[i] >> 8) < (hk[i - 1] >> 8)) {
@@ -606,8 +669,8 @@ static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int n
       mr[gq].end = hb[i].misc_base + hb[i].nmisc;
     }
   }
-  HIPCHK(hipMemcpyAsync(c->ranges.p, rg.data(), ngens * sizeof(GenRange), hipMemcpyHostToDevice, st));
-  HIPCHK(hipMemcpyAsync(c->miscranges.p, mr.data(), ngens * sizeof(MiscRange), hipMemcpyHostToDevice, st));
+  HIPCHK(h2d(c, c->ranges.p, rg.data(), ngens * sizeof(GenRange), st));
+  HIPCHK(h2d(c, c->miscranges.p, mr.data(), ngens * sizeof(MiscRange), st));
   // The fixed-model chains (run lengths, pixel types, P-frame symbols) and the colour chains read the same lists
   // and write disjoint coder entries: they run side by side on two streams and join before the coder.  (Forking before the sort -
   // the fixed models need the run list only - was tried again with round 3's partition kernels: the sort beside them still takes
@@ -719,7 +782,7 @@ void scpr_deinit(scpr_codec* c) {  // ScreenCodec::Deinit, screencap.cpp:1619-16
 void scpr_destroy(scpr_codec* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  (void)hipStreamSynchronize(c->stream);
+  (void)sync_out(c, c->stream);
   (void)hipStreamSynchronize(c->stream2);
   DevBuf* all[] = {&c->planes, &c->tnmap, &c->exitmap, &c->entry, &c->runrec, &c->tilecnt, &c->tileoff, &c->hdrrec, &c->hdrcnt, &c->frametot, &c->flags, &c->slotlist, &c->genlist,
                    &c->bases, &c->totals, &c->runs, &c->runpos, &c->keys[0], &c->keys[1], &c->vals[0], &c->vals[1], &c->cstart, &c->sorttmp,
@@ -730,6 +793,7 @@ void scpr_destroy(scpr_codec* c) {
     for (int k = 0; k < 2; k++) (void)hipEventDestroy(c->ev[s][k]);
   (void)hipStreamDestroy(c->stream);
   (void)hipStreamDestroy(c->stream2);
+  if (c->pin) (void)hipHostFree(c->pin);
   (void)hipEventDestroy(c->ev_fork);
   (void)hipEventDestroy(c->ev_join);
   delete c;
@@ -738,7 +802,7 @@ void scpr_destroy(scpr_codec* c) {
 int scpr_set_cu_mask(scpr_codec* c, const uint32_t* mask, int words) {
   if (!c || words < 0 || (words > 0 && !mask)) return SCPR_E_PARAM;
   if (hipSetDevice(c->device) != hipSuccess) return SCPR_E_DEVICE;
-  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(sync_out(c, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream2));
   hipStream_t a = nullptr, b = nullptr;
   if (words > 0) {
@@ -782,7 +846,7 @@ int scpr_seed_shard(scpr_codec* c, uint32_t frames_before, int last_was_flat, ui
     c->last_flat_rgb = last_flat_rgb & 0xFFFFFFu;
     const Geom& g = c->g;
     hipLaunchKernelGGL(k_fill_flat, dim3((g.H * g.S + 255) / 256), dim3(256), 0, c->stream, c->planes.as<u8>(), g, c->pslot, c->last_flat_rgb);
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(sync_out(c, c->stream));
     c->live_valid = true;       // that flat frame renewed the models ...
     c->live_has_state = false;  // ... and nothing has been coded with them
     c->dec_live = false;
@@ -801,8 +865,8 @@ int scpr_export_mv_memory(scpr_codec* c, int32_t* mx, int32_t* my) {
   if (rc != SCPR_OK) return rc;
   const int nblocks = ((c->g.W + 15) / 16) * ((c->g.H + 15) / 16);
   std::vector<u32> h(nblocks);
-  HIPCHK(hipMemcpyAsync(h.data(), c->mvs.p, (size_t)nblocks * 4, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(d2h(c, h.data(), c->mvs.p, (size_t)nblocks * 4, c->stream));
+  HIPCHK(sync_out(c, c->stream));
   for (int i = 0; i < nblocks; i++) mx[i] = (int16_t)(h[i] & 0xFFFF), my[i] = (int16_t)(h[i] >> 16);
   return nblocks;
 }
@@ -818,8 +882,8 @@ int scpr_import_mv_memory(scpr_codec* c, const int32_t* mx, const int32_t* my) {
     if (mx[i] < -256 || mx[i] > 256 || my[i] < -256 || my[i] > 256) return SCPR_E_PARAM;  // (msr_x = msr_y = min(high_range, 256), :76-80)
     h[i] = ((u32)(mx[i] & 0xFFFF)) | ((u32)(my[i] & 0xFFFF) << 16);
   }
-  HIPCHK(hipMemcpyAsync(c->mvs.p, h.data(), (size_t)nblocks * 4, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(h2d(c, c->mvs.p, h.data(), (size_t)nblocks * 4, c->stream));
+  HIPCHK(sync_out(c, c->stream));
   return nblocks;
 }
 
@@ -829,6 +893,7 @@ int scpr_import_mv_memory(scpr_codec* c, const int32_t* mx, const int32_t* my) {
 int scpr_motion_prepass(scpr_codec* c, const void* d_frames, int nframes, const int* ftypes, int loss, int32_t* mx, int32_t* my) {
   if (!c || !c->inited || !d_frames || !ftypes || !mx || !my || nframes < 0) return SCPR_E_PARAM;
   if (hipSetDevice(c->device) != hipSuccess) return SCPR_E_DEVICE;
+  pin_reset(c);
   if (c->have_codec && c->version == 2) return SCPR_E_BAD_VERSION;
   int rc = ensure_codec(c, c->have_codec ? c->version : 4);
   if (rc != SCPR_OK) return rc;
@@ -842,7 +907,7 @@ int scpr_motion_prepass(scpr_codec* c, const void* d_frames, int nframes, const 
   DevBuf keep;
   HIPCHK(keep.reserve((size_t)nblocks * 4 + g.plane_stride));
   HIPCHK(hipMemcpyAsync(keep.p, c->mvs.p, (size_t)nblocks * 4, hipMemcpyDeviceToDevice, st));
-  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(sync_out(c, st));
   struct Restore {  // (every return below leaves the codec as it was)
     scpr_codec* c;
     DevBuf& keep;
@@ -852,7 +917,7 @@ int scpr_motion_prepass(scpr_codec* c, const void* d_frames, int nframes, const 
       (void)hipMemcpyAsync(c->mvs.p, keep.p, (size_t)nblocks * 4, hipMemcpyDeviceToDevice, c->stream);
       if (planes_saved)
         (void)hipMemcpyAsync(c->planes.as<u8>() + (size_t)c->pslot * c->g.plane_stride, (u8*)keep.p + (size_t)nblocks * 4, c->g.plane_stride, hipMemcpyDeviceToDevice, c->stream);
-      (void)hipStreamSynchronize(c->stream);
+      (void)sync_out(c, c->stream);
       keep.release();
       if (loss_before != c->last_loss) setup_loss(c, loss_before);
     }
@@ -890,8 +955,8 @@ int scpr_motion_prepass(scpr_codec* c, const void* d_frames, int nframes, const 
                          c->bs);
     }
     std::vector<u32> hflags((size_t)n * 2);
-    HIPCHK(hipMemcpyAsync(hflags.data(), d_nonflat, (size_t)n * 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(d2h(c, hflags.data(), d_nonflat, (size_t)n * 8, st));
+    HIPCHK(sync_out(c, st));
     // P-frame iff the picture is not flat, a frame has been coded and the caller allows it (screencap.cpp:1488-1511)
     std::vector<PFrame> pfr;
     std::vector<int> lossslots;
@@ -902,20 +967,20 @@ int scpr_motion_prepass(scpr_codec* c, const void* d_frames, int nframes, const 
       frames_done++;
     }
     if (c->loss_mask != 0xFFFFFFFFu && !lossslots.empty()) {
-      HIPCHK(hipMemcpyAsync(c->slotlist.p, lossslots.data(), lossslots.size() * 4, hipMemcpyHostToDevice, st));
+      HIPCHK(h2d(c, c->slotlist.p, lossslots.data(), lossslots.size() * 4, st));
       dim3 gl((g.H * (g.S >> 2) + 255) / 256, (unsigned)lossslots.size());
       hipLaunchKernelGGL(k_loss, gl, dim3(256), 0, st, c->planes.as<u8>(), g, c->slotlist.as<int>(), c->loss_mask, c->corr_mask);
     }
     if (!pfr.empty() && (rc = motion_stage(c, pfr)) != SCPR_OK) return rc;
     HIPCHK(hipMemcpyAsync(c->planes.as<u8>() + (size_t)c->pslot * g.plane_stride, c->planes.as<u8>() + (size_t)(n - 1) * g.plane_stride, g.plane_stride, hipMemcpyDeviceToDevice, st));
-    HIPCHK(hipStreamSynchronize(st));  // (pfr / lossslots are host memory)
+    HIPCHK(sync_out(c, st));  // (pfr / lossslots are host memory)
     HIPCHK(hipGetLastError());
   }
   u32 err = 0;
   std::vector<u32> h(nblocks);
-  HIPCHK(hipMemcpyAsync(h.data(), c->mvs.p, (size_t)nblocks * 4, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipMemcpyAsync(&err, c->err.p, 4, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(d2h(c, h.data(), c->mvs.p, (size_t)nblocks * 4, st));
+  HIPCHK(d2h(c, &err, c->err.p, 4, st));
+  HIPCHK(sync_out(c, st));
   if (err & 8) {
     fprintf(stderr, "[scpr] motion-vector pipeline stalled\n");
     return SCPR_E_DEVICE;
@@ -928,6 +993,7 @@ int64_t scpr_compress_batch(scpr_codec* c, const void* d_frames, int nframes, in
   if (!c || !c->inited || !d_frames || !ftypes || !d_out || !sizes || nframes < 0) return SCPR_E_PARAM;
   if (c->crashed) return 0;  // screencap.cpp:1634
   if (hipSetDevice(c->device) != hipSuccess) return SCPR_E_DEVICE;
+  pin_reset(c);
   if (c->have_codec && c->version == 2) return SCPR_E_BAD_VERSION;  // a codec that has decoded version 2 cannot encode (no version 2 encoder here)
   int rc = ensure_codec(c, c->have_codec ? c->version : 4);  // the encoder always writes v4 (screencap.cpp:1646-1648)
   if (rc != SCPR_OK) return rc;
@@ -961,8 +1027,8 @@ int64_t scpr_compress_batch(scpr_codec* c, const void* d_frames, int nframes, in
     }
     stage_end(c, ST_PACK);
     std::vector<u32> hflags((size_t)n * 2);
-    HIPCHK(hipMemcpyAsync(hflags.data(), d_nonflat, (size_t)n * 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(d2h(c, hflags.data(), d_nonflat, (size_t)n * 8, st));
+    HIPCHK(sync_out(c, st));
 
     // frame-type decisions: CScreenCapt::CompressFrame, screencap.cpp:1488-1511 - and once more over fewer frames if the
     // chunk's symbol totals turn out to pass 32 bits (k_bases; noise-like content only: ~5 symbols per pixel)
@@ -1085,8 +1151,8 @@ int64_t scpr_compress_batch(scpr_codec* c, const void* d_frames, int nframes, in
     HIPCHK(c->packets.reserve((size_t)n * sizeof(Packet)));
     HIPCHK(c->pktoff.reserve((size_t)n * 8));
     HIPCHK(c->outsizes.reserve((size_t)n * 4));
-    if (nb) HIPCHK(hipMemcpyAsync(c->rblocks.p, blocks.data(), (size_t)nb * sizeof(RansBlock), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(c->packets.p, pk.data(), (size_t)n * sizeof(Packet), hipMemcpyHostToDevice, st));
+    if (nb) HIPCHK(h2d(c, c->rblocks.p, blocks.data(), (size_t)nb * sizeof(RansBlock), st));
+    HIPCHK(h2d(c, c->packets.p, pk.data(), (size_t)n * sizeof(Packet), st));
     if (nb) {
       stage_begin(c, ST_RANS);
       hipLaunchKernelGGL(k_rans, dim3((nb + 63) / 64), dim3(256), 0, st, c->entries.as<u32>(), c->rblocks.as<RansBlock>(), nb, c->rcp.as<RansRcp>(), c->rscratch.as<u8>(),
@@ -1101,11 +1167,11 @@ int64_t scpr_compress_batch(scpr_codec* c, const void* d_frames, int nframes, in
     stage_end(c, ST_GATHER);
     u64 chunk_total = 0;
     u32 err = 0, atop = 0;
-    HIPCHK(hipMemcpyAsync(&atop, c->arena_top.p, 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(sizes + f0, c->outsizes.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(&chunk_total, c->total64.p, 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(&err, c->err.p, 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(d2h(c, &atop, c->arena_top.p, 4, st));
+    HIPCHK(d2h(c, sizes + f0, c->outsizes.p, (size_t)n * 4, st));
+    HIPCHK(d2h(c, &chunk_total, c->total64.p, 8, st));
+    HIPCHK(d2h(c, &err, c->err.p, 4, st));
+    HIPCHK(sync_out(c, st));
     HIPCHK(hipGetLastError());  // a kernel that could not be launched (the launches themselves are not checked one by one)
     timing_collect(c);
     c->arena_used_bound = atop;  // what the arena really holds: it does not grow with the number of calls
@@ -1133,6 +1199,7 @@ int64_t scpr_compress_batch(scpr_codec* c, const void* d_frames, int nframes, in
 int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* sizes, const int* ftypes, int nframes, void* d_frames_out, int pitch) {
   if (!c || !c->inited || !d_packets || !sizes || !ftypes || !d_frames_out || nframes < 0) return SCPR_E_PARAM;
   if (hipSetDevice(c->device) != hipSuccess) return SCPR_E_DEVICE;
+  pin_reset(c);
   hipStream_t st = c->stream;
   timing_reset(c);
   // first bytes of every packet decide version / flat / coded (screencap.cpp:1700, :1536)
@@ -1142,11 +1209,11 @@ int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* 
   if (nframes) {
     HIPCHK(c->pktoff.reserve((size_t)(nframes + 1) * 8));
     HIPCHK(c->outsizes.reserve((size_t)nframes * 4));
-    HIPCHK(hipMemcpyAsync(c->pktoff.p, offs.data(), (size_t)(nframes + 1) * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(h2d(c, c->pktoff.p, offs.data(), (size_t)(nframes + 1) * 8, st));
     hipLaunchKernelGGL(k_heads, dim3((nframes + 255) / 256), dim3(256), 0, st, (const u8*)d_packets, c->pktoff.as<u64>(), nframes, c->outsizes.as<u32>());
-    HIPCHK(hipMemcpyAsync(heads.data(), c->outsizes.p, (size_t)nframes * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(d2h(c, heads.data(), c->outsizes.p, (size_t)nframes * 4, st));
   }
-  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(sync_out(c, st));
   int done = 0;
   HIPCHK(c->err.reserve(64));
   for (int f0 = 0; f0 < nframes;) {
@@ -1222,8 +1289,8 @@ int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* 
       const bool cont = gops[0].load != 0;
       if (cont && !v2 && getenv("SCPR_DEBUG_KEYS")) {  // design aid: every table index of the kept records lies inside the kept part of the arena
         std::vector<u32> hr((size_t)NCOLCTX * DECREC_WORDS);
-        HIPCHK(hipMemcpyAsync(hr.data(), c->dec_colour_persist.p, hr.size() * 4, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(d2h(c, hr.data(), c->dec_colour_persist.p, hr.size() * 4, st));
+        HIPCHK(sync_out(c, st));
         size_t bad = 0, dense = 0, firstbad = 0;
         for (size_t r = 0; r < (size_t)NCOLCTX; r++) {
           const u32 kind = hr[r * DECREC_WORDS] & 255u;
@@ -1262,9 +1329,9 @@ int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* 
       const size_t arena_cap = std::min<size_t>(1 + true_bound, c->dec_arena_used + budget) + 1 + 64;
       HIPCHK(c->dec_arena.reserve_keep(arena_cap * sizeof(DenseTab), c->dec_arena_used * sizeof(DenseTab), st));
       c->h_dec_top0 = (u32)c->dec_arena_used;  // (a member: the source of an asynchronous copy must outlive the call)
-      HIPCHK(hipMemcpyAsync(c->dec_arena_top.p, &c->h_dec_top0, 4, hipMemcpyHostToDevice, st));
-      HIPCHK(hipMemcpyAsync(c->decframes.p, fr.data(), fr.size() * sizeof(DecFrame), hipMemcpyHostToDevice, st));
-      HIPCHK(hipMemcpyAsync(c->decgops.p, gops.data(), ng * sizeof(DecGop), hipMemcpyHostToDevice, st));
+      HIPCHK(h2d(c, c->dec_arena_top.p, &c->h_dec_top0, 4, st));
+      HIPCHK(h2d(c, c->decframes.p, fr.data(), fr.size() * sizeof(DecFrame), st));
+      HIPCHK(h2d(c, c->decgops.p, gops.data(), ng * sizeof(DecGop), st));
       Arena ar{c->dec_arena.as<DenseTab>(), c->dec_arena_top.as<u32>(), (u32)arena_cap - 1u, c->err.as<u32>()};  // (the last table allocated is the sink)
       // LDS ring of 32-bit pixels: the predictors look back one row + 1 pixel, a finished row is flushed at most
       // one run after it ends, and a run writes up to 255 pixels ahead: a power of two >= W + 512 pixels.
@@ -1308,9 +1375,9 @@ int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* 
     }
     stage_end(c, ST_DECODE);
     u32 atop = 0;
-    HIPCHK(hipMemcpyAsync(errv, c->err.p, 32, hipMemcpyDeviceToHost, st));
-    if (ng) HIPCHK(hipMemcpyAsync(&atop, c->dec_arena_top.p, 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));  // also covers fr / gops (host memory)
+    HIPCHK(d2h(c, errv, c->err.p, 32, st));
+    if (ng) HIPCHK(d2h(c, &atop, c->dec_arena_top.p, 4, st));
+    HIPCHK(sync_out(c, st));  // also covers fr / gops (host memory)
     HIPCHK(hipGetLastError());         // a kernel that could not be launched
     // A record that names a table beyond the arena's sink (bit 16; refused by the table cache, never followed) is an error of
     // whatever attempt shows it, and always said: an overflow hands out the sink, so no state the decoder makes by itself holds
@@ -1353,7 +1420,7 @@ int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* 
       hipLaunchKernelGGL(k_unpack_rows, gr, dim3(256), 0, st, c->planes.as<u8>(), out, g, pitch, c->bpp, c->rs, c->gs, c->bs);
     }
     stage_end(c, ST_UNPACK);
-    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(sync_out(c, st));
     HIPCHK(hipGetLastError());
     timing_collect(c);
     const u32 err = errv[0];
@@ -1375,7 +1442,7 @@ int scpr_compress_frame(scpr_codec* c, const void* src, void* dst, int dst_len, 
   const size_t fb = (size_t)c->pitch_in * c->g.H, cap = (size_t)c->g.W * c->g.H * 6 + 64;
   HIPCHK(c->hoststage_in.reserve(fb));
   HIPCHK(c->hoststage_out.reserve(cap));
-  HIPCHK(hipMemcpyAsync(c->hoststage_in.p, src, fb, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(h2d(c, c->hoststage_in.p, src, fb, c->stream));
   uint32_t sz = 0;
   int64_t r = scpr_compress_batch(c, c->hoststage_in.p, 1, ftype, loss, c->hoststage_out.p, cap, &sz);
   if (r <= 0) return (int)r;
@@ -1392,7 +1459,7 @@ int scpr_decompress_frame(scpr_codec* c, const void* src, int src_len, void* dst
   const size_t ob = (size_t)pitch * c->prm.height;
   HIPCHK(c->hoststage_in.reserve((size_t)src_len + 64));
   HIPCHK(c->hoststage_out.reserve(ob));
-  HIPCHK(hipMemcpyAsync(c->hoststage_in.p, src, (size_t)src_len, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(h2d(c, c->hoststage_in.p, src, (size_t)src_len, c->stream));
   uint32_t sz = (uint32_t)src_len;
   int r = scpr_decompress_batch(c, c->hoststage_in.p, &sz, &ftype, 1, c->hoststage_out.p, pitch);
   if (r < 0) return r;

@@ -45,6 +45,8 @@ def side_by_side():
              "enc last 96 / dec first 160": (list(range(160, 256)), list(range(160))), "enc odd / dec even": (list(range(1, ncu, 2)), list(range(0, ncu, 2))),
              "enc 16 of every 64 / dec the rest": ([q for q in range(ncu) if q % 64 >= 48], [q for q in range(ncu) if q % 64 < 48])}
     out = torch.empty(N * w * h * 4, dtype=torch.uint8, device=dev)
+    if "--first" in sys.argv:
+        pairs = {k: pairs[k] for k in list(pairs)[:1]}
     for name, (ec, dc) in pairs.items():
         enc, dec = ScreenCodec(0).Init(w, h, 32).SetCuMask(ec), ScreenCodec(0).Init(w, h, 32).SetCuMask(dc)
         pk, sizes, ft = enc.CompressBatch(f, [0] * N)
