@@ -142,6 +142,7 @@ struct scpr_codec {
   // wait for that stream.  h2d(): the source is copied here first (it may die right after the call).  d2h(): lands here, and
   // sync_out() hands it to where it was meant to go after the stream has been waited for.  A request the pool cannot hold
   // falls back to the direct copy.
+  int ncu = 256;  // compute units the codec's kernels may run on (the device's, or the bits of its CU mask)
   u8* pin = nullptr;
   size_t pin_cap = 0, pin_used = 0;
   struct PendingOut {
@@ -521,11 +522,12 @@ static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int n
     hipLaunchKernelGGL(k_tiles, dim3(g.ntiles, ni), dim3(256), 0, st, planes, g, d_slots, c->exitmap.as<u8>(), c->tnmap.as<u8>(), c->tnmap.as<u8>() + (size_t)c->tn_half);
     hipLaunchKernelGGL(k_entries, dim3(ni), dim3(64), 0, st, c->exitmap.as<u8>(), c->entry.as<u8>(), g, d_slots);
     // k_runs walks one tile per lane, a cache line of the type/length map at a time: with every CU full of its waves the lines
-    // in use (8 MB per XCD) do not fit the XCD's 4 MB L2 and are fetched three times over.  Unused dynamic LDS keeps it to two
-    // workgroups per CU - each line comes in once (profiles/: FETCH_SIZE 1.98 GB -> 0.40 GB per launch, +0.2 ms).
-    static const int runs_lds = getenv("SCPR_RUNS_LDS") ? atoi(getenv("SCPR_RUNS_LDS")) : 65000;
-    hipLaunchKernelGGL(k_runs, dim3((g.ntiles + 255) / 256, ni), dim3(256), runs_lds, st, g, d_slots, c->entry.as<u8>(), c->tnmap.as<u8>(), c->tnmap.as<u8>() + (size_t)c->tn_half, c->runrec.as<u32>(),
-                       c->tilecnt.as<u32>());
+    // in use (8 MB per XCD) do not fit the XCD's 4 MB L2 and are fetched three times over.  Two workgroups per CU, each taking
+    // its pairs grid-stride: each line comes in once (profiles/: FETCH_SIZE 1.98 GB -> 0.40 GB per launch, +0.2 ms).
+    static const int runs_per_cu = getenv("SCPR_RUNS_PER_CU") ? atoi(getenv("SCPR_RUNS_PER_CU")) : 2;
+    const int run_groups = ((g.ntiles + 255) / 256) * ni;
+    hipLaunchKernelGGL(k_runs, dim3((unsigned)std::max(1, std::min(run_groups, runs_per_cu * c->ncu))), dim3(256), 0, st, g, d_slots, ni, c->entry.as<u8>(), c->tnmap.as<u8>(),
+                       c->tnmap.as<u8>() + (size_t)c->tn_half, c->runrec.as<u32>(), c->tilecnt.as<u32>());
     hipLaunchKernelGGL(k_header, dim3(ni), dim3(64), 0, st, planes, g, d_slots, c->hdrrec.as<u32>(), c->hdrcnt.as<u32>());
     stage_end(c, ST_CLASSIFY);
     stage_begin(c, ST_SCAN);
@@ -735,6 +737,10 @@ scpr_codec* scpr_create(int device) {
   if (hipSetDevice(device) != hipSuccess) return nullptr;
   scpr_codec* c = new scpr_codec;
   c->device = device;
+  {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0) c->ncu = v;
+  }
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
     delete c;
@@ -825,6 +831,15 @@ int scpr_set_cu_mask(scpr_codec* c, const uint32_t* mask, int words) {
   (void)hipStreamDestroy(c->stream2);
   c->stream = a;
   c->stream2 = b;
+  {
+    int v = 0;
+    if (words > 0) {
+      for (int i = 0; i < words; i++) v += __builtin_popcount(mask[i]);
+    } else if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess) {
+      v = 0;
+    }
+    if (v > 0) c->ncu = v;
+  }
   return SCPR_OK;
 }
 

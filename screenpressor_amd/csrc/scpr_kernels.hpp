@@ -431,10 +431,15 @@ __global__ __launch_bounds__(64) void k_entries(const u8* __restrict__ exitmap, 
 // points are known, and a frame has 2000 of them: the walk needs no pointer doubling (the second k_tiles pass it replaces
 // re-classified every pixel and squared the successor function nine times to mark the same path).
 // tilecnt: {runs, literal runs} per tile.   runrec: rel_start | type<<10 | n<<16
-__global__ __launch_bounds__(256) void k_runs(Geom g, const int* __restrict__ slots, const u8* __restrict__ entry, const u8* __restrict__ tnmap, const u8* __restrict__ nlong,
+// A fixed number of workgroups (two per CU: the host's choice) take the (frame, group of 256 tiles) pairs in launch order,
+// grid-stride: the lines of the type/length map being walked at any moment are those of ~512 pairs and stay in the L2.  (The
+// first form bought the same limit with 65 000 bytes of LDS it never touched - and starved beside another kernel that holds LDS.)
+__global__ __launch_bounds__(256) void k_runs(Geom g, const int* __restrict__ slots, int nslots, const u8* __restrict__ entry, const u8* __restrict__ tnmap, const u8* __restrict__ nlong,
                                               u32* __restrict__ runrec, u32* __restrict__ tilecnt) {
-  const int slot = slots[blockIdx.y], tile = blockIdx.x * 256 + threadIdx.x;
-  if (tile >= g.ntiles) return;
+ const int groups = (g.ntiles + 255) / 256;
+ for (int wk = blockIdx.x; wk < groups * nslots; wk += gridDim.x) {
+  const int slot = slots[wk / groups], tile = (wk % groups) * 256 + threadIdx.x;
+  if (tile >= g.ntiles) continue;
   const size_t ti = (size_t)slot * g.ntiles + tile;
   const u8* tn = tnmap + ti * TILE;
   const u8* nl = nlong + ti * TILE;
@@ -473,6 +478,7 @@ __global__ __launch_bounds__(256) void k_runs(Geom g, const int* __restrict__ sl
   }
   tilecnt[ti * 2] = (u32)cnt;
   tilecnt[ti * 2 + 1] = (u32)lit;
+ }
 }
 
 // runs of identical pixels over raster pixels 0..W (first row and pixel (0,1)):
