@@ -465,8 +465,17 @@ static int fixed_chains(scpr_codec* c, hipStream_t s2, FixBufs& fb, const u32* e
   hipLaunchKernelGGL(k_part_scan, dim3(NC), dim3(SCAN_T), 0, s2, fb.cnt.as<u32>(), fb.off.as<u32>(), nblk, fb.tot.as<u32>());
   if (nblk) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_part_scatter<SRC>), dim3(nblk), dim3(256), 0, s2, el, elpos, (u32)n, fb.off.as<u32>(), nblk, fb.tot.as<u32>(), fb.sym.as<u16>(), fb.pos.as<u32>());
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_part_genstart<SRC>), dim3(ngens), dim3(64), 0, s2, el, (u32)n, ranges, ngens, fb.off.as<u32>(), nblk, fb.tot.as<u32>(), fb.gen.as<u32>());
+  // How far apart (in coder entries) a generation's model waves may be, scpr_fixed.hpp.  Measured on the headline batch (300
+  // generations), bytes written by the kernel / its time: no window 3.74 GB / 2.16 ms, 16384 entries 1.56 / -, 4096 0.95 / 1.28,
+  // 2048 0.84 GB / 1.28 ms - 0.83 GB is every 32-byte sector of the entry array written once (the colour entries between the
+  // fixed models' are written by another kernel at another time).  With few generations there is nothing to hold back for (one
+  // 300-frame GOP is ONE workgroup: in step it takes 15.6-19.8 ms instead of 12.3, its waves waiting for the model with the
+  // most symbols window after window): no window.  SCPR_FIXED_WINDOW overrides (0: none).
+  static const long window_env = getenv("SCPR_FIXED_WINDOW") ? strtol(getenv("SCPR_FIXED_WINDOW"), nullptr, 0) : -1;
+  const u32 auto_window = ngens >= 16 ? 2048u : 0u;
+  const u32 fixed_window = window_env >= 0 ? (u32)window_env : auto_window;
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fixed_chain2<SRC, MAXSYM>), dim3(ngens), dim3(64 * NC), (size_t)NC * 2 * MAXSYM * 4, s2, fb.sym.as<u16>(), fb.pos.as<u32>(), fb.gen.as<u32>(), ngens,
-                     load_first ? 1 : 0, pin, pout, c->entries.as<u32>());
+                     load_first ? 1 : 0, pin, pout, c->entries.as<u32>(), fixed_window);
   (void)c;
   return SCPR_OK;
 }

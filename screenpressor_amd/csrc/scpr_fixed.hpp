@@ -278,11 +278,21 @@ __global__ __launch_bounds__(64) void k_part_genstart(const u32* __restrict__ el
 // the host hands out two arrays and swaps them.  Dynamic LDS: 2 * MAXSYM words per wave.
 template <class SRC, int MAXSYM>
 __global__ __launch_bounds__(64 * SRC::NCLS) void k_fixed_chain2(const u16* __restrict__ fl_sym, const u32* __restrict__ fl_pos, const u32* __restrict__ gstart, int ngens, int load_first,
-                                                                 const FixedPersist* persist /* [NCLS] */, FixedPersist* persist_out, u32* __restrict__ entries) {
+                                                                 const FixedPersist* persist /* [NCLS] */, FixedPersist* persist_out, u32* __restrict__ entries, u32 window) {
   // one wave per model; a wave owns its table: fc = freq | cum << 16 (what goes to the coder as it is), cnt; lanes of a wave
   // talk through LDS in program order (wavefront fences only, no barriers)
   extern __shared__ __align__(16) u32 chain_lds[];
+  // The waves of a generation write into the same stretch of the coder's entry array, each its own model's entries: a 4-byte
+  // store here, another model's next to it much later - left to themselves the twelve fronts drift apart by megabytes and the L2
+  // hands every store on as a 32-byte write by itself (4.5 GB for 134 M entries, profiles/).  They go in step instead: a wave
+  // publishes the stream position of the first symbol of the trip it is about to code, and starts that trip only when it lies
+  // within a window of the hindmost front - so that what the L2 holds of the entry array is a few hundred kilobytes per
+  // generation and a line has collected its models' words before it leaves.  The hindmost wave never waits (no deadlock); a
+  // wave that is done publishes the end of positions.
+  __shared__ u32 front[SRC::NCLS];
   const int cls = threadIdx.x >> 6, gen = blockIdx.x, lane = threadIdx.x & 63;
+  if (threadIdx.x < SRC::NCLS) front[threadIdx.x] = 0u;
+  __syncthreads();
   u32* fc = chain_lds + (size_t)cls * 2 * MAXSYM;
   u32* cnt = fc + MAXSYM;
   const int nsym = SRC::nsym(cls);
@@ -337,6 +347,18 @@ __global__ __launch_bounds__(64 * SRC::NCLS) void k_fixed_chain2(const u16* __re
   for (u32 base = s; base < e; base += 256) {
     const uint2 sy = sy1;
     const uint4 po = po1;
+    if (window) {  // (0: every wave at its own pace)
+      const u32 first = rfl(po.x);  // lane 0, slot 0: the trip's first symbol
+      if (lane == 0) __hip_atomic_store(&front[cls], first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      for (;;) {
+        u32 f = lane < SRC::NCLS ? lds_peek(&front[lane]) : 0xFFFFFFFFu;
+#pragma unroll
+        for (int d = 8; d >= 1; d >>= 1) f = min(f, (u32)__shfl_xor((int)f, d));  // (NCLS <= 16: the first row of lanes)
+        const u32 hind = rfl(f);
+        if (first - hind <= window) break;  // (first >= hind: this wave's own front is among them)
+        __builtin_amdgcn_s_sleep(4);
+      }
+    }
     sy1 = sy2, po1 = po2;
     if (base + 512u + 4u * lane < e) sy2 = ld_sym(base + 512u + 4u * lane), po2 = ld_pos(base + 512u + 4u * lane);
     const int cntm = (int)min(256u, e - base);
@@ -382,6 +404,7 @@ __global__ __launch_bounds__(64 * SRC::NCLS) void k_fixed_chain2(const u16* __re
       }
     }
   }
+  if (lane == 0) __hip_atomic_store(&front[cls], 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   if (gen == ngens - 1) {  // the last generation of the call is the live one
     wave_fence();
     for (int j = lane; j < nsym; j += 64) {
