@@ -39,6 +39,7 @@ constexpr u32 V2_TOP = 1u << 24;        // TOP, sub.h:14
 struct WaveDecV2 {
   static constexpr bool kHelpers = false;  // one wave per GOP, no helper waves
   static constexpr bool kFastRuns = false;  // decode_intra_frame: no second instance of the run body for this coder
+  struct NAsk {};                           // (the fast runs' early table read, scpr_wave.hpp: not for this coder)
   int ndec = 0;                             // (unused: the range coder has no blocks)
   const int lane;
   V2Lds& L;
@@ -213,8 +214,9 @@ struct WaveDecV2 {
 
   // (the template parameters and the second argument only exist to match WaveDec - its symbols hand their coder step on to
   // the next one, decode_intra_frame - and are never used with this coder)
-  template <bool CHK = true, bool PIPE = false, bool DOUT = false>
-  __device__ __forceinline__ int fixed_n(int t, u32* = nullptr) { return dec_lds<4>(L.fx.n[t], 256, 400); }   // SC_NSTEP
+  template <bool CHK = true, bool PIPE = false, bool DOUT = false, bool PRE = false>
+  __device__ __forceinline__ int fixed_n(int t, u32* = nullptr, const NAsk* = nullptr) { return dec_lds<4>(L.fx.n[t], 256, 400); }   // SC_NSTEP
+  __device__ __forceinline__ void fixed_n_ask(int, NAsk&) {}
   template <bool CHK = true, bool DEFER = false>
   __device__ __forceinline__ int fixed_p(int t, u32* = nullptr) { return dec_lds<1>(L.fx.p[t], 6, 1000); }    // SC_UNSTEP
   __device__ __forceinline__ int fixed_x(int k) { return k == 0 ? dec_lds<4>(L.fx.x, 256, 1) : dec_lds<4>(L.fx.bn, 256, 20); }  // SC_XXSTEP / SC_BTNSTEP

@@ -1063,13 +1063,28 @@ struct WaveDec : WaveModel {
   // PIPE: the coder step of the symbol before (pend: advance + count) is taken while the table's words are on their way
   // from LDS (see record<CHK, PIPE>).
   // DOUT: its own coder step is left in `pend` for the caller (the key-frame loop takes it under the run's ring read).
-  template <bool CHK = true, bool PIPE = false, bool DOUT = false>
-  __device__ __forceinline__ int fixed_n(int t, u32* pend = nullptr) {
+  // PRE: the table's three words were asked for by fixed_n_ask() as soon as the type was known - in front of a literal's three
+  // colour symbols, under which their LDS round trip then goes by (a run without a literal comes here at once: as before).
+  struct NAsk {
+    u32 e0, e1, et;
+  };
+  __device__ __forceinline__ void fixed_n_ask(int t, NAsk& q) {
+    wave_fence();
+    const u32 addr = (u32)(size_t)L.fx.ntab[t] + 4u * (u32)lane;
+    asm volatile("ds_read_b32 %0, %3\n\tds_read_b32 %1, %3 offset:256\n\tds_read_b32 %2, %3 offset:1024" : "=v"(q.e0), "=v"(q.e1), "=v"(q.et) : "v"(addr) : "memory");
+  }
+  template <bool CHK = true, bool PIPE = false, bool DOUT = false, bool PRE = false>
+  __device__ __forceinline__ int fixed_n(int t, u32* pend = nullptr, const NAsk* pre = nullptr) {
     wave_fence();
     u32* tab = L.fx.ntab[t];
     const u32 addr = (u32)(size_t)tab + 4u * (u32)lane;  // LDS offset = low 32 bits of the flat address
     u32 e0, e1, et;
-    if constexpr (PIPE) {
+    if constexpr (PRE) {
+      e0 = pre->e0, e1 = pre->e1, et = pre->et;
+      advance(pend[0], pend[1], pend[2]);
+      count<CHK>();
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(e0), "+v"(e1), "+v"(et) : : "memory");
+    } else if constexpr (PIPE) {
       asm volatile("ds_read_b32 %0, %3\n\tds_read_b32 %1, %3 offset:256\n\tds_read_b32 %2, %3 offset:1024" : "=v"(e0), "=v"(e1), "=v"(et) : "v"(addr) : "memory");
       advance(pend[0], pend[1], pend[2]);
       count<CHK>();
@@ -1636,8 +1651,11 @@ __device__ __forceinline__ void decode_intra_frame(DEC& D, const Geom& g, u8* __
     D.template stamp<4>();
     u32 pend[3];  // the fast instance (wave decoder): every symbol's coder step is taken by the next symbol, under its table fetch
     constexpr bool CHAIN = FAST && DEC::kFastRuns;
-    if constexpr (CHAIN) t = D.template fixed_p<false, true>(t, pend);
-    else if constexpr (FAST) t = D.template fixed_p<false>(t);
+    [[maybe_unused]] typename DEC::NAsk nask;
+    if constexpr (CHAIN) {
+      t = D.template fixed_p<false, true>(t, pend);
+      D.fixed_n_ask(t, nask);
+    } else if constexpr (FAST) t = D.template fixed_p<false>(t);
     else if (lim == NP) t = D.fixed_p(t);
     D.template stamp<0>();
     D.template event<13>();
@@ -1674,7 +1692,7 @@ __device__ __forceinline__ void decode_intra_frame(DEC& D, const Geom& g, u8* __
     }
     int n;
     if constexpr (CHAIN) {
-      n = D.template fixed_n<false, true, true>(t, pend);  // (its own step: under the run's ring read, below)
+      n = D.template fixed_n<false, true, true, true>(t, pend, &nask);  // (its own step: under the run's ring read, below)
       D.ndec += t == 0 ? 5 : 2;  // the symbols of this run (type, three colour bytes of a literal, length)
     } else if constexpr (FAST) {
       n = D.template fixed_n<false>(t);
