@@ -2143,8 +2143,11 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
       D.template stamp<7>();
       u32 pend[3];  // the fast instance (wave decoder): every symbol's coder step is taken by the next symbol, under its table fetch
       constexpr bool CHAIN = FAST && DEC::kFastRuns;
-      if constexpr (CHAIN) pt = D.template fixed_p<false, true>(last_t, pend);
-      else pt = D.template fixed_p<!FAST>(last_t);
+      [[maybe_unused]] typename DEC::NAsk nask;
+      if constexpr (CHAIN) {
+        pt = D.template fixed_p<false, true>(last_t, pend);
+        D.fixed_n_ask(pt, nask);  // (the run-length table: on its way while a literal's colour symbols are decoded, see decode_intra_frame)
+      } else pt = D.template fixed_p<!FAST>(last_t);
       D.template stamp<0>();
       D.template event<13>();
       if (pt == 0) D.template event<14>();
@@ -2164,7 +2167,7 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
       }
       D.template stamp<1>();
       int rem;
-      if constexpr (CHAIN) rem = D.template fixed_n<false, true>(pt, pend);
+      if constexpr (CHAIN) rem = D.template fixed_n<false, true, false, true>(pt, pend, &nask);
       else rem = D.template fixed_n<!FAST>(pt);
       D.template stamp<2>();
       if constexpr (!FAST) {  // (a rect always starts in this instance)
