@@ -63,7 +63,13 @@ void scpr_crash_happened(scpr_codec* c);
  *      screencap.cpp:1668 - NOT DWORD-aligned, which only differs for odd widths;
  *      the decompress side writes RGB16 rows at the caller's `pitch`, :1726-1734).
  * *ftype in: 0 = key frame wanted, 1 = P allowed; out: type produced.
- * Returns the compressed size, 0 when refused (crashed), < 0 on error. */
+ * Returns the compressed size, 0 when refused (crashed), < 0 on error.
+ * dst_len: room at dst (the reference's dstLength; its own guard, CheckDstLength,
+ *      screencap.cpp:300-314, is commented out and CodecInst provides W*H*6 bytes,
+ *      screenpressor.cpp:386-388).  A packet that does not fit is REFUSED with
+ *      SCPR_E_CAPACITY and the codec is left exactly as the call found it (models,
+ *      previous frame, motion-vector memory, flat-frame memory, frame count): the
+ *      same frame may be given again with more room. */
 int scpr_compress_frame(scpr_codec* c, const void* src, void* dst, int dst_len, int* ftype, int loss);
 
 /* ScreenCodec::DecompressFrame (screencap.cpp:1695-1743).  Host pointers.
@@ -79,7 +85,14 @@ int scpr_decompress_frame(scpr_codec* c, const void* src, int src_len, void* dst
  * ftypes:   host array, in/out as *ftype above.
  * d_out:    device buffer receiving the packets back to back in frame order.
  * sizes:    host array receiving each packet's size.
- * Returns the total number of bytes written, or < 0. */
+ * Returns the total number of bytes written, or < 0.
+ * SCPR_E_CAPACITY (the packets do not fit out_capacity): the WHOLE call is taken
+ * back - codec state and `ftypes` are as before it, d_out holds nothing of use.
+ * How: a chunk's packets are bounded before anything is coded (2 bytes per coder
+ * entry + 4 per block of 131072 + headers); only when that bound exceeds the room
+ * left is the state the chains are about to change copied aside first (models,
+ * live dense tables, previous frame: ~10-30 MB device to device), so a call with
+ * W*H*6 bytes per frame never pays for it. */
 int64_t scpr_compress_batch(scpr_codec* c, const void* d_frames, int nframes, int* ftypes, int loss,
                             void* d_out, size_t out_capacity, uint32_t* sizes);
 
@@ -132,7 +145,13 @@ int scpr_motion_prepass(scpr_codec* c, const void* d_frames, int nframes, const 
  * again; call it between calls, not during one.  words = 0 lifts the limit.
  * For running two codecs side by side on one card - a decoder's chains (one
  * wave per GOP) beside another codec's encoder - without either taking the
- * other's LDS and issue slots.  Returns 0 or < 0. */
+ * other's LDS and issue slots.  Returns 0 or < 0.
+ * Stream semantics change with a mask: hipExtStreamCreateWithCUMask takes no
+ * flags, so the masked streams are BLOCKING streams - they synchronise
+ * implicitly with the NULL stream (torch's default stream is the NULL stream),
+ * where the codec's ordinary streams are hipStreamNonBlocking.  A caller that
+ * wants two masked codecs side by side keeps its own work off the NULL stream
+ * (torch: a non-default stream) while they run. */
 int scpr_set_cu_mask(scpr_codec* c, const uint32_t* mask, int words);
 
 /* ---- instrumentation ------------------------------------------------------ */
@@ -151,6 +170,12 @@ int64_t scpr_debug_entries(scpr_codec* c, uint16_t* out, int64_t cap);
 /* Debug tap (tests only): bytes currently allocated for the dense-table arenas of
  * the compress side and of the decompress side. */
 int scpr_debug_arena(scpr_codec* c, uint64_t* enc_bytes, uint64_t* dec_bytes);
+
+/* Test hook: the next scpr_compress_batch fails on purpose.  1: SCPR_E_DEVICE between
+ * the read-backs of its results and their hand-over to the caller's variables (what a
+ * HIP error there leaves queued); 2: two colour keys change places behind the radix
+ * sort (an unsorted result: the call ends with SCPR_E_DEVICE, no chain is followed). */
+int scpr_debug_inject(scpr_codec* c, int what);
 
 /* Test hook: runs ONE colour context over `n` symbols through the wave-per-chain
  * encoder kernel and returns the coder entries ({freq, cum} pairs; freq 0 = raw). */

@@ -18,7 +18,7 @@ _LIB_PATH = os.environ.get("SCPR_AMD_LIB", os.path.join(_PKG, "libscpr_amd.so"))
 SCPR_OK, SCPR_E_DEVICE, SCPR_E_PARAM, SCPR_E_BAD_VERSION, SCPR_E_CAPACITY, SCPR_E_STREAM = 0, -1, -2, -3, -4, -5
 EXPORTS = ["scpr_create", "scpr_destroy", "scpr_init", "scpr_deinit", "scpr_crash_happened", "scpr_compress_frame",
            "scpr_decompress_frame", "scpr_compress_batch", "scpr_decompress_batch", "scpr_last_timing", "scpr_stage_name",
-           "scpr_seed_shard", "scpr_export_mv_memory", "scpr_import_mv_memory", "scpr_motion_prepass", "scpr_set_cu_mask", "scpr_debug_entries", "scpr_debug_arena", "scpr_debug_colour_chain", "scpr_version",
+           "scpr_seed_shard", "scpr_export_mv_memory", "scpr_import_mv_memory", "scpr_motion_prepass", "scpr_set_cu_mask", "scpr_debug_entries", "scpr_debug_arena", "scpr_debug_colour_chain", "scpr_debug_inject", "scpr_version",
            # include/scpr_driver.h, include/scpr_avi.h
            "scpr_driver_open", "scpr_driver_close", "scpr_driver_configure", "scpr_driver_compress_query", "scpr_driver_compress_get_format",
            "scpr_driver_compress_get_size", "scpr_driver_compress_begin", "scpr_driver_compress_end", "scpr_driver_compress",
@@ -35,6 +35,10 @@ class ScprParams(C.Structure):
 
 class BadVersionException(Exception):
     """screencap.h:86-90"""
+
+
+class CapacityError(RuntimeError):
+    """SCPR_E_CAPACITY: the packets do not fit the destination; the codec is as the call found it"""
 
 
 _lib = None
@@ -73,6 +77,7 @@ def load_library() -> C.CDLL:
         L.scpr_set_cu_mask.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_int]
         L.scpr_debug_arena.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.scpr_debug_colour_chain.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.scpr_debug_inject.argtypes = [C.c_void_p, C.c_int]
         L.scpr_version.restype = C.c_char_p
         _lib = L
     return _lib
@@ -156,15 +161,17 @@ class ScreenCodec:
     def _check(rc):
         if rc == SCPR_E_BAD_VERSION:
             raise BadVersionException(rc)
+        if rc == SCPR_E_CAPACITY:
+            raise CapacityError(f"scpr error {rc}: destination too small (nothing was coded)")
         if rc < 0:
             raise RuntimeError(f"scpr error {rc}")
         return rc
 
     # ScreenCodec::CompressFrame: (bytes, ftype_out); ftype_in 0 = key frame wanted, 1 = P allowed
-    def CompressFrame(self, frame: np.ndarray, ftype: int = 1, loss: int | None = None):
+    def CompressFrame(self, frame: np.ndarray, ftype: int = 1, loss: int | None = None, dst_len: int | None = None):
         src = np.ascontiguousarray(frame, dtype=np.uint8).reshape(-1)
         assert src.size == self.frame_bytes, (src.size, self.frame_bytes)
-        dst = np.empty(self.max_packet, dtype=np.uint8)
+        dst = np.empty(self.max_packet if dst_len is None else dst_len, dtype=np.uint8)
         ft = C.c_int(ftype)
         n = self._check(self._L.scpr_compress_frame(self._h, src.ctypes.data_as(C.c_void_p), dst.ctypes.data_as(C.c_void_p),
                                                     dst.size, C.byref(ft), self.loss if loss is None else loss))
@@ -185,6 +192,8 @@ class ScreenCodec:
             self._check(self._L.scpr_set_cu_mask(self._h, None, 0))
             return self
         cus = sorted(set(int(q) for q in cus))
+        if not cus or cus[0] < 0:
+            raise ValueError("SetCuMask: an empty (or negative) list of compute units; None lifts the limit")
         words = cus[-1] // 32 + 1
         m = (C.c_uint32 * words)()
         for q in cus:
@@ -201,8 +210,8 @@ class ScreenCodec:
         assert frames.is_cuda and frames.dtype == torch.uint8 and frames.is_contiguous() and frames.numel() == n * self.frame_bytes
         own = out is None
         if own:
-            # room for incompressible pictures (a literal pixel costs a little over three bytes): a batch that does not fit ends in
-            # SCPR_E_CAPACITY after the models have moved on, so the default is the safe size; pass `out` to reuse a smaller buffer
+            # room for incompressible pictures (a literal pixel costs a little over three bytes); a batch that does not fit ends in
+            # CapacityError with the codec left as the call found it.  Pass `out` to reuse a smaller buffer
             # (kept on the object and grown when a call needs more: 2.5 GB for 300 frames of 1080p is not allocated per call)
             need = min(n * self.max_packet, max(64 << 20, n * (self.width * self.height * 4 + 1024)))
             if getattr(self, "_out", None) is None or self._out.numel() < need or self._out.device != frames.device:
@@ -238,6 +247,10 @@ class ScreenCodec:
         st = (C.c_float * 32)()
         k = self._L.scpr_last_timing(self._h, C.byref(tot), st, 32)
         return tot.value, {self._L.scpr_stage_name(i).decode(): st[i] for i in range(k)}
+
+    def debug_inject(self, what: int):
+        """scpr_debug_inject (tests): the next CompressBatch fails on purpose - 1 between read-back and hand-over, 2 unsorted keys"""
+        self._L.scpr_debug_inject(self._h, what)
 
     def debug_arena(self):
         """(compress side, decompress side) bytes allocated for dense tables"""

@@ -102,8 +102,8 @@ struct scpr_codec {
   int slots = 0;   // frames per encode chunk (bounded by the per-frame scratch the encoder needs)
   int dslots = 0;  // frames per decode chunk (the decoder needs planes only: a long stream keeps all its GOPs in flight)
   size_t plane_slots = 0;  // planes allocated for frames; the previous frame of the stream lives in slot `pslot` == plane_slots
-  u32 planes_stride = 0;   // geometry the planes were last cleared for (plane stride, row stride)
-  int planes_S = 0;
+  u32 planes_stride = 0;   // geometry the planes were last cleared for (plane stride, row stride, picture size)
+  int planes_S = 0, planes_W = 0, planes_H = 0;
   int pslot = 0;
   // per-slot worst-case buffers
   DevBuf planes, exitmap, entry, runrec, tilecnt, tileoff, hdrrec, hdrcnt, frametot, tnmap;
@@ -157,7 +157,29 @@ struct scpr_codec {
   float stage_ms[ST_COUNT];
   float total_ms = 0;
   int64_t dbg_entries = 0;
+  // What a compress call changes, kept so that a call whose packets turn out not to fit the caller's buffer leaves the codec as it
+  // found it (SCPR_E_CAPACITY; the reference's own guard, CheckDstLength, screencap.cpp:300-314, is commented out and its caller
+  // provides W*H*6 bytes).  The vector memory is copied at every call's start (a few KB); the rest - models, the live generation's
+  // dense tables, the previous frame - only when a chunk's packets MAY not fit (2 bytes per coder entry + 4 per block + headers
+  // against the room left), or at the start of a call of several frames whose buffer is below the closed-form worst case.
+  DevBuf snap_mvs, snap_state;
+  bool snap_taken = false;
+  size_t snap_tables = 0;
+  int dbg_inject = 0;  // scpr_debug_inject: tests make the next compress call fail at a chosen place
 };
+struct EncHostState {  // the host half of that
+  u32 frames_done, last_flat_rgb, live_stamp, next_stamp;
+  bool last_flat, live_valid, live_has_state;
+  int live_buf;
+  size_t arena_used_bound, live_symbols;
+};
+static EncHostState host_state(const scpr_codec* c) {
+  return {c->frames_done, c->last_flat_rgb, c->live_stamp, c->next_stamp, c->last_flat, c->live_valid, c->live_has_state, c->live_buf, c->arena_used_bound, c->live_symbols};
+}
+static void set_host_state(scpr_codec* c, const EncHostState& h) {
+  c->frames_done = h.frames_done, c->last_flat_rgb = h.last_flat_rgb, c->live_stamp = h.live_stamp, c->next_stamp = h.next_stamp, c->last_flat = h.last_flat;
+  c->live_valid = h.live_valid, c->live_has_state = h.live_has_state, c->live_buf = h.live_buf, c->arena_used_bound = h.arena_used_bound, c->live_symbols = h.live_symbols;
+}
 
 static void stage_begin(scpr_codec* c, int s, hipStream_t on = nullptr) {
   if (!c->ev_used[s]) (void)hipEventRecord(c->ev[s][0], on ? on : c->stream);
@@ -333,7 +355,9 @@ static int ensure_codec(scpr_codec* c, int version) {  // CreateCodec + CScreenC
     // written to a slot (pack kernels, decoder) writes its rows whole, padding included - clearing all planes was 1.9 GB per Init
     // for a codec that had held 300 frames of 1080p.  A new geometry clears them all: the slack between rows and planes sits
     // elsewhere.
-    const bool same_geom = c->planes_stride == g.plane_stride && c->planes_S == g.S;
+    // (the SAME picture size: equal strides are shared by other sizes - W = 3 and 4 both have S = 12 - whose row padding, trailing
+    // rows and the slack behind a plane then hold the old picture's pixels)
+    const bool same_geom = c->planes_stride == g.plane_stride && c->planes_S == g.S && c->planes_W == g.W && c->planes_H == g.H;
     HIPCHK(hipMemsetAsync(c->planes.as<u8>() + (same_geom ? c->plane_slots * (size_t)g.plane_stride : 0), 0,
                           (same_geom ? 1 : c->plane_slots + 1) * (size_t)g.plane_stride, c->stream));
   } else {
@@ -379,6 +403,8 @@ static int ensure_codec(scpr_codec* c, int version) {  // CreateCodec + CScreenC
   setup_loss(c, (int)p.loss);
   c->planes_stride = g.plane_stride;
   c->planes_S = g.S;
+  c->planes_W = g.W;
+  c->planes_H = g.H;
   c->have_codec = true;
   return SCPR_OK;
 }
@@ -407,6 +433,53 @@ static int compact_tables(scpr_codec* c, DevBuf& arena, DevBuf& other, DevBuf& t
   if (*top > first) HIPCHK(hipMemcpyAsync(arena.as<DenseTab>() + first, other.as<DenseTab>() + first, (size_t)(*top - first) * sizeof(DenseTab), hipMemcpyDeviceToDevice, st));
   return SCPR_OK;
 }
+// ---- a compress call that can be taken back (see scpr_codec::snap_state) --------------------------------------------------
+static size_t snap_fixed_bytes() { return 2 * 12 * sizeof(FixedPersist); }
+static size_t snap_misc_bytes() { return 2 * MC_COUNT * sizeof(FixedPersist); }
+static size_t snap_colour_bytes() { return 2 * (size_t)NCOLCTX * sizeof(ColState); }
+// the device half: models (both copies), the live generation's dense tables and the arena's top, the previous frame of the stream.
+// `hs` = the host state to go with it (the tables it counts are the ones copied).  Nothing of it has been touched by the call so
+// far when this runs: the chains, the arena and the previous-frame slot are only written after a chunk's totals are known.
+static int snap_take(scpr_codec* c, const EncHostState& hs) {
+  if (c->snap_taken) return SCPR_OK;
+  hipStream_t st = c->stream;
+  const size_t fb = snap_fixed_bytes(), mb = snap_misc_bytes(), cb = snap_colour_bytes(), pb = c->g.plane_stride;
+  const size_t tabs = c->arena.p ? std::min<size_t>(hs.arena_used_bound, c->arena.cap / sizeof(DenseTab)) : 0;
+  HIPCHK(c->snap_state.reserve(fb + mb + cb + 16 + pb + tabs * sizeof(DenseTab)));
+  u8* q = c->snap_state.as<u8>();
+  HIPCHK(hipMemcpyAsync(q, c->fixed_persist.p, fb, hipMemcpyDeviceToDevice, st));
+  HIPCHK(hipMemcpyAsync(q + fb, c->misc_persist.p, mb, hipMemcpyDeviceToDevice, st));
+  HIPCHK(hipMemcpyAsync(q + fb + mb, c->colour_persist.p, cb, hipMemcpyDeviceToDevice, st));
+  HIPCHK(hipMemcpyAsync(q + fb + mb + cb, c->arena_top.p, 4, hipMemcpyDeviceToDevice, st));
+  HIPCHK(hipMemcpyAsync(q + fb + mb + cb + 16, c->planes.as<u8>() + (size_t)c->pslot * pb, pb, hipMemcpyDeviceToDevice, st));
+  if (tabs) HIPCHK(hipMemcpyAsync(q + fb + mb + cb + 16 + pb, c->arena.p, tabs * sizeof(DenseTab), hipMemcpyDeviceToDevice, st));
+  c->snap_tables = tabs;
+  c->snap_taken = true;
+  return SCPR_OK;
+}
+static int snap_restore(scpr_codec* c, const EncHostState& hs) {
+  hipStream_t st = c->stream;
+  const int nblk = ((c->g.W + 15) / 16) * ((c->g.H + 15) / 16);
+  HIPCHK(hipStreamSynchronize(c->stream2));
+  HIPCHK(hipMemcpyAsync(c->mvs.p, c->snap_mvs.p, (size_t)nblk * 4, hipMemcpyDeviceToDevice, st));
+  if (c->snap_taken) {
+    const size_t fb = snap_fixed_bytes(), mb = snap_misc_bytes(), cb = snap_colour_bytes(), pb = c->g.plane_stride;
+    const u8* q = c->snap_state.as<u8>();
+    HIPCHK(hipMemcpyAsync(c->fixed_persist.p, q, fb, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(c->misc_persist.p, q + fb, mb, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(c->colour_persist.p, q + fb + mb, cb, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(c->arena_top.p, q + fb + mb + cb, 4, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(c->planes.as<u8>() + (size_t)c->pslot * pb, q + fb + mb + cb + 16, pb, hipMemcpyDeviceToDevice, st));  // (ensure_planes carries this slot along when the planes grow)
+    if (c->snap_tables) HIPCHK(hipMemcpyAsync(c->arena.p, q + fb + mb + cb + 16 + pb, c->snap_tables * sizeof(DenseTab), hipMemcpyDeviceToDevice, st));
+  }
+  HIPCHK(sync_out(c, st));
+  set_host_state(c, hs);
+  return SCPR_OK;
+}
+// the most a frame's packet can take: header, at most 2 bytes per coder entry (a 12-bit interval moves the 31-bit state by at most
+// 12 bits, bytes leave it 8 at a time: ransmt.h:120 sizes its scratch the same way), 4 bytes of state per block of 131072 entries
+static u64 packet_bound(u32 hdr_len, u64 nsyms) { return (u64)hdr_len + 2 * nsyms + 4 * ((nsyms + kBlockEntries - 1) / kBlockEntries); }
+
 // Block compare and motion search of the P-frames `pfr` of a chunk (DecideBlockTypes / FindMV, screencap.cpp:928-1087, :684-814):
 // leaves binfo / btype / bmv / pinfo for the symbol stages and the vector memory mvs[] as the reference leaves it.  Shared by
 // the encoder and by scpr_motion_prepass, which needs nothing else of a P-frame.
@@ -479,13 +552,14 @@ static int fixed_chains(scpr_codec* c, hipStream_t s2, FixBufs& fb, const u32* e
   (void)c;
   return SCPR_OK;
 }
-static u64 chunk_total_limit() {  // SCPR_DEBUG_CHUNK_LIMIT: tests reach the re-cut of a chunk with small frames
-  static const u64 v = getenv("SCPR_DEBUG_CHUNK_LIMIT") ? strtoull(getenv("SCPR_DEBUG_CHUNK_LIMIT"), nullptr, 0) : kChunkTotalLimit;
-  return v;
+static u64 chunk_total_limit() {  // SCPR_DEBUG_CHUNK_LIMIT: tests reach the re-cut of a chunk with small frames (read per chunk: a test may set it)
+  const char* e = getenv("SCPR_DEBUG_CHUNK_LIMIT");
+  return e ? strtoull(e, nullptr, 0) : kChunkTotalLimit;
 }
 constexpr int kMaxChunkGens = 512;  // generations per encode chunk (see scpr_compress_batch)
 constexpr int kRecut = 1;  // encode_chunk: the chunk's symbol totals pass 32 bits - nothing has been coded, *nfit frames would fit
-static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int ngens, bool load_first, std::vector<FrameBase>& hb, std::vector<u32>& pchanged, int* nfit) {
+static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int ngens, bool load_first, std::vector<FrameBase>& hb, std::vector<u32>& pchanged, int* nfit, u64 room,
+                        const EncHostState& hs0) {
   const Geom& g = c->g;
   hipStream_t st = c->stream;
   const u8* planes = c->planes.as<u8>();
@@ -567,6 +641,14 @@ static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int n
   HIPCHK(sync_out(c, st));
   *nfit = (int)tot[4];
   if (*nfit < n) return kRecut;  // (the 32-bit bases of the frames past *nfit have wrapped: the caller cuts the chunk there)
+  {  // may the chunk's packets not fit?  Then the state the chains are about to change is kept first (nothing has changed it yet).
+    u64 bound = 0;
+    for (int i = 0; i < n; i++) bound += packet_bound(cf[i].hdr_len, cf[i].kind == 1 ? 0 : hb[i].nsyms);
+    if (bound > room) {
+      int rc = snap_take(c, hs0);
+      if (rc != SCPR_OK) return rc;
+    }
+  }
   const size_t Rtot = tot[0], Ttot = tot[1], Ctot = tot[2], Mtot = tot[3];
   const size_t nchains = (size_t)ngens * NCOLCTX;
   HIPCHK(c->runs.reserve(Rtot * 4 + 64));
@@ -637,7 +719,14 @@ static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int n
       HIPCHK(c->sorttmp.reserve(stmp));
       HIPCHK(rocprim::radix_sort_pairs(c->sorttmp.p, stmp, c->keys[0].as<u32>(), c->keys[1].as<u32>(), c->vals[0].as<u32>(), c->vals[1].as<u32>(), Ctot, 8, 22 + genbits, st));
     }
-    hipLaunchKernelGGL(k_chain_starts, dim3((unsigned)((Ctot + 256) / 256)), dim3(256), 0, st, c->keys[1].as<u32>(), (u32)Ctot, (u32)nchains, c->cstart.as<u32>());
+    // (tests: two keys of the sorted array change places - what rocPRIM's defect looks like from here)
+    if (c->dbg_inject == 2 && Ctot > 1) {
+      c->dbg_inject = 0;
+      hipLaunchKernelGGL(k_debug_swap, dim3(1), dim3(1), 0, st, c->keys[1].as<u32>(), 0u, (u32)Ctot - 1u);
+    }
+    // chain starts from the sorted keys - and the proof that they ARE sorted: a pair out of order sets bit 5 of the error word, which
+    // keeps the chain kernels from following chain lengths made of garbage (k_colour_chain_w, k_chain_lists) and ends the call
+    hipLaunchKernelGGL(k_chain_starts, dim3((unsigned)((Ctot + 256) / 256)), dim3(256), 0, st, c->keys[1].as<u32>(), (u32)Ctot, (u32)nchains, c->cstart.as<u32>(), c->err.as<u32>());
   }
   stage_end(c, ST_SORT);
   if (getenv("SCPR_DEBUG_KEYS") && Ctot) {
@@ -797,9 +886,10 @@ void scpr_deinit(scpr_codec* c) {  // ScreenCodec::Deinit, screencap.cpp:1619-16
 void scpr_destroy(scpr_codec* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  (void)sync_out(c, c->stream);
+  pin_reset(c);  // (read-backs a failed call left queued are dropped, not delivered: their destinations are gone)
+  (void)hipStreamSynchronize(c->stream);
   (void)hipStreamSynchronize(c->stream2);
-  DevBuf* all[] = {&c->planes, &c->tnmap, &c->exitmap, &c->entry, &c->runrec, &c->tilecnt, &c->tileoff, &c->hdrrec, &c->hdrcnt, &c->frametot, &c->flags, &c->slotlist, &c->genlist,
+  DevBuf* all[] = {&c->snap_mvs, &c->snap_state, &c->planes, &c->tnmap, &c->exitmap, &c->entry, &c->runrec, &c->tilecnt, &c->tileoff, &c->hdrrec, &c->hdrcnt, &c->frametot, &c->flags, &c->slotlist, &c->genlist,
                    &c->bases, &c->totals, &c->runs, &c->runpos, &c->keys[0], &c->keys[1], &c->vals[0], &c->vals[1], &c->cstart, &c->sorttmp,
                    &c->entries, &c->ranges, &c->rblocks, &c->rscratch, &c->rsize, &c->packets, &c->pktoff, &c->blkdst, &c->outsizes, &c->total64, &c->arena,
                    &c->arena_top, &c->err, &c->rcp, &c->decframes, &c->decstates, &c->hoststage_in, &c->hoststage_out, &c->chainlists, &c->chaincounts, &c->fixr.cnt, &c->fixr.off, &c->fixr.tot, &c->fixr.sym, &c->fixr.pos, &c->fixr.gen, &c->fixm.cnt, &c->fixm.off, &c->fixm.tot, &c->fixm.sym, &c->fixm.pos, &c->fixm.gen, &c->kinds, &c->pidx, &c->fidx, &c->pframes, &c->pflag, &c->binfo, &c->smv, &c->btype, &c->bmv, &c->bcnt, &c->boff, &c->bflag, &c->pinfo, &c->ptot, &c->pbase, &c->misc, &c->miscpos, &c->miscranges, &c->mvs, &c->mvs_keep, &c->fixed_persist, &c->misc_persist, &c->colour_persist, &c->decgops, &c->decfixed, &c->dec_fixed_persist, &c->dec_colour_persist, &c->dec_arena, &c->dec_arena2, &c->arena2, &c->dec_arena_top, &c->mvdict, &c->mvpre, &c->gmask};
@@ -817,6 +907,7 @@ void scpr_destroy(scpr_codec* c) {
 int scpr_set_cu_mask(scpr_codec* c, const uint32_t* mask, int words) {
   if (!c || words < 0 || (words > 0 && !mask)) return SCPR_E_PARAM;
   if (hipSetDevice(c->device) != hipSuccess) return SCPR_E_DEVICE;
+  pin_reset(c);
   HIPCHK(sync_out(c, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream2));
   hipStream_t a = nullptr, b = nullptr;
@@ -862,6 +953,7 @@ void scpr_crash_happened(scpr_codec* c) {
 int scpr_seed_shard(scpr_codec* c, uint32_t frames_before, int last_was_flat, uint32_t last_flat_rgb) {
   if (!c || !c->inited) return SCPR_E_PARAM;
   if (hipSetDevice(c->device) != hipSuccess) return SCPR_E_DEVICE;
+  pin_reset(c);
   int rc = ensure_codec(c, c->have_codec ? c->version : 4);
   if (rc != SCPR_OK) return rc;
   c->frames_done = frames_before;
@@ -885,6 +977,7 @@ int scpr_seed_shard(scpr_codec* c, uint32_t frames_before, int last_was_flat, ui
 int scpr_export_mv_memory(scpr_codec* c, int32_t* mx, int32_t* my) {
   if (!c || !c->inited || !mx || !my) return SCPR_E_PARAM;
   if (hipSetDevice(c->device) != hipSuccess) return SCPR_E_DEVICE;
+  pin_reset(c);
   int rc = ensure_codec(c, c->have_codec ? c->version : 4);
   if (rc != SCPR_OK) return rc;
   const int nblocks = ((c->g.W + 15) / 16) * ((c->g.H + 15) / 16);
@@ -898,6 +991,7 @@ int scpr_export_mv_memory(scpr_codec* c, int32_t* mx, int32_t* my) {
 int scpr_import_mv_memory(scpr_codec* c, const int32_t* mx, const int32_t* my) {
   if (!c || !c->inited || !mx || !my) return SCPR_E_PARAM;
   if (hipSetDevice(c->device) != hipSuccess) return SCPR_E_DEVICE;
+  pin_reset(c);
   int rc = ensure_codec(c, c->have_codec ? c->version : 4);
   if (rc != SCPR_OK) return rc;
   const int nblocks = ((c->g.W + 15) / 16) * ((c->g.H + 15) / 16);
@@ -1028,6 +1122,24 @@ int64_t scpr_compress_batch(scpr_codec* c, const void* d_frames, int nframes, in
   const size_t frame_bytes = (size_t)c->pitch_in * g.H;
   int64_t written = 0;
   HIPCHK(hipMemsetAsync(c->err.p, 0, 32, st));
+  // what the call would have to undo if its packets do not fit (scpr_codec::snap_state)
+  const EncHostState hs0 = host_state(c);
+  const std::vector<int> ftypes0(ftypes, ftypes + nframes);
+  c->snap_taken = false;
+  {
+    const size_t nblk0 = (size_t)((g.W + 15) / 16) * ((g.H + 15) / 16);
+    HIPCHK(c->snap_mvs.reserve(nblk0 * 4));
+    HIPCHK(hipMemcpyAsync(c->snap_mvs.p, c->mvs.p, nblk0 * 4, hipMemcpyDeviceToDevice, st));
+    // a call of several frames may be cut into chunks, and a later chunk cannot take back an earlier one's changes: kept now unless
+    // the buffer holds the worst case anyway (at most 5 coder entries per pixel + 16 per block: Appendix A of SURVEY.md)
+    const u64 worst = packet_bound(4, 5ull * g.NP + 16ull * nblk0 + 16);
+    if (nframes > 1 && (u64)out_capacity < worst * (u64)nframes && (rc = snap_take(c, hs0)) != SCPR_OK) return rc;
+  }
+  auto refuse = [&](int code) {  // the codec as the call found it
+    for (int i = 0; i < nframes; i++) ftypes[i] = ftypes0[i];
+    const int r2 = snap_restore(c, hs0);
+    return (int64_t)(r2 != SCPR_OK ? r2 : code);
+  };
   for (int f0 = 0, used = 0; f0 < nframes; f0 += used) {
     int n = std::min(c->slots, nframes - f0);  // (may shrink below: at most kMaxChunkGens generations per chunk)
     const int npacked = n;
@@ -1130,7 +1242,7 @@ int64_t scpr_compress_batch(scpr_codec* c, const void* d_frames, int nframes, in
         c->live_has_state = coded;
       }
       int nfit = n;
-      rc = encode_chunk(c, n, cf, ngens, load_first, hb, pchanged, &nfit);
+      rc = encode_chunk(c, n, cf, ngens, load_first, hb, pchanged, &nfit, (u64)(out_capacity - (size_t)written), hs0);
       if (rc == kRecut) {
         if (nfit < 1) return SCPR_E_DEVICE;  // (one frame always fits: 5 symbols per pixel of at most 8000 x 8191 pixels)
         c->frames_done = s_frames_done, c->last_flat_rgb = s_flat_rgb, c->last_flat = s_flat, c->live_valid = s_live_valid, c->live_has_state = s_live_has_state;
@@ -1141,9 +1253,6 @@ int64_t scpr_compress_batch(scpr_codec* c, const void* d_frames, int nframes, in
       if (rc != SCPR_OK) return rc;
       break;
     }
-    // the last plane of the chunk is the "previous frame" of the next call
-    HIPCHK(hipMemcpyAsync(c->planes.as<u8>() + (size_t)c->pslot * g.plane_stride, c->planes.as<u8>() + (size_t)(n - 1) * g.plane_stride, g.plane_stride, hipMemcpyDeviceToDevice, st));
-
     // rANS blocks and packets
     std::vector<RansBlock> blocks;
     std::vector<Packet> pk(n);
@@ -1180,7 +1289,7 @@ int64_t scpr_compress_batch(scpr_codec* c, const void* d_frames, int nframes, in
     if (nb) {
       stage_begin(c, ST_RANS);
       hipLaunchKernelGGL(k_rans, dim3((nb + 63) / 64), dim3(256), 0, st, c->entries.as<u32>(), c->rblocks.as<RansBlock>(), nb, c->rcp.as<RansRcp>(), c->rscratch.as<u8>(),
-                         c->rsize.as<u32>());
+                         c->rsize.as<u32>(), c->err.as<u32>());
       stage_end(c, ST_RANS);
     }
     stage_begin(c, ST_GATHER);
@@ -1195,11 +1304,21 @@ int64_t scpr_compress_batch(scpr_codec* c, const void* d_frames, int nframes, in
     HIPCHK(d2h(c, sizes + f0, c->outsizes.p, (size_t)n * 4, st));
     HIPCHK(d2h(c, &chunk_total, c->total64.p, 8, st));
     HIPCHK(d2h(c, &err, c->err.p, 4, st));
+    if (c->dbg_inject == 1) {  // (tests: a failure between a read-back and its hand-over - the pool then holds pointers into this frame)
+      c->dbg_inject = 0;
+      return SCPR_E_DEVICE;
+    }
     HIPCHK(sync_out(c, st));
     HIPCHK(hipGetLastError());  // a kernel that could not be launched (the launches themselves are not checked one by one)
     timing_collect(c);
+    if (err & 32) {
+      fprintf(stderr, "[scpr] the colour symbols came back from the radix sort out of order (rocPRIM; DESIGN.md 9): nothing was coded with them\n");
+      return SCPR_E_DEVICE;
+    }
+    if (err & 2) return refuse(SCPR_E_CAPACITY);  // (the bound said this could happen: the state was kept)
     c->arena_used_bound = atop;  // what the arena really holds: it does not grow with the number of calls
-    if (err & 2) return SCPR_E_CAPACITY;
+    // the last plane of the chunk is the "previous frame" of the next call
+    HIPCHK(hipMemcpyAsync(c->planes.as<u8>() + (size_t)c->pslot * g.plane_stride, c->planes.as<u8>() + (size_t)(n - 1) * g.plane_stride, g.plane_stride, hipMemcpyDeviceToDevice, st));
     if (err & 1) {
       fprintf(stderr, "[scpr] dense-table arena overflow\n");
       return SCPR_E_DEVICE;
@@ -1460,17 +1579,19 @@ int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* 
 int scpr_compress_frame(scpr_codec* c, const void* src, void* dst, int dst_len, int* ftype, int loss) {
   if (!c || !c->inited || !src || !dst || !ftype) return SCPR_E_PARAM;
   if (c->crashed) return 0;
+  if (dst_len < 0) return SCPR_E_PARAM;
   if (hipSetDevice(c->device) != hipSuccess) return SCPR_E_DEVICE;
+  pin_reset(c);
   int rc = ensure_codec(c, c->have_codec ? c->version : 4);
   if (rc != SCPR_OK) return rc;
-  const size_t fb = (size_t)c->pitch_in * c->g.H, cap = (size_t)c->g.W * c->g.H * 6 + 64;
+  // (the caller's room is the batch call's capacity: a packet that does not fit is refused there with the codec left as it was)
+  const size_t fb = (size_t)c->pitch_in * c->g.H, cap = std::min<size_t>((size_t)c->g.W * c->g.H * 6 + 64, (size_t)dst_len);
   HIPCHK(c->hoststage_in.reserve(fb));
-  HIPCHK(c->hoststage_out.reserve(cap));
+  HIPCHK(c->hoststage_out.reserve(cap + 64));
   HIPCHK(h2d(c, c->hoststage_in.p, src, fb, c->stream));
   uint32_t sz = 0;
   int64_t r = scpr_compress_batch(c, c->hoststage_in.p, 1, ftype, loss, c->hoststage_out.p, cap, &sz);
   if (r <= 0) return (int)r;
-  if ((int64_t)dst_len < r) return SCPR_E_CAPACITY;
   HIPCHK(hipMemcpy(dst, c->hoststage_out.p, (size_t)r, hipMemcpyDeviceToHost));
   return (int)r;
 }
@@ -1480,6 +1601,7 @@ int scpr_decompress_frame(scpr_codec* c, const void* src, int src_len, void* dst
   if (c->crashed && ftype > 0) return 0;
   if (!c->have_codec && ftype > 0) return 0;
   if (hipSetDevice(c->device) != hipSuccess) return SCPR_E_DEVICE;
+  pin_reset(c);
   const size_t ob = (size_t)pitch * c->prm.height;
   HIPCHK(c->hoststage_in.reserve((size_t)src_len + 64));
   HIPCHK(c->hoststage_out.reserve(ob));
@@ -1518,6 +1640,15 @@ extern "C" int scpr_debug_profile(unsigned long long* out) {
   return 24;
 }
 #endif
+#ifdef SCPR_PROFILE
+// design work only: colour symbols of the decoder by class since the last call (ticks, count) x 8 - scpr_wave.hpp, WaveDec::cls_end
+extern "C" int scpr_debug_cprof(unsigned long long* out) {
+  unsigned long long z[32] = {0};
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(scpr::g_cprof), sizeof z) != hipSuccess) return -1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(scpr::g_cprof), z, sizeof z) != hipSuccess) return -1;
+  return 32;
+}
+#endif
 int scpr_debug_colour_chain(int device, const uint8_t* syms, int n, int f0, uint16_t* out) {
   if (hipSetDevice(device) != hipSuccess) return SCPR_E_DEVICE;
   std::vector<u32> keys(n), vals(n);
@@ -1550,6 +1681,15 @@ int scpr_debug_colour_chain(int device, const uint8_t* syms, int n, int f0, uint
   HIPCHK(hipMemcpy(out, de.p, (size_t)n * 4, hipMemcpyDeviceToHost));
   for (DevBuf* b : {&dk, &dv, &dc, &dl, &dn, &de, &da, &dt}) b->release();
   return n;
+}
+
+// Test hook: the next scpr_compress_batch fails on purpose.  1: returns SCPR_E_DEVICE between the read-backs of its results and
+// their hand-over (what a HIP error there leaves behind); 2: two colour keys change places behind the radix sort (an unsorted
+// result, as rocPRIM's defect gives: the call must end with SCPR_E_DEVICE, not follow the chains).
+int scpr_debug_inject(scpr_codec* c, int what) {
+  if (!c) return SCPR_E_PARAM;
+  c->dbg_inject = what;
+  return SCPR_OK;
 }
 
 int scpr_debug_arena(scpr_codec* c, uint64_t* enc_bytes, uint64_t* dec_bytes) {

@@ -618,13 +618,25 @@ __device__ __forceinline__ void emit_colour(u32 gen, u32 pix, u32 prev_g, u32 pr
 // plane/context) is >= q, for q = 0 .. nchains (so cstart[nchains] = n).  One thread per sorted position plus a
 // sentinel; a thread fills the (usually empty) gap of chains between its predecessor and itself.  This replaces a
 // histogram of one global atomic per colour symbol, most of them on a handful of hot contexts.
-__global__ __launch_bounds__(256) void k_chain_starts(const u32* __restrict__ skeys, u32 n, u32 nchains, u32* __restrict__ cstart) {
+// The same pass proves the order it relies on (the sort is rocPRIM's, and rocPRIM 4.2 has returned unsorted output: DESIGN.md 9):
+// a key below its predecessor - or one that names no chain of this call - sets bit 5 of *err and writes nothing.
+__global__ __launch_bounds__(256) void k_chain_starts(const u32* __restrict__ skeys, u32 n, u32 nchains, u32* __restrict__ cstart, u32* __restrict__ err) {
   const u32 i = blockIdx.x * 256 + threadIdx.x;
   if (i > n) return;
   auto chain = [](u32 key) { return (key >> 22) * (u32)NCOLCTX + ((key >> 8) & 0x3FFFu); };
-  const u32 qi = i < n ? chain(skeys[i]) : nchains;
-  const u32 q0 = i > 0 ? chain(skeys[i - 1]) + 1 : 0u;
+  const u32 ki = i < n ? skeys[i] : 0u, kp = i > 0 ? skeys[i - 1] : 0u;
+  const u32 qi = i < n ? chain(ki) : nchains;
+  const u32 q0 = i > 0 ? chain(kp) + 1 : 0u;
+  if ((i > 0 && i < n && (ki >> 8) < (kp >> 8)) || qi > nchains) {
+    atomicOr(err, 32u);
+    return;
+  }
   for (u32 q = q0; q <= qi; q++) cstart[q] = i;
+}
+__global__ void k_debug_swap(u32* a, u32 i, u32 j) {  // scpr_debug_inject(2)
+  const u32 t = a[i];
+  a[i] = a[j];
+  a[j] = t;
 }
 
 // unified run list + colour symbols.  grid = (ntiles + 1, frames); the extra
@@ -788,7 +800,12 @@ __device__ __forceinline__ void rans_emit(u8* const base, u32& off, const uint2 
 }
 constexpr int RANS_TRIP = 32;  // entries per hand-over between the four waves (a barrier each: 16 -> 32 took the stage from 8.65 to 7.5 ms; 40 is slower again, the unrolled trip outgrows its registers)
 __global__ __launch_bounds__(256) void k_rans(const u32* __restrict__ entries, const RansBlock* __restrict__ blocks, int nblocks, const RansRcp* __restrict__ rcp_g,
-                                              u8* __restrict__ scratch, u32* __restrict__ blksize) {
+                                              u8* __restrict__ scratch, u32* __restrict__ blksize, const u32* __restrict__ err) {
+  if (*err & 32u) {  // the colour symbols were not sorted (k_chain_starts): their entries were never written - nothing to code
+    const int b0 = blockIdx.x * 64 + (int)threadIdx.x;
+    if (threadIdx.x < 64 && b0 < nblocks) blksize[b0] = 0;
+    return;
+  }
   __shared__ RansRcp lrcp[kProbScale + 1];          // reciprocals in LDS: the lookup is off the HBM path
   __shared__ uint4 rec[2][RANS_TRIP][64];           // feeders -> coder, two trips
   __shared__ uint2 hand[2][RANS_TRIP][64];          // coder -> writer, two trips

@@ -223,6 +223,7 @@ struct WaveModel {
   u32 dc_lds = 0;         // the cache's LDS offset (0: none)
 #ifdef SCPR_PROFILE
   u32 dmiss = 0;
+  u64 dmiss_ticks = 0;
 #endif
   __device__ __forceinline__ WaveModel(u16* tmp_, Arena a, int f0_) : lane(lane_id()), l15(lane_id() & 15), tmp(tmp_), arena(a), f0(f0_) {}
   template <bool DST_LDS>
@@ -244,6 +245,7 @@ struct WaveModel {
     if (SCPR_UNLIKELY(tag != idx + 1u)) {
 #ifdef SCPR_PROFILE
       dmiss++;
+      const u64 tm0 = __builtin_readcyclecounter();
 #endif
       if (SCPR_UNLIKELY(idx > arena.cap)) {  // beyond the sink: never a table (a record that is not what it says): reported, not followed
         glb_or_lane0(arena.err, 16u);
@@ -254,6 +256,10 @@ struct WaveModel {
       if (!fresh) copy_tab<true>(c, arena.tabs + idx, lane);
       dtag[slot] = idx + 1u;  // (every lane the same word: no lane mask, no branch)
       wave_fence();
+#ifdef SCPR_PROFILE
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      dmiss_ticks += __builtin_readcyclecounter() - tm0;
+#endif
     }
     return c;
   }
@@ -775,6 +781,7 @@ struct WaveModel {
 
 #ifdef SCPR_PROFILE
 __device__ u64 g_prof[24];
+__device__ u64 g_cprof[32];  // colour symbols by class: [2k] s_memtime ticks, [2k + 1] count - see WaveDec::cls_end
 // design aid (tools/profile_chains.py): one record per colour chain of 2048 symbols or more - length, cycles, final kind | d << 8,
 // symbols that took the general small-table path, symbols coded by the epoch-parallel dense path, raw symbols
 __device__ u32 g_chainrec[8192][8];
@@ -857,11 +864,37 @@ struct WaveDec : WaveModel {
     if (prof_last) prof[SEC] += t - prof_last;
     prof_last = t;
   }
+  // colour symbols by class (0 top entry of a small table, 1 another entry, 2 small table's general path, 3 dense hit, 4 dense
+  // general path, 5 raw, 6 record-cache miss [the miss alone, also inside its symbol's class], 7 dense-table cache miss [likewise])
+  u64 cprof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, cls_t0 = 0;
+  __device__ __forceinline__ void cls_begin() { cls_t0 = __builtin_readcyclecounter(); }
+  template <int K>
+  __device__ __forceinline__ void cls_end() {
+    cprof[2 * K] += __builtin_readcyclecounter() - cls_t0;
+    cprof[2 * K + 1]++;
+  }
+  // (a class that is only known at run time: a wave-uniform flag, both ways written out - no indexed register array)
+  template <int K0, int K1>
+  __device__ __forceinline__ void cls_end2(int second) {
+    const u64 dt = __builtin_readcyclecounter() - cls_t0;
+    if (rfl((u32)second)) cprof[2 * K1] += dt, cprof[2 * K1 + 1]++;
+    else cprof[2 * K0] += dt, cprof[2 * K0 + 1]++;
+  }
+  template <int K>
+  __device__ __forceinline__ void cls_add(u64 t) {
+    cprof[2 * K] += t;
+    cprof[2 * K + 1]++;
+  }
 #else
   template <int SEC>
   __device__ __forceinline__ void stamp() {}
   template <int EV>
   __device__ __forceinline__ void event() {}
+  __device__ __forceinline__ void cls_begin() {}
+  template <int K>
+  __device__ __forceinline__ void cls_end() {}
+  template <int K0, int K1>
+  __device__ __forceinline__ void cls_end2(int) {}
 #endif
   __device__ __forceinline__ void need(int k) {
     while (SCPR_UNLIKELY(nb < k)) {
@@ -1328,6 +1361,9 @@ struct WaveDec : WaveModel {
     asm volatile("" : "+s"(h0), "+s"(h1), "+s"(h2));
     if (SCPR_UNLIKELY(tag != (u32)ctxid)) {
       event<9>();
+#ifdef SCPR_PROFILE
+      const u64 tm0 = __builtin_readcyclecounter();
+#endif
       u32* r = L.crec[slot_of(ctxid)];
       {  // (the record's words by its first lanes, without a branch on the lane: masked stores, a load every lane can make)
         const int wl = min(lane, DECREC_WORDS - 1);
@@ -1341,6 +1377,9 @@ struct WaveDec : WaveModel {
       h0 = rfl(hw.x);
       h1 = rfl(hw.y);
       h2 = rfl(hw.z);
+#ifdef SCPR_PROFILE
+      cls_add<6>(__builtin_readcyclecounter() - tm0);
+#endif
     }
     hz = h2;  // (wave-uniform already)
   }
@@ -1462,6 +1501,7 @@ struct WaveDec : WaveModel {
     ColHdr h;
     u32 w, ra = 0, ea, h0, h1, hz;
     u32* r = nullptr;
+    cls_begin();
     if constexpr (MODE == 2) record<CHK, true>(ctxid, w, ea, h0, h1, hz, pend[0], pend[1], pend[2]);
     else record<CHK, false>(ctxid, w, ea, h0, h1, hz);
     event<8>();
@@ -1515,6 +1555,7 @@ struct WaveDec : WaveModel {
 asm volatile("ds_add_u32 %0, %1 offset:4" ::"v"(ea), "v"(ktop) : "memory");
         wave_fence();
         if constexpr (MODE == 0) count<CHK>();
+        cls_end<0>();
       } else {  // another entry, an unmet symbol, or a rescale is due
         header();
         h.top = hz;
@@ -1522,7 +1563,13 @@ asm volatile("ds_add_u32 %0, %1 offset:4" ::"v"(ea), "v"(ktop) : "memory");
         const int t = small_hit(h, w, (int)v, c, fr, cf);
         if (SCPR_UNLIKELY(t >= 0)) {
           event<12>();
+#ifdef SCPR_PROFILE
+          const u64 tm0 = __builtin_readcyclecounter();
+#endif
           c = small_op<true>(r, h, w, (int)v, fr, cf);
+#ifdef SCPR_PROFILE
+          cls_add<2>(__builtin_readcyclecounter() - tm0);
+#endif
         }
         if ((h.kind | 1) == 5) {  // still a small table: its top entry may have moved, or the counts before it have changed
           const u32 nt = small_top(h, w) | ((u32)h.fmax << 20);
@@ -1534,9 +1581,11 @@ asm volatile("ds_add_u32 %0, %1 offset:4" ::"v"(ea), "v"(ktop) : "memory");
         asm volatile("ds_write_b32 %0, %1 offset:16" ::"v"(ea), "v"(w) : "memory");
         wave_fence();
         tail();
+        cls_end<1>();
       }
     } else {
       header();
+
       h.fshift = (int)((h0 >> 16) & 15u);
       h.dense = hz;
 #ifdef SCPR_PROFILE
@@ -1560,15 +1609,24 @@ asm volatile("ds_add_u32 %0, %1 offset:4" ::"v"(ea), "v"(ktop) : "memory");
         }
         wave_fence();
         scalar_hdr(h);
+        cls_end<5>();
       } else {
         event<10>();
         const int t = PF ? dense_hit_p(h, w, (int)v, c, fr, cf) : dense_hit(h, w, (int)v, c, fr, cf);
         if (SCPR_UNLIKELY(t >= 0)) {
+#ifdef SCPR_PROFILE
+          const u64 tm0 = __builtin_readcyclecounter();
+#endif
           c = dense_op<true>(r, h, (int)v, fr, cf);
           scalar_hdr(h);
+#ifdef SCPR_PROFILE
+          cls_add<4>(__builtin_readcyclecounter() - tm0);
+#endif
         }
+        cls_end<3>();
       }
       tail();
+      
     }
     return c;
   }
@@ -2394,6 +2452,10 @@ __global__ __launch_bounds__(HAS_P ? 512 : 64) void k_decode_gop_w(const u8* __r
 #ifdef SCPR_PROFILE
   if (lane == 0)
     for (int i = 0; i < 24; i++) atomicAdd((unsigned long long*)&g_prof[i], (unsigned long long)(i == 15 ? D.dmiss : D.prof[i]));
+  if (lane == 0) {
+    D.cprof[14] += D.dmiss_ticks, D.cprof[15] += D.dmiss;
+    for (int i = 0; i < 16; i++) atomicAdd((unsigned long long*)&g_cprof[i], (unsigned long long)D.cprof[i]);
+  }
 #endif
 }
 
@@ -2444,6 +2506,7 @@ __global__ __launch_bounds__(64) void k_colour_chain_w(const u32* __restrict__ s
   __shared__ __attribute__((aligned(16))) DenseTab ltab;  // the chain's dense table while the context is of kind 6 or 7
   WaveModel M(tmp, arena, f0);
   const int lane = M.lane;
+  if (rfl(*arena.err) & 32u) return;  // the sorted keys are not sorted (k_chain_starts): the chain starts mean nothing
   u32 cn[CHAIN_CLASSES], n = 0;
 #pragma unroll
   for (int k = 0; k < CHAIN_CLASSES; k++) {

@@ -13,9 +13,15 @@ that starts at or after a repeated flat colour produces the single stream's byte
 block, the last vector found in ANY earlier frame (mvs[], screencap.cpp:96-97; read as "the vector of the block above",
 :726-735; never reset - RenewI :178-198 touches models only).  `handover_mv_memory` passes it down the ranks before
 anything is coded: rank r takes the memory rank r-1's shard leaves behind, runs the motion-only pre-pass over its own
-shard (scpr_motion_prepass: conversion, block compare, motion search - a few per cent of an encode) and passes the
-result on; then every rank imports what it received and all ranks code their shards side by side.  With (1)-(3) seeded
-a shard's packets are the single stream's packets.
+shard (scpr_motion_prepass: conversion, block compare, motion search) and passes the result on; then every rank imports
+what it received and all ranks code their shards side by side.  With (1)-(3) seeded a shard's packets are the single
+stream's packets.
+
+What the hand-over costs: the pre-pass is the motion stage of the encoder and that is about HALF of an I+P encode (measured:
+34 ms against 70 ms for 150 frames of 3840x2160; 21.5 of ~37 ms at 1080p), and the chain is serial - rank r waits
+for r pre-passes, so at N = 8 the last rank starts coding after ~7 x 34 ms, several encode-times.  It is real serial work
+inside the timed configs[3] step and grows linearly with N; bench.py reports it as its own field (`handover_ms`) so that the
+strong-scaling number can be read for what it is.
 """
 from __future__ import annotations
 
@@ -42,10 +48,18 @@ def shard_gops(ftypes_in, world: int) -> list[tuple[int, int]]:
     return [(cuts[r], cuts[r + 1]) for r in range(world)]
 
 
-def flat_colour(frame: np.ndarray, width: int, height: int, bpp: int):
+def flat_colour(frame: np.ndarray, width: int, height: int, bpp: int, masks=(0x7C00, 0x3E0, 0x1F)):
     """b0 | b1 << 8 | b2 << 16 of the picture's one colour, or None if it is not a flat picture (IsFlat,
-    screencap.cpp:1436-1444, on the colour bytes the codec sees: RGB32 drops byte 3, :1652-1664)"""
-    assert bpp in (24, 32), "flat-frame seeding is implemented for RGB32 / RGB24 input"
+    screencap.cpp:1436-1444, on the colour bytes the codec sees: RGB32 drops byte 3, :1652-1664; RGB16 is converted to
+    RGB24 with the caller's masks first, :1665-1678 - rows of width * 2 bytes back to back, :1668 - and the flat rule
+    :1488-1500 applies to what comes out)"""
+    assert bpp in (16, 24, 32)
+    if bpp == 16:
+        w16 = np.asarray(frame, dtype=np.uint8).reshape(-1)[: height * width * 2].view("<u2").astype(np.uint32)
+        sh = [next((k for k in range(16) if (m >> k) & 1), 16) for m in masks]  # ScreenCodec::Init's shifts, screencap.cpp:1572-1583
+        c = [(w16 & np.uint32(m)) >> np.uint32(q) if q < 16 else np.zeros_like(w16) for m, q in zip(masks, sh)]
+        v = (c[0] & 255) | ((c[1] & 255) << 8) | ((c[2] & 255) << 16)
+        return int(v[0]) if (v == v[0]).all() else None
     px = bpp // 8
     pitch = width * 4 if bpp == 32 else (width * 3 + 3) & ~3
     rows = np.asarray(frame, dtype=np.uint8).reshape(height, pitch)[:, : width * px].reshape(height, width, px)[..., :3]
@@ -55,18 +69,18 @@ def flat_colour(frame: np.ndarray, width: int, height: int, bpp: int):
     return int(c[0]) | (int(c[1]) << 8) | (int(c[2]) << 16)
 
 
-def shard_seed(get_frame, lo: int, width: int, height: int, bpp: int):
+def shard_seed(get_frame, lo: int, width: int, height: int, bpp: int, masks=(0x7C00, 0x3E0, 0x1F)):
     """Arguments of scpr_seed_shard / ScreenCodec.SeedShard for a shard whose first frame is `lo` of the stream:
     (frames_before, last_was_flat, last_flat_rgb).  `get_frame(t)` returns input frame t; only the frames right
     before the cut are looked at (one, unless they are flat).  GOPs share nothing else except the motion-vector
     memory (module docstring)."""
     if lo <= 0:
         return 0, False, 0
-    last = flat_colour(get_frame(lo - 1), width, height, bpp)
+    last = flat_colour(get_frame(lo - 1), width, height, bpp, masks)
     # fn counts coded (non-flat) frames only (flat frames return before fn++, screencap.cpp:1488-1500)
     coded, t = 0, lo - 1
     while t >= 0 and coded == 0:
-        coded += flat_colour(get_frame(t), width, height, bpp) is None
+        coded += flat_colour(get_frame(t), width, height, bpp, masks) is None
         t -= 1
     return coded, last is not None, (last or 0)
 

@@ -461,3 +461,34 @@ def test_bench_launcher_names_the_rank_that_died():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--selftest-launcher"], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode != 0 and time.time() - t0 < 120
     assert "rank 1 of 2 exited with code 3" in r.stderr and "gives up before the rendezvous" in r.stderr, r.stderr[-2000:]
+
+
+def test_rgb16_shard_starting_on_a_repeated_flat_colour_equals_the_single_stream():
+    """The flat rule (screencap.cpp:1488-1500) applies to RGB16 input AFTER its conversion to RGB24 (:1665-1678): two
+    16-bit pictures that differ only in bits outside the colour masks are the same flat picture, and the seed's colour is the
+    converted one.  Odd width: RGB16 rows are read back to back (:1668)."""
+    import oracle_api as O
+    from screenpressor_amd.sharding import flat_colour, shard_gops, shard_seed
+    w, h = 33, 18
+    rng = np.random.default_rng(6)
+
+    def pic(words):
+        return np.ascontiguousarray(words, dtype="<u2").view(np.uint8).reshape(-1)
+    busy = [pic(rng.integers(0, 0x8000, (h, w))) for _ in range(4)]
+    flat_a = pic(np.full((h, w), 0x2A5F))
+    flat_b = pic(np.full((h, w), 0x2A5F | 0x8000))  # bit 15 is in none of the 5-5-5 masks: the same picture to the codec
+    assert flat_colour(flat_a, w, h, 16) == flat_colour(flat_b, w, h, 16) == (0x0A | (0x12 << 8) | (0x1F << 16))
+    assert flat_colour(busy[0], w, h, 16) is None
+    frames = [busy[0], busy[0], flat_a, flat_b, busy[1], busy[2], flat_a, busy[3]]
+    ft_in = [0, 1, 1, 0, 1, 1, 1, 1]
+    assert shard_gops(ft_in, 2) == [(0, 3), (3, 8)]
+    one = O.OracleCodec(w, h, 16)
+    single = [one.compress(f, key=(k == 0)) for f, k in zip(frames, ft_in)]
+    assert len(single[3][0]) == 4 and single[4][1] == 1  # the repeated flat frame, then a P-frame
+    got = []
+    for lo, hi in shard_gops(ft_in, 2):
+        enc = O.OracleCodec(w, h, 16)
+        if lo:
+            enc.seed_shard(*shard_seed(lambda t: frames[t], lo, w, h, 16))
+        got += [enc.compress(frames[t], key=(ft_in[t] == 0)) for t in range(lo, hi)]
+    assert got == single

@@ -11,6 +11,9 @@ R=$PWD
 OUT=$R/gpurun_out/prof/$TAG
 rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
+# what these profiles are profiles OF: the digest of the kernel sources on this box, and when (bench.py quotes the HBM traffic only
+# while its own sources still have this digest)
+python3 -c "import sys, datetime; sys.path.insert(0, '$R'); import bench; print(bench.csrc_digest()); print(datetime.datetime.utcnow().strftime('%Y-%m-%dT%H:%MZ'))" > $OUT/csrc_sha256.txt
 cd /tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/stats -o run --output-format csv -- python3 $R/bench.py --no-others --steps 3 --warmup 1 --cpu-frames 24 > $OUT/bench_stats.log 2>&1
 echo stats done

@@ -57,4 +57,24 @@ for nm, x in zip(names, v):
 for nm, x in zip(["colour symbols", "record cache misses", "dense-table symbols", "raw symbols", "small-table slow path", "runs", "literal runs", "dense-table cache misses"], ev):
     print("%-50s %.0f per frame" % (nm, x / n))
 print("dense fast-path hits per frame: %.0f; small-table hits on the top entry: %.0f, in one-symbol tables: %.0f" % (ex[0] / n, ex[1] / n, ex[2] / n))
+cp = (C.c_ulonglong * 32)()
+if hasattr(L, "scpr_debug_cprof") or True:
+    L.scpr_debug_cprof(cp)
+    cpv = list(cp)
+    cls_names = ["top entry of a small table", "small table, any other way (whole symbol)", "[of which: small_op alone, the general path]", "dense table (whole symbol but the tail)", "[of which: dense_op alone, the general path]",
+                 "raw byte, kinds 0-3 (but the tail)", "[record-cache miss alone]", "[dense-table cache miss alone]"]
+    print("colour symbols by class (ticks include the record fetch; a miss is also inside its symbol's class):")
+    classes = {}
+    for k, nm in enumerate(cls_names):
+        t, cnt = cpv[2 * k], cpv[2 * k + 1]
+        if cnt:
+            print("  %-48s %9.0f per frame x %7.0f ticks = %10.0f ticks/frame" % (nm, cnt / n, t / cnt, t / n))
+            classes[nm] = {"per_frame": cnt / n, "ticks_each": t / cnt, "ticks_per_frame": t / n}
+    if os.environ.get("SCPR_PROFILE_JSON"):
+        import json
+        json.dump({"argv": sys.argv[1:], "frames_profiled": n, "ticks_per_frame": tot / n,
+                   "sections_ticks_per_frame": {nm: x / n for nm, x in zip(names, v) if x},
+                   "events_per_frame": {nm: x / n for nm, x in zip(["colour symbols", "record cache misses", "dense-table symbols", "raw symbols", "small-table slow path", "runs", "literal runs", "dense-table cache misses"], ev)},
+                   "extra_ticks_per_frame": {"rect write-back": ex[3] / n, "motion blocks": ex[4] / n, "run length end to end of single-row fill": ex[5] / n, "general fills": ex[6] / n},
+                   "colour_classes": classes}, open(os.environ["SCPR_PROFILE_JSON"], "w"), indent=1)
 print("P-frame, more sections (ticks/frame): rect write-back %.0f, motion blocks (symbols, hand-over) %.0f; after the run length to the end of the single-row fill %.0f, general fills %.0f ('runs' above is then the loop between runs)" % (ex[3] / n, ex[4] / n, ex[5] / n, ex[6] / n))
