@@ -104,6 +104,31 @@ int64_t scpr_compress_batch(scpr_codec* c, const void* d_frames, int nframes, in
 int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* sizes, const int* ftypes,
                           int nframes, void* d_frames_out, int pitch);
 
+/* ---- batch entry points with HOST pointers (an addition) --------------------
+ * The reference's boundary hands over host memory (ScreenCodec::CompressFrame,
+ * screencap.cpp:1632: pSrc / pDst; DecompressFrame, :1695).  These are the two
+ * batch calls in that shape - same arguments, same results, same state rules,
+ * h_* pointing to host memory - with the PCIe crossings taken BESIDE the kernels:
+ *   compress:   the frames come over in sub-batches on a copy stream (sub-batch
+ *               k + 1 while k is coded); the packets, ~1 % of the frames, are
+ *               written by the gather kernel straight into h_out.
+ *   decompress: the packets go over first; the chain of every coded key frame
+ *               sends each finished row to h_frames_out itself (RGB32 output of
+ *               version 3 / 4 streams), so the pictures cross while the chains
+ *               run; P-frames, flat frames and the other pixel formats are
+ *               unpacked into h_frames_out by kernels once their GOPs are done.
+ * Host memory the HIP runtime does not know (malloc, numpy) is registered with it
+ * on first use (hipHostRegister: pinned and mapped) and stays so until
+ * scpr_destroy: reuse the buffers.  Memory that is pinned already (hipHostMalloc,
+ * torch pin_memory) is used as it is.  Memory that cannot be registered goes
+ * through staging copies (same results, no overlap).
+ * scpr_compress_batch_host is taken back whole on SCPR_E_CAPACITY, like
+ * scpr_compress_batch. */
+int64_t scpr_compress_batch_host(scpr_codec* c, const void* h_frames, int nframes, int* ftypes, int loss,
+                                 void* h_out, size_t out_capacity, uint32_t* sizes);
+int scpr_decompress_batch_host(scpr_codec* c, const void* h_packets, const uint32_t* sizes, const int* ftypes,
+                               int nframes, void* h_frames_out, int pitch);
+
 /* ---- sharding support (an addition) ----------------------------------------
  * GOPs are independent except for what CScreenCapt keeps ACROSS key frames:
  * `fn > 0` (a frame has been coded: P-frames are allowed, screencap.cpp:1504)

@@ -17,7 +17,7 @@ _LIB_PATH = os.environ.get("SCPR_AMD_LIB", os.path.join(_PKG, "libscpr_amd.so"))
 
 SCPR_OK, SCPR_E_DEVICE, SCPR_E_PARAM, SCPR_E_BAD_VERSION, SCPR_E_CAPACITY, SCPR_E_STREAM = 0, -1, -2, -3, -4, -5
 EXPORTS = ["scpr_create", "scpr_destroy", "scpr_init", "scpr_deinit", "scpr_crash_happened", "scpr_compress_frame",
-           "scpr_decompress_frame", "scpr_compress_batch", "scpr_decompress_batch", "scpr_last_timing", "scpr_stage_name",
+           "scpr_decompress_frame", "scpr_compress_batch", "scpr_decompress_batch", "scpr_compress_batch_host", "scpr_decompress_batch_host", "scpr_last_timing", "scpr_stage_name",
            "scpr_seed_shard", "scpr_export_mv_memory", "scpr_import_mv_memory", "scpr_motion_prepass", "scpr_set_cu_mask", "scpr_debug_entries", "scpr_debug_arena", "scpr_debug_colour_chain", "scpr_debug_inject", "scpr_version",
            # include/scpr_driver.h, include/scpr_avi.h
            "scpr_driver_open", "scpr_driver_close", "scpr_driver_configure", "scpr_driver_compress_query", "scpr_driver_compress_get_format",
@@ -65,6 +65,9 @@ def load_library() -> C.CDLL:
         L.scpr_compress_batch.restype = C.c_int64
         L.scpr_compress_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32)]
         L.scpr_decompress_batch.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_int), C.c_int, C.c_void_p, C.c_int]
+        L.scpr_compress_batch_host.restype = C.c_int64
+        L.scpr_compress_batch_host.argtypes = L.scpr_compress_batch.argtypes
+        L.scpr_decompress_batch_host.argtypes = L.scpr_decompress_batch.argtypes
         L.scpr_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int]
         L.scpr_stage_name.restype = C.c_char_p
         L.scpr_stage_name.argtypes = [C.c_int]
@@ -240,6 +243,46 @@ class ScreenCodec:
         if sync:  # (see CompressBatch)
             torch.cuda.synchronize(packets.device)
         r = self._check(self._L.scpr_decompress_batch(self._h, C.c_void_p(packets.data_ptr()), sz, ft, n, C.c_void_p(out.data_ptr()), pitch))
+        return r, out
+
+    # the batch calls with HOST memory (numpy arrays or CPU torch tensors, pinned or not): the reference's boundary hands over host
+    # pointers (screencap.cpp:1632, :1695); the transfers run beside the kernels (scpr_compress_batch_host / scpr_decompress_batch_host)
+    @staticmethod
+    def _host_ptr(a):
+        if isinstance(a, np.ndarray):
+            assert a.dtype == np.uint8 and a.flags["C_CONTIGUOUS"]
+            return a.ctypes.data, a.size
+        assert not a.is_cuda and a.is_contiguous() and a.element_size() == 1  # a CPU torch tensor
+        return a.data_ptr(), a.numel()
+
+    def CompressBatchHost(self, frames, ftypes, loss: int | None = None, out=None):
+        """frames: n * frame_bytes bytes of host memory; out: host buffer for the packets (default: a numpy array of the safe size).
+        Returns (packets: the used part of `out`, sizes, ftypes produced)."""
+        n = len(ftypes)
+        ptr, nbytes = self._host_ptr(frames)
+        assert nbytes == n * self.frame_bytes, (nbytes, n, self.frame_bytes)
+        if out is None:
+            out = np.empty(min(n * self.max_packet, max(64 << 20, n * (self.width * self.height * 4 + 1024))), dtype=np.uint8)
+        optr, ocap = self._host_ptr(out)
+        ft = (C.c_int * n)(*[int(x) for x in ftypes])
+        sizes = (C.c_uint32 * n)()
+        total = self._check(self._L.scpr_compress_batch_host(self._h, C.c_void_p(ptr), n, ft, self.loss if loss is None else loss, C.c_void_p(optr), ocap, sizes))
+        return out[:total], np.frombuffer(sizes, dtype=np.uint32).copy(), list(ft)
+
+    def DecompressBatchHost(self, packets, sizes, ftypes, pitch: int | None = None, out=None):
+        """packets: host memory (exactly sum(sizes) bytes or more); out: host buffer for n frames of `pitch`-byte rows (default: numpy).
+        Returns (frames decoded, out)."""
+        n = len(sizes)
+        pitch = self.pitch if pitch is None else pitch
+        ptr, nbytes = self._host_ptr(packets)
+        assert nbytes >= int(np.sum(sizes))
+        if out is None:
+            out = np.empty(n * pitch * self.height, dtype=np.uint8)
+        optr, ocap = self._host_ptr(out)
+        assert ocap >= n * pitch * self.height
+        sz = (C.c_uint32 * n)(*[int(x) for x in sizes])
+        ft = (C.c_int * n)(*[int(x) for x in ftypes])
+        r = self._check(self._L.scpr_decompress_batch_host(self._h, C.c_void_p(ptr), sz, ft, n, C.c_void_p(optr), pitch))
         return r, out
 
     def last_timing(self):

@@ -166,6 +166,17 @@ struct scpr_codec {
   bool snap_taken = false;
   size_t snap_tables = 0;
   int dbg_inject = 0;  // scpr_debug_inject: tests make the next compress call fail at a chosen place
+  // the host-pointer batch calls (scpr_compress_batch_host / scpr_decompress_batch_host): a stream of its own for the copies that
+  // run beside the kernels, staging on the device for two sub-batches of frames, and the host ranges this codec has registered
+  // with the runtime (hipHostRegister: pinned and mapped into the device's address space; released by scpr_destroy)
+  hipStream_t stream3 = nullptr;
+  hipEvent_t ev_in[2] = {nullptr, nullptr};
+  DevBuf hb_frames, hb_packets, hb_list;
+  struct HostRange {
+    void* base;
+    size_t bytes;
+  };
+  std::vector<HostRange> host_ranges;
 };
 struct EncHostState {  // the host half of that
   u32 frames_done, last_flat_rgb, live_stamp, next_stamp;
@@ -889,7 +900,14 @@ void scpr_destroy(scpr_codec* c) {
   pin_reset(c);  // (read-backs a failed call left queued are dropped, not delivered: their destinations are gone)
   (void)hipStreamSynchronize(c->stream);
   (void)hipStreamSynchronize(c->stream2);
-  DevBuf* all[] = {&c->snap_mvs, &c->snap_state, &c->planes, &c->tnmap, &c->exitmap, &c->entry, &c->runrec, &c->tilecnt, &c->tileoff, &c->hdrrec, &c->hdrcnt, &c->frametot, &c->flags, &c->slotlist, &c->genlist,
+  for (const auto& r : c->host_ranges) (void)hipHostUnregister(r.base);
+  c->host_ranges.clear();
+  if (c->stream3) {
+    (void)hipStreamSynchronize(c->stream3);
+    (void)hipStreamDestroy(c->stream3);
+    for (int k = 0; k < 2; k++) (void)hipEventDestroy(c->ev_in[k]);
+  }
+  DevBuf* all[] = {&c->hb_frames, &c->hb_packets, &c->hb_list, &c->snap_mvs, &c->snap_state, &c->planes, &c->tnmap, &c->exitmap, &c->entry, &c->runrec, &c->tilecnt, &c->tileoff, &c->hdrrec, &c->hdrcnt, &c->frametot, &c->flags, &c->slotlist, &c->genlist,
                    &c->bases, &c->totals, &c->runs, &c->runpos, &c->keys[0], &c->keys[1], &c->vals[0], &c->vals[1], &c->cstart, &c->sorttmp,
                    &c->entries, &c->ranges, &c->rblocks, &c->rscratch, &c->rsize, &c->packets, &c->pktoff, &c->blkdst, &c->outsizes, &c->total64, &c->arena,
                    &c->arena_top, &c->err, &c->rcp, &c->decframes, &c->decstates, &c->hoststage_in, &c->hoststage_out, &c->chainlists, &c->chaincounts, &c->fixr.cnt, &c->fixr.off, &c->fixr.tot, &c->fixr.sym, &c->fixr.pos, &c->fixr.gen, &c->fixm.cnt, &c->fixm.off, &c->fixm.tot, &c->fixm.sym, &c->fixm.pos, &c->fixm.gen, &c->kinds, &c->pidx, &c->fidx, &c->pframes, &c->pflag, &c->binfo, &c->smv, &c->btype, &c->bmv, &c->bcnt, &c->boff, &c->bflag, &c->pinfo, &c->ptot, &c->pbase, &c->misc, &c->miscpos, &c->miscranges, &c->mvs, &c->mvs_keep, &c->fixed_persist, &c->misc_persist, &c->colour_persist, &c->decgops, &c->decfixed, &c->dec_fixed_persist, &c->dec_colour_persist, &c->dec_arena, &c->dec_arena2, &c->arena2, &c->dec_arena_top, &c->mvdict, &c->mvpre, &c->gmask};
@@ -1107,39 +1125,41 @@ int scpr_motion_prepass(scpr_codec* c, const void* d_frames, int nframes, const 
   return nblocks;
 }
 
-int64_t scpr_compress_batch(scpr_codec* c, const void* d_frames, int nframes, int* ftypes, int loss, void* d_out, size_t out_capacity, uint32_t* sizes) {
-  if (!c || !c->inited || !d_frames || !ftypes || !d_out || !sizes || nframes < 0) return SCPR_E_PARAM;
-  if (c->crashed) return 0;  // screencap.cpp:1634
-  if (hipSetDevice(c->device) != hipSuccess) return SCPR_E_DEVICE;
-  pin_reset(c);
-  if (c->have_codec && c->version == 2) return SCPR_E_BAD_VERSION;  // a codec that has decoded version 2 cannot encode (no version 2 encoder here)
-  int rc = ensure_codec(c, c->have_codec ? c->version : 4);  // the encoder always writes v4 (screencap.cpp:1646-1648)
-  if (rc != SCPR_OK) return rc;
-  if (loss != c->last_loss) setup_loss(c, loss);
-  timing_reset(c);
+// A compress call that can be taken back: txn_begin() at its start (host state kept, vector memory copied, and - a call of several
+// frames whose buffer is below the closed-form worst case - the device state too: such a call may be cut into chunks, and a later
+// chunk cannot take back an earlier one's changes), compress_core() once or, for the host-pointer form, once per sub-batch, and
+// txn_refuse() when the core says SCPR_E_CAPACITY.
+struct EncTxn {
+  EncHostState hs0;
+  std::vector<int> ftypes0;
+};
+static int txn_begin(scpr_codec* c, EncTxn& t, const int* ftypes, int nframes, size_t out_capacity) {
+  const Geom& g = c->g;
+  t.hs0 = host_state(c);
+  t.ftypes0.assign(ftypes, ftypes + nframes);
+  c->snap_taken = false;
+  const size_t nblk0 = (size_t)((g.W + 15) / 16) * ((g.H + 15) / 16);
+  HIPCHK(c->snap_mvs.reserve(nblk0 * 4));
+  HIPCHK(hipMemcpyAsync(c->snap_mvs.p, c->mvs.p, nblk0 * 4, hipMemcpyDeviceToDevice, c->stream));
+  // (at most 5 coder entries per pixel + 16 per block: Appendix A of SURVEY.md)
+  const u64 worst = packet_bound(4, 5ull * g.NP + 16ull * nblk0 + 16);
+  if (nframes > 1 && (u64)out_capacity < worst * (u64)nframes) return snap_take(c, t.hs0);
+  return SCPR_OK;
+}
+static int64_t txn_refuse(scpr_codec* c, const EncTxn& t, int* ftypes, int code) {  // the codec as the call found it
+  for (size_t i = 0; i < t.ftypes0.size(); i++) ftypes[i] = t.ftypes0[i];
+  const int r2 = snap_restore(c, t.hs0);
+  return (int64_t)(r2 != SCPR_OK ? r2 : code);
+}
+// frames resident on the device -> packets at d_out (device memory, or host memory mapped into the device's address space).
+// Returns the bytes written, or < 0; SCPR_E_CAPACITY leaves the taking back to the caller (txn_refuse).
+static int64_t compress_core(scpr_codec* c, const void* d_frames, int nframes, int* ftypes, void* d_out, size_t out_capacity, uint32_t* sizes, const EncHostState& hs0) {
+  int rc = SCPR_OK;
   const Geom& g = c->g;
   hipStream_t st = c->stream;
   const size_t frame_bytes = (size_t)c->pitch_in * g.H;
   int64_t written = 0;
   HIPCHK(hipMemsetAsync(c->err.p, 0, 32, st));
-  // what the call would have to undo if its packets do not fit (scpr_codec::snap_state)
-  const EncHostState hs0 = host_state(c);
-  const std::vector<int> ftypes0(ftypes, ftypes + nframes);
-  c->snap_taken = false;
-  {
-    const size_t nblk0 = (size_t)((g.W + 15) / 16) * ((g.H + 15) / 16);
-    HIPCHK(c->snap_mvs.reserve(nblk0 * 4));
-    HIPCHK(hipMemcpyAsync(c->snap_mvs.p, c->mvs.p, nblk0 * 4, hipMemcpyDeviceToDevice, st));
-    // a call of several frames may be cut into chunks, and a later chunk cannot take back an earlier one's changes: kept now unless
-    // the buffer holds the worst case anyway (at most 5 coder entries per pixel + 16 per block: Appendix A of SURVEY.md)
-    const u64 worst = packet_bound(4, 5ull * g.NP + 16ull * nblk0 + 16);
-    if (nframes > 1 && (u64)out_capacity < worst * (u64)nframes && (rc = snap_take(c, hs0)) != SCPR_OK) return rc;
-  }
-  auto refuse = [&](int code) {  // the codec as the call found it
-    for (int i = 0; i < nframes; i++) ftypes[i] = ftypes0[i];
-    const int r2 = snap_restore(c, hs0);
-    return (int64_t)(r2 != SCPR_OK ? r2 : code);
-  };
   for (int f0 = 0, used = 0; f0 < nframes; f0 += used) {
     int n = std::min(c->slots, nframes - f0);  // (may shrink below: at most kMaxChunkGens generations per chunk)
     const int npacked = n;
@@ -1315,7 +1335,7 @@ int64_t scpr_compress_batch(scpr_codec* c, const void* d_frames, int nframes, in
       fprintf(stderr, "[scpr] the colour symbols came back from the radix sort out of order (rocPRIM; DESIGN.md 9): nothing was coded with them\n");
       return SCPR_E_DEVICE;
     }
-    if (err & 2) return refuse(SCPR_E_CAPACITY);  // (the bound said this could happen: the state was kept)
+    if (err & 2) return SCPR_E_CAPACITY;  // (the bound said this could happen: the state was kept - the caller takes the call back)
     c->arena_used_bound = atop;  // what the arena really holds: it does not grow with the number of calls
     // the last plane of the chunk is the "previous frame" of the next call
     HIPCHK(hipMemcpyAsync(c->planes.as<u8>() + (size_t)c->pslot * g.plane_stride, c->planes.as<u8>() + (size_t)(n - 1) * g.plane_stride, g.plane_stride, hipMemcpyDeviceToDevice, st));
@@ -1339,10 +1359,27 @@ int64_t scpr_compress_batch(scpr_codec* c, const void* d_frames, int nframes, in
   return written;
 }
 
-int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* sizes, const int* ftypes, int nframes, void* d_frames_out, int pitch) {
-  if (!c || !c->inited || !d_packets || !sizes || !ftypes || !d_frames_out || nframes < 0) return SCPR_E_PARAM;
+int64_t scpr_compress_batch(scpr_codec* c, const void* d_frames, int nframes, int* ftypes, int loss, void* d_out, size_t out_capacity, uint32_t* sizes) {
+  if (!c || !c->inited || !d_frames || !ftypes || !d_out || !sizes || nframes < 0) return SCPR_E_PARAM;
+  if (c->crashed) return 0;  // screencap.cpp:1634
   if (hipSetDevice(c->device) != hipSuccess) return SCPR_E_DEVICE;
   pin_reset(c);
+  if (c->have_codec && c->version == 2) return SCPR_E_BAD_VERSION;  // a codec that has decoded version 2 cannot encode (no version 2 encoder here)
+  int rc = ensure_codec(c, c->have_codec ? c->version : 4);  // the encoder always writes v4 (screencap.cpp:1646-1648)
+  if (rc != SCPR_OK) return rc;
+  if (loss != c->last_loss) setup_loss(c, loss);
+  timing_reset(c);
+  EncTxn txn;
+  if ((rc = txn_begin(c, txn, ftypes, nframes, out_capacity)) != SCPR_OK) return rc;
+  const int64_t r = compress_core(c, d_frames, nframes, ftypes, d_out, out_capacity, sizes, txn.hs0);
+  return r == SCPR_E_CAPACITY ? txn_refuse(c, txn, ftypes, SCPR_E_CAPACITY) : r;
+}
+
+// packets resident on the device -> frames at d_frames_out: device memory, or (out_is_host) the host's buffer mapped into the
+// device's address space - then the chains of coded key frames send every finished row there themselves (decode_intra_frame's
+// hdst: the pictures cross PCIe while the chains run) and only what they did not send (P-frames, flat frames; every frame of
+// other pixel formats or of a version 2 stream) is unpacked afterwards, by kernels that write to the host directly.
+static int decompress_core(scpr_codec* c, const void* d_packets, const uint32_t* sizes, const int* ftypes, int nframes, void* d_frames_out, int pitch, bool out_is_host) {
   hipStream_t st = c->stream;
   timing_reset(c);
   // first bytes of every packet decide version / flat / coded (screencap.cpp:1700, :1536)
@@ -1498,6 +1535,8 @@ int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* 
       }
       const u8* pk = (const u8*)d_packets;
       const u8* pk_end = pk + offs[nframes];  // nothing is read at or past this address (the reader supplies 0xFF there)
+      // the chunk's frames in the host's buffer, for the chains to send their rows to (RGB32 of version 3 / 4 streams)
+      u8* hout = (out_is_host && c->bpp == 4 && !v2) ? (u8*)d_frames_out + (size_t)f0 * pitch * g.H : nullptr;
       if (v2) {
         auto kern = has_p ? k_decode_gop_v2<true> : k_decode_gop_v2<false>;
         HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
@@ -1510,10 +1549,11 @@ int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* 
         // eight waves when every GOP has a CU to itself (six helpers: the wave that would share the chain's SIMD leaves at
         // once), four when CUs are shared (three helpers; two waves per SIMD at most: the chain keeps its 256 registers)
         static const bool no_helpers = getenv("SCPR_NO_HELPERS") != nullptr;  // (design aid: the chain's wave alone, for the counters of tools/decoder_pmc2.sh)
-        const unsigned threads = has_p && !no_helpers ? (ng <= 256 ? 512u : 256u) : 64u;
+        // (a batch of key frames for the host: a second wave per workgroup sends the rows - row_streamer)
+        const unsigned threads = has_p ? (no_helpers ? 64u : ng <= 256 ? 512u : 256u) : hout ? 128u : 64u;
         hipLaunchKernelGGL(kern, dim3((unsigned)ng), dim3(threads), dyn, st, pk, pk_end, c->decframes.as<DecFrame>(), c->decgops.as<DecGop>(), c->planes.as<u8>(), g,
                            c->decstates.as<DecRec>(), ar, c->f0, c->err.as<u32>(), ring, c->decfixed.as<FixedBlob>(), (int)std::min<u32>(c->prm.high_range_x, 256),
-                           (int)std::min<u32>(c->prm.high_range_y, 256), ndc, dcache_off);
+                           (int)std::min<u32>(c->prm.high_range_y, 256), ndc, dcache_off, hout, pitch);
       }
     }
     stage_end(c, ST_DECODE);
@@ -1552,7 +1592,24 @@ int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* 
     HIPCHK(hipMemcpyAsync(c->planes.as<u8>() + (size_t)c->pslot * g.plane_stride, c->planes.as<u8>() + (size_t)(n - 1) * g.plane_stride, g.plane_stride, hipMemcpyDeviceToDevice, st));
     stage_begin(c, ST_UNPACK);
     u8* out = (u8*)d_frames_out + (size_t)f0 * pitch * g.H;
-    if (c->bpp == 4) {
+    if (c->bpp == 4 && out_is_host && c->version != 2) {
+      // a chunk of key frames only: the coded ones are at the host already (their workgroups' row streamers sent them); a chunk
+      // with P-frames runs the workgroup form of the kernel, which sends nothing
+      bool chunk_has_p = false;
+      for (int i = 0; i < n; i++) chunk_has_p |= ftypes[f0 + i] != 0;
+      std::vector<int> rest;
+      for (int i = 0; i < n; i++) {
+        const bool flat_key = !ftypes[f0 + i] && (heads[f0 + i] & 15) == 1;
+        if (chunk_has_p || flat_key) rest.push_back(i);
+      }
+      if (!rest.empty()) {
+        HIPCHK(c->hb_list.reserve(rest.size() * 4));
+        HIPCHK(h2d(c, c->hb_list.p, rest.data(), rest.size() * 4, st));
+        dim3 gr((g.H * ((g.W + 3) >> 2) + 256 * PACK_ITEMS - 1) / (256 * PACK_ITEMS), (unsigned)rest.size());
+        hipLaunchKernelGGL(k_unpack32_list, gr, dim3(256), 0, st, c->planes.as<u8>(), out, g, pitch, c->hb_list.as<int>());
+        HIPCHK(sync_out(c, st));  // (`rest` is host memory)
+      }
+    } else if (c->bpp == 4) {
       dim3 gr((g.H * ((g.W + 3) >> 2) + 256 * PACK_ITEMS - 1) / (256 * PACK_ITEMS), n);
       hipLaunchKernelGGL(k_unpack32, gr, dim3(256), 0, st, c->planes.as<u8>(), out, g, pitch);
     } else if (c->bpp == 3 && pitch == g.S && ((size_t)out & 3) == 0) {
@@ -1573,6 +1630,156 @@ int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* 
     f0 += n;
   }
   return done;
+}
+
+int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* sizes, const int* ftypes, int nframes, void* d_frames_out, int pitch) {
+  if (!c || !c->inited || !d_packets || !sizes || !ftypes || !d_frames_out || nframes < 0) return SCPR_E_PARAM;
+  if (hipSetDevice(c->device) != hipSuccess) return SCPR_E_DEVICE;
+  pin_reset(c);
+  return decompress_core(c, d_packets, sizes, ftypes, nframes, d_frames_out, pitch, false);
+}
+
+// ---- batch entry points with HOST pointers ------------------------------------------------------------------------------------
+// The reference's boundary hands over host memory (ScreenCodec::CompressFrame / DecompressFrame, screencap.cpp:1632, :1695).  These
+// are the batch calls in that shape, with the PCIe crossings taken beside the kernels instead of around them:
+//   compress: the frames come over in sub-batches on a copy stream, sub-batch k + 1 while sub-batch k is being coded; the packets
+//             (~1 % of the frames) are written by the gather kernel straight into the host's buffer;
+//   decompress: the packets go over first (small); every coded key frame's rows leave for the host's buffer as the chain
+//             finishes them (decompress_core), so the 8 MB per picture cross while the 110 ms of chain run, not after.
+// Host memory the runtime does not know yet is registered (pinned + mapped) once and kept for the codec's life: a caller that
+// reuses its buffers - a capture loop does - pays for that once.  Memory that cannot be mapped goes through staging copies.
+static int host_view(scpr_codec* c, const void* p, size_t bytes, void** dev) {
+  *dev = nullptr;
+  if (!bytes) return SCPR_OK;
+  hipPointerAttribute_t a{};
+  if (hipPointerGetAttributes(&a, p) == hipSuccess && a.type == hipMemoryTypeHost) {  // pinned by someone already (hipHostMalloc / hipHostRegister)
+    if (hipHostGetDevicePointer(dev, const_cast<void*>(p), 0) == hipSuccess && *dev) return SCPR_OK;
+  }
+  (void)hipGetLastError();  // (an unknown pointer is an "invalid value" to the query: not an error of ours)
+  for (const auto& r : c->host_ranges)
+    if ((const u8*)p >= (const u8*)r.base && (const u8*)p + bytes <= (const u8*)r.base + r.bytes) {
+      void* d0 = nullptr;
+      if (hipHostGetDevicePointer(&d0, r.base, 0) != hipSuccess || !d0) break;
+      *dev = (u8*)d0 + ((const u8*)p - (const u8*)r.base);
+      return SCPR_OK;
+    }
+  // (ranges that overlap the new one are given up first: a range is registered once)
+  for (size_t i = 0; i < c->host_ranges.size();) {
+    const auto r = c->host_ranges[i];
+    if ((const u8*)p < (const u8*)r.base + r.bytes && (const u8*)r.base < (const u8*)p + bytes) {
+      (void)hipHostUnregister(r.base);
+      c->host_ranges.erase(c->host_ranges.begin() + (long)i);
+    } else {
+      i++;
+    }
+  }
+  if (hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterMapped) != hipSuccess) {
+    (void)hipGetLastError();
+    return SCPR_E_DEVICE;  // (the caller falls back to staging copies)
+  }
+  c->host_ranges.push_back({const_cast<void*>(p), bytes});
+  if (hipHostGetDevicePointer(dev, const_cast<void*>(p), 0) != hipSuccess || !*dev) return SCPR_E_DEVICE;
+  return SCPR_OK;
+}
+
+int64_t scpr_compress_batch_host(scpr_codec* c, const void* h_frames, int nframes, int* ftypes, int loss, void* h_out, size_t out_capacity, uint32_t* sizes) {
+  if (!c || !c->inited || !h_frames || !ftypes || !h_out || !sizes || nframes < 0) return SCPR_E_PARAM;
+  if (c->crashed) return 0;
+  if (hipSetDevice(c->device) != hipSuccess) return SCPR_E_DEVICE;
+  pin_reset(c);
+  if (c->have_codec && c->version == 2) return SCPR_E_BAD_VERSION;
+  int rc = ensure_codec(c, c->have_codec ? c->version : 4);
+  if (rc != SCPR_OK) return rc;
+  if (loss != c->last_loss) setup_loss(c, loss);
+  timing_reset(c);
+  if (nframes == 0) return 0;
+  const Geom& g = c->g;
+  const size_t frame_bytes = (size_t)c->pitch_in * g.H;
+  if (!c->stream3) {
+    // A stream of ANOTHER PRIORITY than the codec's two: the runtime maps streams onto a few hardware queues, streams of one
+    // priority share them round robin, and the third stream of this codec landed on the queue of the second - its kernels (the
+    // fixed-model chains) then waited for the whole upload in front of them (rocprofv3 --memory-copy-trace: a 10 ms hole in every
+    // sub-batch).  Queues of different priorities are different queues.
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    if (least != greatest) HIPCHK(hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, least));
+    else HIPCHK(hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
+    for (int k = 0; k < 2; k++) HIPCHK(hipEventCreateWithFlags(&c->ev_in[k], hipEventDisableTiming));
+  }
+  // the frames: pinned (or registered now) so that the copies are DMA transfers that run beside the kernels
+  void* dv = nullptr;
+  (void)host_view(c, h_frames, frame_bytes * (size_t)nframes, &dv);  // (not mappable: the copies below still work, through the runtime's staging)
+  // the packets: straight into the host's buffer when it can be mapped, else into a device buffer that is copied back at the end
+  void* out_dev = nullptr;
+  const bool out_mapped = host_view(c, h_out, out_capacity, &out_dev) == SCPR_OK && out_dev;
+  // (not mapped: a device buffer for what the reference's own caller provides per frame, W*H*6 - CompressGetSize, screenpressor.cpp:386-388;
+  // should noise-like pictures need more and the host's buffer have it, the call is made once more with the closed-form worst case)
+  const size_t nblk0 = (size_t)((g.W + 15) / 16) * ((g.H + 15) / 16);
+  const size_t most = (size_t)g.W * g.H * 6 + 64, worst = (size_t)packet_bound(4, 5ull * g.NP + 16ull * nblk0 + 16);
+  size_t dev_cap = std::min(out_capacity, most * (size_t)nframes);
+  for (int attempt = 0;; attempt++) {
+  if (!out_mapped) {
+    HIPCHK(c->hb_packets.reserve(dev_cap + 64));
+    out_dev = c->hb_packets.p;
+  }
+  // sub-batches: big enough that the coder's one serial chain per call (7.5 ms whatever the frames) is paid a few times only, small
+  // enough that the first one's transfer is not all of the wait: a third of the call, at least 16 frames
+  const int sub_env = getenv("SCPR_HOST_SUB") ? atoi(getenv("SCPR_HOST_SUB")) : 0;  // (tests and tuning: frames per sub-batch)
+  const int sub = std::max(1, std::min(nframes, sub_env > 0 ? sub_env : std::max(16, (nframes + 2) / 3)));
+  const int nsub = (nframes + sub - 1) / sub;
+  HIPCHK(c->hb_frames.reserve((size_t)std::min(nframes, 2 * sub) * frame_bytes));
+  EncTxn txn;
+  if ((rc = txn_begin(c, txn, ftypes, nframes, out_mapped ? out_capacity : dev_cap)) != SCPR_OK) return rc;
+  auto upload = [&](int k) {
+    const int a = k * sub, n = std::min(sub, nframes - a);
+    hipError_t e = hipMemcpyAsync(c->hb_frames.as<u8>() + (size_t)(k & 1) * sub * frame_bytes, (const u8*)h_frames + (size_t)a * frame_bytes, (size_t)n * frame_bytes, hipMemcpyHostToDevice, c->stream3);
+    if (e == hipSuccess) e = hipEventRecord(c->ev_in[k & 1], c->stream3);
+    return e;
+  };
+  HIPCHK(upload(0));
+  int64_t written = 0;
+  const size_t cap = out_mapped ? out_capacity : dev_cap;
+  for (int k = 0; k < nsub; k++) {
+    const int a = k * sub, n = std::min(sub, nframes - a);
+    if (k + 1 < nsub) HIPCHK(upload(k + 1));  // (its half of the staging was read by sub-batch k - 1, whose call has returned)
+    HIPCHK(hipStreamWaitEvent(c->stream, c->ev_in[k & 1], 0));
+    const int64_t r = compress_core(c, c->hb_frames.as<u8>() + (size_t)(k & 1) * sub * frame_bytes, n, ftypes + a, (u8*)out_dev + written, cap - (size_t)written, sizes + a, txn.hs0);
+    if (r < 0) {
+      (void)hipStreamSynchronize(c->stream3);
+      if (r != SCPR_E_CAPACITY) return r;
+      const int64_t r2 = txn_refuse(c, txn, ftypes, SCPR_E_CAPACITY);
+      if (r2 != SCPR_E_CAPACITY || out_mapped || attempt || dev_cap >= out_capacity) return r2;
+      written = -1;  // the device buffer was the limit, not the host's: once more with room for the worst case
+      break;
+    }
+    written += r;
+  }
+  if (written < 0) {
+    dev_cap = std::min(out_capacity, worst * (size_t)nframes);
+    continue;
+  }
+  if (!out_mapped && written > 0) HIPCHK(hipMemcpy(h_out, out_dev, (size_t)written, hipMemcpyDeviceToHost));
+  return written;
+  }
+}
+
+int scpr_decompress_batch_host(scpr_codec* c, const void* h_packets, const uint32_t* sizes, const int* ftypes, int nframes, void* h_frames_out, int pitch) {
+  if (!c || !c->inited || !h_packets || !sizes || !ftypes || !h_frames_out || nframes < 0) return SCPR_E_PARAM;
+  if (hipSetDevice(c->device) != hipSuccess) return SCPR_E_DEVICE;
+  pin_reset(c);
+  if (nframes == 0) return 0;
+  size_t total = 0;
+  for (int i = 0; i < nframes; i++) total += sizes[i];
+  const size_t ob = (size_t)pitch * c->prm.height * (size_t)nframes;
+  HIPCHK(c->hb_packets.reserve(total + 64));
+  HIPCHK(hipMemcpyAsync(c->hb_packets.p, h_packets, total, hipMemcpyHostToDevice, c->stream));  // ~1 % of the pictures: not worth a pipeline
+  void* out_dev = nullptr;
+  if (host_view(c, h_frames_out, ob, &out_dev) == SCPR_OK && out_dev) return decompress_core(c, c->hb_packets.p, sizes, ftypes, nframes, out_dev, pitch, true);
+  // the host's buffer cannot be mapped: decode to the device, copy back
+  HIPCHK(c->hb_frames.reserve(ob));
+  const int r = decompress_core(c, c->hb_packets.p, sizes, ftypes, nframes, c->hb_frames.p, pitch, false);
+  if (r > 0) HIPCHK(hipMemcpy(h_frames_out, c->hb_frames.p, (size_t)pitch * c->prm.height * (size_t)r, hipMemcpyDeviceToHost));
+  return r;
 }
 
 // ---- per-frame entry points with host pointers (the reference's own shape) ----

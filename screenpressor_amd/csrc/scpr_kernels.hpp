@@ -213,6 +213,30 @@ __global__ __launch_bounds__(256) void k_unpack32(const u8* __restrict__ planes,
     }
   }
 }
+// the same for the frames of a list (slots[blockIdx.y]): the host-pointer decode call unpacks what the decoder's chains have not
+// already sent to the host row by row (P-frames, flat frames) - straight into the host's mapped buffer
+__global__ __launch_bounds__(256) void k_unpack32_list(const u8* __restrict__ planes, u8* __restrict__ dst, Geom g, int pitch, const int* __restrict__ slots) {
+  const int f = slots[blockIdx.y], G = (g.W + 3) >> 2, total = g.H * G;
+  for (int it = 0; it < PACK_ITEMS; it++) {
+    const int idx = (blockIdx.x * PACK_ITEMS + it) * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int y = idx / G, gx = idx - y * G;
+    const u32* s = (const u32*)(planes + (size_t)f * g.plane_stride + (size_t)y * g.S) + gx * 3;
+    const int room = g.S - gx * 12;
+    u32 w0 = s[0], w1 = room > 4 ? s[1] : 0, w2 = room > 8 ? s[2] : 0;
+    u32* o = (u32*)(dst + (size_t)f * pitch * g.H + (size_t)y * pitch) + gx * 4;
+    const int nv = min(4, g.W - gx * 4);
+    if (nv == 4 && ((pitch | (int)(size_t)dst) & 15) == 0) {
+      *(uint4*)o = make_uint4((w0 & 0xFFFFFFu) | 0xFF000000u, ((w0 >> 24) | ((w1 & 0xFFFFu) << 8)) | 0xFF000000u, ((w1 >> 16) | ((w2 & 0xFFu) << 16)) | 0xFF000000u,
+                              (w2 >> 8) | 0xFF000000u);
+    } else {
+      o[0] = (w0 & 0xFFFFFFu) | 0xFF000000u;
+      if (nv > 1) o[1] = ((w0 >> 24) | ((w1 & 0xFFFFu) << 8)) | 0xFF000000u;
+      if (nv > 2) o[2] = ((w1 >> 16) | ((w2 & 0xFFu) << 16)) | 0xFF000000u;
+      if (nv > 3) o[3] = (w2 >> 8) | 0xFF000000u;
+    }
+  }
+}
 // plane -> RGB24 rows with the caller's pitch / RGB16 (screencap.cpp:1726-1737)
 __global__ __launch_bounds__(256) void k_unpack_rows(const u8* __restrict__ planes, u8* __restrict__ dst, Geom g, int pitch, int bpp, int rs, int gs, int bs) {
   const int f = blockIdx.y, total = g.H * g.W;

@@ -65,6 +65,12 @@ __device__ __forceinline__ void glb_st_if(u32* p, u32 v, bool on) {
   u64 keep;
   asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %1\n\tglobal_store_dword %2, %3, off\n\ts_mov_b64 exec, %0\n\ts_waitcnt vmcnt(0)" : "=&s"(keep) : "s"(__ballot(on)), "v"(p), "v"(v) : "memory", "scc");
 }
+// (the same without the wait: for a store whose completion nothing here depends on - a later load of the same address by this wave
+// is served after it, the memory pipeline keeps a wave's accesses to one address in order)
+__device__ __forceinline__ void glb_st_if_nowait(u32* p, u32 v, bool on) {
+  u64 keep;
+  asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %1\n\tglobal_store_dword %2, %3, off\n\ts_mov_b64 exec, %0" : "=&s"(keep) : "s"(__ballot(on)), "v"(p), "v"(v) : "memory", "scc");
+}
 __device__ __forceinline__ void glb_or_lane0(u32* p, u32 v) {  // agent scope, nothing returned (error flags)
   u64 keep;
   asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_or %1, %2, off\n\ts_mov_b64 exec, %0\n\ts_waitcnt vmcnt(0)" : "=&s"(keep) : "v"(p), "v"(v) : "memory");
@@ -148,6 +154,18 @@ struct __attribute__((aligned(16))) WaveLds {
   u32 crec[CACHE_N][DECREC_WORDS];
   u16 tmp[256];
   u32 dtag[64];        // tags of the dense-table cache (WaveModel::tab_of)
+  // key frames whose picture goes to the HOST (scpr_decompress_batch_host): the chain says how many rows of the plane are complete
+  // in HBM (bit 31: and nothing more will come), a second wave of the workgroup converts them to RGB32 and sends them over PCIe
+  // (row_streamer) - stores to the host's memory issued by the chain itself cost it 4 % (120 ms per key frame instead of 115.6)
+  // Measured (tools/exp_host_dec.py, ablation builds): the chain's own announcements cost nothing (114.8 ms per key frame with a
+  // streamer that leaves at once, 114.5 without them); the streamer at work costs the chain 3 % (118.3 ms) - its stores to the
+  // host's memory and the chain's loads (packet blocks, record misses: 3700 a frame) go through the CU's one vector-memory
+  // pipeline, and a store that is waiting for PCIe holds a load up.  A streamer on ANOTHER compute unit would share one with
+  // another chain (every CU has one) and the launch is as slow as its slowest chain: not built.
+  struct {
+    u32 rows;
+    u32 pad[3];
+  } hs;
   FixedLdsP fp;
   u32 tile[17 * 17 + 1];  // P-frame block under reconstruction, with one row above and one column to the left (+ a cell that takes the stores of idle lanes)
   u32 ptile[256];      // the same rect in the previous frame (row-major, w * h pixels): what "previous frame" runs copy (decode_inter_frame reads it through the tile's pointer)
@@ -1366,10 +1384,13 @@ struct WaveDec : WaveModel {
 #endif
       u32* r = L.crec[slot_of(ctxid)];
       {  // (the record's words by its first lanes, without a branch on the lane: masked stores, a load every lane can make)
+        // The new record is ASKED FOR first and the old one sent off behind it, unwaited: one trip to L2 on the chain instead of
+        // two (the store used to be waited for before the load was issued: 961 ticks per miss, 609 misses per P-frame).
         const int wl = min(lane, DECREC_WORDS - 1);
         const bool in = lane < DECREC_WORDS;
-        glb_st_if(&gstates[tag != kNoCtx ? tag : (u32)ctxid].w[wl], r[wl], in && tag != kNoCtx);
+        const u32 old = r[wl];
         const u32 nw = gstates[ctxid].w[wl];
+        glb_st_if_nowait(&gstates[tag != kNoCtx ? tag : (u32)ctxid].w[wl], old, in && tag != kNoCtx);
         lds_st_if(&r[wl], lane == 3 ? (u32)ctxid : nw, in);
       }
       wave_fence();
@@ -1665,8 +1686,11 @@ __device__ __forceinline__ u32 ld3_l2(const u8* p) {
 // pixels indexed by raster position (it always holds the last two rows: the predictors read
 // "previous", "top" and "top-left" from it); every finished row is packed to RGB24 and flushed
 // to HBM four pixels per lane.  The plane in HBM is never read back.
+// rows_word (may be null): an LDS word in which the chain announces how many rows of the plane are complete in HBM, for the
+// workgroup's row streamer (below): the picture crosses PCIe WHILE the chain decodes (a key frame is 110 ms of chain and 8 MB of
+// pixels: 75 MB/s per wave, 22 GB/s for 300 waves) instead of after it.
 template <class DEC>
-__device__ __forceinline__ void decode_intra_frame(DEC& D, const Geom& g, u8* __restrict__ dst, u32* ring, int ring_pixels) {
+__device__ __forceinline__ void decode_intra_frame(DEC& D, const Geom& g, u8* __restrict__ dst, u32* ring, int ring_pixels, u32* rows_word = nullptr) {
   const int lane = D.lane;
   const u32 pm = (u32)ring_pixels - 1u;
   const int W = g.W, H = g.H, S = g.S, NP = g.NP;
@@ -1676,6 +1700,12 @@ __device__ __forceinline__ void decode_intra_frame(DEC& D, const Geom& g, u8* __
   int flushed = 0, rowbase = 0;  // rowbase = flushed * W: first pixel of the row being decoded
   auto flush_rows = [&](int to) __attribute__((always_inline)) {
     wave_fence();
+    if (rows_word != nullptr) {
+      // the rows flushed before this call have reached L2 by now (a row of chain ago: the wait is for nothing, as a rule) and the
+      // streamer may take them; this call's rows are announced by the next one (the frame's end announces the last)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(rows_word, (u32)flushed, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
     for (; flushed < to; flushed++, rowbase += W) {
       const u32 p0 = (u32)rowbase;
       u8* row = dst + (size_t)flushed * S;
@@ -2398,16 +2428,74 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
   flush_jobs();  // the frame is complete (and the next one reads it) when every block is in place
 }
 
+// The second wave of a key frame's workgroup when the picture goes to the host: rows [done, rows) of the plane - RGB24, complete
+// in HBM, announced by the chain in `*rows_word` - go out as RGB32 with alpha 255 (ScreenCodec::DecompressFrame's conversion,
+// screencap.cpp:1711-1725) to the host's buffer (mapped into the device's address space: the stores cross PCIe), four pixels per
+// lane.  Ends when the chain has set bit 31 and everything announced is sent: the chain sets it on every way out.
+constexpr u32 kRowsEnd = 0x80000000u;
+__device__ __forceinline__ void row_streamer(const u32* rows_word, const u8* __restrict__ plane, u8* __restrict__ hdst, int hpitch, const Geom& g) {
+  const int lane = lane_id();
+  const int W = g.W, S = g.S;
+  const bool h16 = (((size_t)hdst | (size_t)hpitch) & 15) == 0;
+  int done = 0;
+  for (;;) {
+    const u32 r = __hip_atomic_load(rows_word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const int upto = min((int)(r & ~kRowsEnd), g.H);
+    if (done < upto) {
+      // Nothing stale from this CU's vector L1: a line that holds the end of one row and the start of the next is read when
+      // the first is sent and would be a stale hit when the second is.  The loads go past the L1 (agent scope: the chain's stores
+      // are in L2) rather than invalidating it under the chain's feet.
+#define SCPR_ROW_LD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+      for (; done < upto; done++) {
+        const u32* row = (const u32*)(plane + (size_t)done * S);
+        u32* ho = (u32*)(hdst + (size_t)done * hpitch);
+        for (int gq = lane; gq * 4 < W; gq += 64) {
+          const int room = S - gq * 12, nv = min(4, W - gq * 4);
+          const u32 w0 = SCPR_ROW_LD(&row[gq * 3]), w1 = room > 4 ? SCPR_ROW_LD(&row[gq * 3 + 1]) : 0u, w2 = room > 8 ? SCPR_ROW_LD(&row[gq * 3 + 2]) : 0u;
+          const u32 A = 0xFF000000u;
+          const u32 p0 = (w0 & 0xFFFFFFu) | A, p1 = ((w0 >> 24) | ((w1 & 0xFFFFu) << 8)) | A, p2 = ((w1 >> 16) | ((w2 & 0xFFu) << 16)) | A, p3 = (w2 >> 8) | A;
+          u32* o = ho + gq * 4;
+          if (h16 && nv == 4) {
+            *(uint4*)o = make_uint4(p0, p1, p2, p3);
+          } else {
+            o[0] = p0;
+            if (nv > 1) o[1] = p1;
+            if (nv > 2) o[2] = p2;
+            if (nv > 3) o[3] = p3;
+          }
+        }
+      }
+      continue;
+    }
+    if (r & kRowsEnd) break;
+    __builtin_amdgcn_s_sleep(32);
+  }
+}
+
 template <bool HAS_P>
-__global__ __launch_bounds__(HAS_P ? 512 : 64) void k_decode_gop_w(const u8* __restrict__ packets, const u8* packets_end, const DecFrame* __restrict__ frames, const DecGop* __restrict__ gops,
+__global__ __launch_bounds__(HAS_P ? 512 : 128) void k_decode_gop_w(const u8* __restrict__ packets, const u8* packets_end, const DecFrame* __restrict__ frames, const DecGop* __restrict__ gops,
                                                      u8* __restrict__ planes, Geom g, DecRec* __restrict__ states, Arena arena, int f0, u32* __restrict__ status, int ring_bytes,
-                                                     FixedBlob* __restrict__ fixedstore, int far_x, int far_y, int ndc, int dcache_off) {
+                                                     FixedBlob* __restrict__ fixedstore, int far_x, int far_y, int ndc, int dcache_off, u8* __restrict__ hout, int hpitch) {
   __shared__ __attribute__((aligned(16))) u8 Lraw[HAS_P ? sizeof(WaveLds) : offsetof(WaveLds, fp)];
   WaveLds& L = *(WaveLds*)Lraw;
   // ring_bytes = 4 * (power of two >= W + 512) pixels, then (P-frames) one byte per 16x16 block, then (at dcache_off) ndc dense tables
   extern __shared__ __align__(16) u8 pix[];
   const DecGop gop = gops[blockIdx.x];
   const int lane = lane_id();
+  // A batch of key frames for the host (hout): the workgroup has a second wave, the row streamer of its coded key frame (a GOP
+  // of this kernel holds one, its first frame; the frames after it can only be flat ones).
+  const bool stream_rows = !HAS_P && hout != nullptr && blockDim.x > 64;
+  if (!HAS_P && blockDim.x > 64) {
+    if (threadIdx.x == 0) L.hs.rows = (stream_rows && gop.count > 0 && frames[gop.first].kind == 0) ? 0u : kRowsEnd;
+    __syncthreads();
+    if (threadIdx.x >= 64) {
+      if (threadIdx.x < 128 && stream_rows) {
+        const DecFrame f0 = frames[gop.first];
+        row_streamer(&L.hs.rows, planes + (size_t)f0.slot * g.plane_stride, hout + (size_t)f0.slot * (size_t)hpitch * g.H, hpitch, g);
+      }
+      return;
+    }
+  }
   for (int i = lane; i < CACHE_N; i += 64) L.crec[i][3] = kNoCtx;  // empty cache
   if (threadIdx.x < 64) L.dtag[lane] = 0;
   if (HAS_P) {
@@ -2439,7 +2527,13 @@ __global__ __launch_bounds__(HAS_P ? 512 : 64) void k_decode_gop_w(const u8* __r
     if (fr.kind == 0) {
       D.fixed_init();  // RenewI (:418); the colour records of the GOP start cleared
       D.stream_init(packets + fr.src_off + 1);
-      decode_intra_frame(D, g, dst, (u32*)pix, ring_bytes >> 2);
+      // (stream_rows: the picture goes to the host's buffer row by row, by the workgroup's second wave; whatever way the frame
+      // ends, the end is announced - with the rows that are complete: all of them, or what a refused stream left)
+      decode_intra_frame(D, g, dst, (u32*)pix, ring_bytes >> 2, stream_rows && fi == gop.first ? &L.hs.rows : nullptr);
+      if (stream_rows && fi == gop.first) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&L.hs.rows, kRowsEnd | (D.bad ? 0u : (u32)g.H), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
     } else if (HAS_P && fr.kind == 2) {
       decode_inter_frame(D, g, dst, planes + (size_t)fr.prev_slot * g.plane_stride, packets + fr.src_off, pix + ring_bytes, far_x, far_y);
     }

@@ -29,18 +29,21 @@ IP = "--ip" in sys.argv  # one GOP: a key frame and n-1 P-frames (sections 5-7 o
 pk, sizes, ft = c.CompressBatch(frames, [0] + [1] * (n - 1) if IP else [0] * n)
 L = K.load_library()
 out = (C.c_ulonglong * 24)()
+cp = (C.c_ulonglong * 32)()
 if IP and skip:  # age the GOP: the first skip + 1 frames are decoded before the counters are cleared
     off = int(np.sum(sizes[:skip + 1]))
     d = K.ScreenCodec()
     d.Init(W, H, 32)
     r, dec0 = d.DecompressBatch(pk[:off], sizes[:skip + 1], ft[:skip + 1])
     L.scpr_debug_profile(out)
+    L.scpr_debug_cprof(cp)
     r, dec = d.DecompressBatch(pk[off:].clone(), sizes[skip + 1:], ft[skip + 1:])
     torch.cuda.synchronize()
     assert torch.equal(dec.reshape(-1), frames[skip + 1:].reshape(-1))
     n = n - skip - 1
 else:
     L.scpr_debug_profile(out)
+    L.scpr_debug_cprof(cp)
     r, dec = c.DecompressBatch(pk, sizes, ft)
     torch.cuda.synchronize()
     assert torch.equal(dec.reshape(-1), frames.reshape(-1))
@@ -57,8 +60,7 @@ for nm, x in zip(names, v):
 for nm, x in zip(["colour symbols", "record cache misses", "dense-table symbols", "raw symbols", "small-table slow path", "runs", "literal runs", "dense-table cache misses"], ev):
     print("%-50s %.0f per frame" % (nm, x / n))
 print("dense fast-path hits per frame: %.0f; small-table hits on the top entry: %.0f, in one-symbol tables: %.0f" % (ex[0] / n, ex[1] / n, ex[2] / n))
-cp = (C.c_ulonglong * 32)()
-if hasattr(L, "scpr_debug_cprof") or True:
+if True:
     L.scpr_debug_cprof(cp)
     cpv = list(cp)
     cls_names = ["top entry of a small table", "small table, any other way (whole symbol)", "[of which: small_op alone, the general path]", "dense table (whole symbol but the tail)", "[of which: dense_op alone, the general path]",
