@@ -7,7 +7,7 @@ import ctypes as C, os, subprocess, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-LIB = os.path.join(ROOT, "screenpressor_amd", "libscpr_amd_prof.so")
+LIB = os.environ.get("SCPR_PROF_LIB", os.path.join(ROOT, "screenpressor_amd", "libscpr_amd_prof.so"))  # (the override: a profile build of an experiment)
 src = os.path.join(ROOT, "screenpressor_amd", "csrc", "scpr_amd.hip")
 if "--build" in sys.argv or not os.path.exists(LIB):
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-strict-aliasing", "-fPIC", "-shared", "-DSCPR_PROFILE", "-mllvm", "-align-all-nofallthru-blocks=6", "-mllvm", "-enable-post-misched=false", "-mllvm", "-structurizecfg-skip-uniform-regions=true",
