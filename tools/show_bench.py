@@ -5,7 +5,9 @@ c = l["config"]
 print("headline", l["value"], "MPix/s", l["ms_per_step"], "ms; parity", {k: l["parity"].get(k) for k in ("ok", "golden_fixture_ok", "golden_stream_ok")}, "frac", l["roofline"]["frac"])
 print("  stages", c["stage_ms_per_step"])
 print("  per-frame", c.get("per_frame_api_ms"), "host-incl", c.get("incl_host_transfer_MPix_s"))
-print("  overlapped steps", c.get("overlapped_steps"))
+print("  host boundary", c.get("host_boundary"))
+print("  chain", l["roofline"].get("chain"), "bound", l["roofline"].get("bound"), "traffic", l["roofline"].get("traffic"), l["roofline"].get("traffic_source"))
+print("  targets", c.get("targets"))
 for o in c.get("others", []):
     if "error" in o:
         print("ERR", o)
