@@ -117,17 +117,23 @@ int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* 
  *               version 3 / 4 streams), so the pictures cross while the chains
  *               run; P-frames, flat frames and the other pixel formats are
  *               unpacked into h_frames_out by kernels once their GOPs are done.
- * Host memory the HIP runtime does not know (malloc, numpy) is registered with it
- * on first use (hipHostRegister: pinned and mapped) and stays so until
- * scpr_destroy: reuse the buffers.  Memory that is pinned already (hipHostMalloc,
- * torch pin_memory) is used as it is.  Memory that cannot be registered goes
- * through staging copies (same results, no overlap).
+ * The overlap needs PINNED host memory: memory the HIP runtime has pinned
+ * (hipHostMalloc, hipHostRegister, torch pin_memory) is recognised and used as it
+ * is; a buffer the caller reuses - a capture loop's frame and packet buffers - is
+ * pinned and mapped once with scpr_host_pin and released with scpr_host_unpin
+ * (or by scpr_destroy).  Pageable memory (malloc, numpy) is never registered behind
+ * the caller's back - a registration would outlive the memory it names - and goes
+ * through the runtime's staging copies: same results, no overlap.
  * scpr_compress_batch_host is taken back whole on SCPR_E_CAPACITY, like
  * scpr_compress_batch. */
 int64_t scpr_compress_batch_host(scpr_codec* c, const void* h_frames, int nframes, int* ftypes, int loss,
                                  void* h_out, size_t out_capacity, uint32_t* sizes);
 int scpr_decompress_batch_host(scpr_codec* c, const void* h_packets, const uint32_t* sizes, const int* ftypes,
                                int nframes, void* h_frames_out, int pitch);
+/* hipHostRegister(p, bytes, mapped) / hipHostUnregister(p) kept by the codec: the batch_host calls take their fast path for
+ * pointers inside a pinned range.  The memory must stay allocated until scpr_host_unpin or scpr_destroy.  0 or < 0. */
+int scpr_host_pin(scpr_codec* c, void* p, size_t bytes);
+int scpr_host_unpin(scpr_codec* c, void* p);
 
 /* ---- sharding support (an addition) ----------------------------------------
  * GOPs are independent except for what CScreenCapt keeps ACROSS key frames:

@@ -17,7 +17,7 @@ _LIB_PATH = os.environ.get("SCPR_AMD_LIB", os.path.join(_PKG, "libscpr_amd.so"))
 
 SCPR_OK, SCPR_E_DEVICE, SCPR_E_PARAM, SCPR_E_BAD_VERSION, SCPR_E_CAPACITY, SCPR_E_STREAM = 0, -1, -2, -3, -4, -5
 EXPORTS = ["scpr_create", "scpr_destroy", "scpr_init", "scpr_deinit", "scpr_crash_happened", "scpr_compress_frame",
-           "scpr_decompress_frame", "scpr_compress_batch", "scpr_decompress_batch", "scpr_compress_batch_host", "scpr_decompress_batch_host", "scpr_last_timing", "scpr_stage_name",
+           "scpr_decompress_frame", "scpr_compress_batch", "scpr_decompress_batch", "scpr_compress_batch_host", "scpr_decompress_batch_host", "scpr_host_pin", "scpr_host_unpin", "scpr_last_timing", "scpr_stage_name",
            "scpr_seed_shard", "scpr_export_mv_memory", "scpr_import_mv_memory", "scpr_motion_prepass", "scpr_set_cu_mask", "scpr_debug_entries", "scpr_debug_arena", "scpr_debug_colour_chain", "scpr_debug_inject", "scpr_version",
            # include/scpr_driver.h, include/scpr_avi.h
            "scpr_driver_open", "scpr_driver_close", "scpr_driver_configure", "scpr_driver_compress_query", "scpr_driver_compress_get_format",
@@ -68,6 +68,8 @@ def load_library() -> C.CDLL:
         L.scpr_compress_batch_host.restype = C.c_int64
         L.scpr_compress_batch_host.argtypes = L.scpr_compress_batch.argtypes
         L.scpr_decompress_batch_host.argtypes = L.scpr_decompress_batch.argtypes
+        L.scpr_host_pin.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.scpr_host_unpin.argtypes = [C.c_void_p, C.c_void_p]
         L.scpr_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int]
         L.scpr_stage_name.restype = C.c_char_p
         L.scpr_stage_name.argtypes = [C.c_int]
@@ -254,6 +256,17 @@ class ScreenCodec:
             return a.ctypes.data, a.size
         assert not a.is_cuda and a.is_contiguous() and a.element_size() == 1  # a CPU torch tensor
         return a.data_ptr(), a.numel()
+
+    def HostPin(self, a):
+        """scpr_host_pin: a host buffer the caller will reuse (numpy array / CPU tensor), pinned and mapped until HostUnpin or close()"""
+        ptr, nbytes = self._host_ptr(a)
+        self._check(self._L.scpr_host_pin(self._h, C.c_void_p(ptr), nbytes))
+        return self
+
+    def HostUnpin(self, a):
+        ptr, _ = self._host_ptr(a)
+        self._check(self._L.scpr_host_unpin(self._h, C.c_void_p(ptr)))
+        return self
 
     def CompressBatchHost(self, frames, ftypes, loss: int | None = None, out=None):
         """frames: n * frame_bytes bytes of host memory; out: host buffer for the packets (default: a numpy array of the safe size).

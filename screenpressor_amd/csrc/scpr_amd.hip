@@ -175,6 +175,7 @@ struct scpr_codec {
   struct HostRange {
     void* base;
     size_t bytes;
+    bool owned;  // registered by this codec (another codec, or the caller, may have pinned the same memory first)
   };
   std::vector<HostRange> host_ranges;
 };
@@ -900,7 +901,9 @@ void scpr_destroy(scpr_codec* c) {
   pin_reset(c);  // (read-backs a failed call left queued are dropped, not delivered: their destinations are gone)
   (void)hipStreamSynchronize(c->stream);
   (void)hipStreamSynchronize(c->stream2);
-  for (const auto& r : c->host_ranges) (void)hipHostUnregister(r.base);
+  for (const auto& r : c->host_ranges)
+    if (r.owned) (void)hipHostUnregister(r.base);  // (what scpr_host_pin registered and nobody took back)
+  (void)hipGetLastError();
   c->host_ranges.clear();
   if (c->stream3) {
     (void)hipStreamSynchronize(c->stream3);
@@ -1646,40 +1649,69 @@ int scpr_decompress_batch(scpr_codec* c, const void* d_packets, const uint32_t* 
 //             (~1 % of the frames) are written by the gather kernel straight into the host's buffer;
 //   decompress: the packets go over first (small); every coded key frame's rows leave for the host's buffer as the chain
 //             finishes them (decompress_core), so the 8 MB per picture cross while the 110 ms of chain run, not after.
-// Host memory the runtime does not know yet is registered (pinned + mapped) once and kept for the codec's life: a caller that
-// reuses its buffers - a capture loop does - pays for that once.  Memory that cannot be mapped goes through staging copies.
+// The fast path wants PINNED host memory (hipHostMalloc / hipHostRegister / torch pin_memory, or scpr_host_pin below for buffers the
+// caller reuses - a capture loop does).  Pageable memory works too, through the runtime's staging copies: same results, no overlap.
+// Where host memory `p` can be reached from the device without a copy by the runtime: memory the runtime has pinned (hipHostMalloc,
+// hipHostRegister by the caller, torch's pin_memory) or that the caller has handed to scpr_host_pin.  Anything else - malloc,
+// numpy - is NOT registered behind the caller's back (a registration outlives the memory it names unless somebody takes it back):
+// the calls then go through the runtime's own staging copies, with the same results and no overlap.
 static int host_view(scpr_codec* c, const void* p, size_t bytes, void** dev) {
   *dev = nullptr;
-  if (!bytes) return SCPR_OK;
-  hipPointerAttribute_t a{};
-  if (hipPointerGetAttributes(&a, p) == hipSuccess && a.type == hipMemoryTypeHost) {  // pinned by someone already (hipHostMalloc / hipHostRegister)
-    if (hipHostGetDevicePointer(dev, const_cast<void*>(p), 0) == hipSuccess && *dev) return SCPR_OK;
-  }
-  (void)hipGetLastError();  // (an unknown pointer is an "invalid value" to the query: not an error of ours)
+  if (!bytes) return SCPR_E_PARAM;
   for (const auto& r : c->host_ranges)
     if ((const u8*)p >= (const u8*)r.base && (const u8*)p + bytes <= (const u8*)r.base + r.bytes) {
       void* d0 = nullptr;
-      if (hipHostGetDevicePointer(&d0, r.base, 0) != hipSuccess || !d0) break;
-      *dev = (u8*)d0 + ((const u8*)p - (const u8*)r.base);
+      if (hipHostGetDevicePointer(&d0, r.base, 0) == hipSuccess && d0) {
+        *dev = (u8*)d0 + ((const u8*)p - (const u8*)r.base);
+        return SCPR_OK;
+      }
+      (void)hipGetLastError();
+    }
+  hipPointerAttribute_t a{};
+  if (hipPointerGetAttributes(&a, p) == hipSuccess && a.type == hipMemoryTypeHost) {
+    if (hipHostGetDevicePointer(dev, const_cast<void*>(p), 0) == hipSuccess && *dev) return SCPR_OK;
+  }
+  (void)hipGetLastError();  // (an unknown pointer is an "invalid value" to the query: not an error of ours, and not to be found by the next caller of hipGetLastError)
+  *dev = nullptr;
+  return SCPR_E_DEVICE;
+}
+
+int scpr_host_pin(scpr_codec* c, void* p, size_t bytes) {
+  if (!c || !p || !bytes) return SCPR_E_PARAM;
+  if (hipSetDevice(c->device) != hipSuccess) return SCPR_E_DEVICE;
+  for (const auto& r : c->host_ranges)
+    if (r.base == p && r.bytes == bytes) return SCPR_OK;
+  if (hipHostRegister(p, bytes, hipHostRegisterMapped) == hipSuccess) {
+    c->host_ranges.push_back({p, bytes, true});
+    return SCPR_OK;
+  }
+  (void)hipGetLastError();
+  // somebody has pinned it already (another codec of the process, the caller): fine, and not this codec's to release
+  hipPointerAttribute_t a{};
+  void* d0 = nullptr;
+  if (hipPointerGetAttributes(&a, p) == hipSuccess && a.type == hipMemoryTypeHost && hipHostGetDevicePointer(&d0, p, 0) == hipSuccess && d0) {
+    c->host_ranges.push_back({p, bytes, false});
+    return SCPR_OK;
+  }
+  (void)hipGetLastError();
+  return SCPR_E_DEVICE;
+}
+
+int scpr_host_unpin(scpr_codec* c, void* p) {
+  if (!c || !p) return SCPR_E_PARAM;
+  if (hipSetDevice(c->device) != hipSuccess) return SCPR_E_DEVICE;
+  for (size_t i = 0; i < c->host_ranges.size(); i++)
+    if (c->host_ranges[i].base == p) {
+      (void)hipStreamSynchronize(c->stream);
+      if (c->stream3) (void)hipStreamSynchronize(c->stream3);
+      const bool owned = c->host_ranges[i].owned;
+      c->host_ranges.erase(c->host_ranges.begin() + (long)i);
+      // (a registration another codec of the process made over the same memory and has released already is not an error of
+      // this call: the codec no longer uses the range, which is what was asked)
+      if (owned && hipHostUnregister(p) != hipSuccess) (void)hipGetLastError();
       return SCPR_OK;
     }
-  // (ranges that overlap the new one are given up first: a range is registered once)
-  for (size_t i = 0; i < c->host_ranges.size();) {
-    const auto r = c->host_ranges[i];
-    if ((const u8*)p < (const u8*)r.base + r.bytes && (const u8*)r.base < (const u8*)p + bytes) {
-      (void)hipHostUnregister(r.base);
-      c->host_ranges.erase(c->host_ranges.begin() + (long)i);
-    } else {
-      i++;
-    }
-  }
-  if (hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterMapped) != hipSuccess) {
-    (void)hipGetLastError();
-    return SCPR_E_DEVICE;  // (the caller falls back to staging copies)
-  }
-  c->host_ranges.push_back({const_cast<void*>(p), bytes});
-  if (hipHostGetDevicePointer(dev, const_cast<void*>(p), 0) != hipSuccess || !*dev) return SCPR_E_DEVICE;
-  return SCPR_OK;
+  return SCPR_E_PARAM;
 }
 
 int64_t scpr_compress_batch_host(scpr_codec* c, const void* h_frames, int nframes, int* ftypes, int loss, void* h_out, size_t out_capacity, uint32_t* sizes) {
@@ -1706,9 +1738,8 @@ int64_t scpr_compress_batch_host(scpr_codec* c, const void* h_frames, int nframe
     else HIPCHK(hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
     for (int k = 0; k < 2; k++) HIPCHK(hipEventCreateWithFlags(&c->ev_in[k], hipEventDisableTiming));
   }
-  // the frames: pinned (or registered now) so that the copies are DMA transfers that run beside the kernels
-  void* dv = nullptr;
-  (void)host_view(c, h_frames, frame_bytes * (size_t)nframes, &dv);  // (not mappable: the copies below still work, through the runtime's staging)
+  // the frames: from pinned memory the copies below are DMA transfers that run beside the kernels; from pageable memory the
+  // runtime stages them itself (same results, little overlap)
   // the packets: straight into the host's buffer when it can be mapped, else into a device buffer that is copied back at the end
   void* out_dev = nullptr;
   const bool out_mapped = host_view(c, h_out, out_capacity, &out_dev) == SCPR_OK && out_dev;

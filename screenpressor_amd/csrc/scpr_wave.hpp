@@ -810,7 +810,12 @@ struct WaveDec : WaveModel {
   // input stream
   const u8* src;
   const u8* src_end;
-  const u32* wbase = nullptr;  // 4-byte aligned base of the current packet
+  // 4-byte aligned base of the current packet - as a GLOBAL pointer: through a generic one the block load is a FLAT load, which
+  // counts on the LDS counter as well, and wherever the compiler then copies the block's register (every join of a loop that may
+  // refill it: the rolled colour loop of a P-frame's literal) it waits for "vmcnt(0) lgkmcnt(0)" - i.e. for the ds_add of the
+  // symbol before, ~70 cycles, twice per colour symbol of a P-frame (round 4; the ISA listing showed it, no counter did)
+  typedef const __attribute__((address_space(1))) u32* GlobalWords;
+  GlobalWords wbase = nullptr;
   u32 wpos = 0, wmax = 0;       // next word to take, the word that holds the last byte of the packet buffer
   u32 tailmask = 0;             // the bytes of word wmax that lie at or past the end of the buffer
   u32 blk = 0;                  // lane i: word i of the current 64-word block
@@ -855,7 +860,7 @@ struct WaveDec : WaveModel {
   __device__ __forceinline__ void stream_init(const u8* s) {  // decodeBegin, screencap.h:295-301
     wave_fence();
     const size_t a = (size_t)rfl64((u64)(size_t)s);  // wave-uniform: keeps the whole stream state in scalar registers
-    wbase = (const u32*)(a & ~(size_t)3);
+    wbase = (GlobalWords)(a & ~(size_t)3);
     const u32 skip = (u32)(a & 3);
     const size_t e = (size_t)rfl64((u64)(size_t)src_end), ab = a & ~(size_t)3;
     wmax = e > ab ? (u32)((e - 1 - ab) >> 2) : 0u;

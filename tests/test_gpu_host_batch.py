@@ -22,7 +22,7 @@ def _flat(w, h, rgb):
 
 @pytest.mark.parametrize("w,h,n,keys_every,sub", [(320, 240, 12, 1, 0), (320, 240, 14, 5, 4), (100, 37, 9, 3, 2), (640, 360, 7, 7, 3)])
 def test_host_batch_calls_equal_the_oracle_stream(w, h, n, keys_every, sub, monkeypatch):
-    """numpy memory (registered with the runtime on first use), key frames and P-frames, a flat frame and a repeated flat frame in
+    """numpy memory (pageable: the calls go through the runtime's staging copies), key frames and P-frames, a flat frame and a repeated flat frame in
     the stream, sub-batches that cut GOPs (SCPR_HOST_SUB: frames per sub-batch); odd pitch (100 x 37: rows of 400 bytes, 16-byte aligned; plane rows padded)"""
     if sub:
         monkeypatch.setenv("SCPR_HOST_SUB", str(sub))
@@ -45,7 +45,7 @@ def test_host_batch_calls_equal_the_oracle_stream(w, h, n, keys_every, sub, monk
     out = np.zeros(n * w * h * 4, np.uint8)
     r, got = dec.DecompressBatchHost(np.ascontiguousarray(pk), sizes, fts, out=out)
     assert r == n and np.array_equal(got.reshape(n, h, w, 4), frames)
-    # the same buffers again (now known to the runtime), the stream continued with P-frames across the call boundary
+    # the stream continued with P-frames across the call boundary
     more = np.stack([seq.frame(n + t) for t in range(3)])
     ref2 = [ora.compress(f, key=False) for f in more]
     pk2, sizes2, fts2 = enc.CompressBatchHost(np.ascontiguousarray(more).reshape(-1), [1, 1, 1])
@@ -117,3 +117,32 @@ def test_host_batch_compress_that_does_not_fit_is_taken_back():
         enc.CompressBatchHost(host_in, ft_in, out=np.empty(need - 3, np.uint8))
     pk, sizes, fts = enc.CompressBatchHost(host_in, ft_in, out=np.empty(need, np.uint8))
     assert pk.tobytes() == b"".join(p for p, _ in ref)
+
+
+def test_host_batch_calls_on_buffers_pinned_through_the_codec():
+    """scpr_host_pin: numpy buffers the caller reuses are pinned and mapped once - the calls then take the path of pinned memory
+    (DMA uploads, packets gathered into the host's buffer, rows sent by the decoder's chains) - and released again"""
+    w, h, n = 320, 200, 10
+    seq = DesktopSequence(w, h, seed=21, sparkles=8)
+    ora = O.OracleCodec(w, h, 32)
+    enc, dec = _codec(w, h), _codec(w, h)
+    buf_in = np.zeros(n * w * h * 4, np.uint8)
+    buf_pk = np.zeros(n * w * h, np.uint8)
+    buf_out = np.zeros(n * w * h * 4, np.uint8)
+    enc.HostPin(buf_in).HostPin(buf_pk)
+    dec.HostPin(buf_pk).HostPin(buf_out)
+    for rnd in range(3):  # the same buffers round after round
+        frames = np.stack([seq.frame(rnd * n + t) for t in range(n)])
+        buf_in[:] = frames.reshape(-1)
+        ft_in = [0 if (rnd == 0 and t == 0) or t == 6 else 1 for t in range(n)]
+        ref = [ora.compress(f, key=(k == 0)) for f, k in zip(frames, ft_in)]
+        pk, sizes, fts = enc.CompressBatchHost(buf_in, ft_in, out=buf_pk)
+        assert pk.tobytes() == b"".join(p for p, _ in ref), rnd
+        buf_out[:] = 0
+        r, got = dec.DecompressBatchHost(pk, sizes, fts, out=buf_out)
+        assert r == n and np.array_equal(got.reshape(n, h, w, 4), frames), rnd
+    dec.HostUnpin(buf_pk).HostUnpin(buf_out)  # (buf_pk was pinned by the encoder's codec first: the decoder's only borrowed it)
+    enc.HostUnpin(buf_in).HostUnpin(buf_pk)
+    # and unpinned again, the same buffers still work (staging copies)
+    pk, sizes, fts = enc.CompressBatchHost(buf_in, [1] * n, out=buf_pk)
+    assert len(sizes) == n

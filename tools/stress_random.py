@@ -4,7 +4,7 @@ import sys, os, time
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 import numpy as np, torch
 import oracle_api as O
-from screenpressor_amd.codec import ScreenCodec
+from screenpressor_amd.codec import ScreenCodec, CapacityError
 from screenpressor_amd.synth import DesktopSequence
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
@@ -53,11 +53,33 @@ for case in range(seed0, seed0 + cases):
         if os.environ.get("VERBOSE"): print("  case", case, "call at frame", t, "size", m, file=sys.stderr, flush=True)
         dev = torch.from_numpy(frames[t:t + m]).cuda().reshape(m, -1)
         try:
-            pk, sizes, fts = enc.CompressBatch(dev, [0 if k else 1 for k in keys[t:t + m]])
             ref = [ora.compress(f, key=k) for f, k in zip(frames[t:t + m], keys[t:t + m])]
+            need = sum(len(p) for p, _ in ref)
+            ft_in = [0 if k else 1 for k in keys[t:t + m]]
+            # round 4: every call is first REFUSED one time in three (a buffer that is too small: the codec must be as it was),
+            # and goes through the host-pointer form one time in three (numpy memory, a random sub-batch size)
+            mode = int(rng.integers(0, 3))
+            if rng.random() < 0.33 and need > 1:
+                room = int(rng.integers(1, need))
+                try:
+                    if mode == 1: enc.CompressBatchHost(np.ascontiguousarray(frames[t:t + m]).reshape(-1), ft_in, out=np.empty(room, np.uint8))
+                    else: enc.CompressBatch(dev, ft_in, out=torch.empty(room, dtype=torch.uint8, device="cuda"))
+                    print("case", case, "a buffer of", room, "bytes for", need, "was not refused", flush=True); ok = False; break
+                except CapacityError:
+                    pass
+            if mode == 1:
+                os.environ["SCPR_HOST_SUB"] = str(int(rng.choice([1, 2, 3, 7, 50])))
+                hpk, sizes, fts = enc.CompressBatchHost(np.ascontiguousarray(frames[t:t + m]).reshape(-1), ft_in)
+                pk = torch.from_numpy(np.array(hpk)).cuda()
+            else:
+                pk, sizes, fts = enc.CompressBatch(dev, ft_in)
             if pk.cpu().numpy().tobytes() != b"".join(p for p, _ in ref) or list(fts) != [ft for _, ft in ref]:
                 print("case", case, (w, h, n, style, kprob, workers, loss, hr, lr), "ENCODE differs in call at frame", t, "size", m, flush=True); ok = False; break
-            r, out = dec.DecompressBatch(pk, sizes, fts)
+            if mode == 1:
+                r, hout = dec.DecompressBatchHost(np.array(pk.cpu().numpy()), sizes, fts)
+                out = torch.from_numpy(hout).cuda()
+            else:
+                r, out = dec.DecompressBatch(pk, sizes, fts)
             if lossy:  # the decoded frames are what the oracle's decoder gives for the same packets
                 if not hasattr(ora, "_d"): ora._d = O.OracleCodec(w, h, 32, loss=loss, high_range=hr, low_range=lr)
                 want = np.stack([ora._d.decompress(p, ft)[1].reshape(h, w, 4) for p, ft in ref])
