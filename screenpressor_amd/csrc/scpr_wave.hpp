@@ -2248,7 +2248,10 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
       if (pt == 0) {
         lastpix = rdl(pend_v, pend_last) & 0xFFFFFFu;  // the last pixel of the run before (long arrived)
         u32 a = (lastpix >> 18) & 63, bb = (lastpix >> 10) & 63;
-#pragma unroll 1
+        // (unrolled: a rolled loop carries the packet block's register round its back edge, and every copy of it waits for
+        // whatever load may still be writing it - 11.03 -> 10.58 ms per P-frame, round 4; in round 3, with the block load a FLAT
+        // load whose waits also covered the LDS queue, the unrolled form had measured slower and the blame went to the instruction cache)
+#pragma unroll
         for (int plane = 0; plane < 3; plane++) {
           u32 c;
           if constexpr (CHAIN) c = (u32)D.template colour<false, 2, true>(plane * 4096 + (int)(a | (bb << 6)), pend);
@@ -2296,9 +2299,15 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
         u32 v = px;
         if (pt != 0) {
           // where lane 0 reads (a cell of the tile, or - cells past the tile's end - of the previous frame's rect), and whether
-          // the lanes read side by side (above, above-left, previous frame) or all the same cell (left): scalar selects
-          const int s0 = pt == 3 ? (int)(ptile - tile) + li : base + (pt == 1 ? -1 : pt == 2 ? -17 : -18);
-          const int each = pt == 1 ? 0 : -1;
+          // the lanes read side by side (above, above-left, previous frame) or all the same cell (left).  ARITHMETIC on the type,
+          // not choices: the optimiser turned the nested choices into a tree of branches (flag registers, exec tests, four taken
+          // branches with padding between their blocks: ~25 instructions where these are 14; round 4, ISA listing of the run loop)
+          u32 upt = (u32)pt;
+          asm volatile("" : "+s"(upt));
+          const int back = 1 + (int)(min(upt >> 1, 1u) << 4) + (int)(upt >> 2);  // 1 -> 1 (left), 2 -> 17 (above), 5 -> 18 (above-left)
+          const u32 is3 = 0u - (((upt ^ 3u) - 1u) >> 31);                          // all ones for 3 (previous frame)
+          const int s0 = (int)((is3 & (u32)((int)(ptile - tile) + li)) | (~is3 & (u32)(base - back)));
+          const int each = 0 - (int)((0u - (upt ^ 1u)) >> 31);                     // 0 for 1 (every lane the same cell), -1 otherwise
           v = tile[s0 + (lc & each)];
         }
         // (no lane mask: the lanes past the run will write to the spare cell)
