@@ -890,6 +890,7 @@ struct WaveDec : WaveModel {
   // colour symbols by class (0 top entry of a small table, 1 another entry, 2 small table's general path, 3 dense hit, 4 dense
   // general path, 5 raw, 6 record-cache miss [the miss alone, also inside its symbol's class], 7 dense-table cache miss [likewise])
   u64 cprof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, cls_t0 = 0;
+  u64 rprof[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // P-frame runs through the general fills: all, literal, left, above, previous frame, above-left / gradient, longer than 64, their pixels
   __device__ __forceinline__ void cls_begin() { cls_t0 = __builtin_readcyclecounter(); }
   template <int K>
   __device__ __forceinline__ void cls_end() {
@@ -2334,6 +2335,14 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
       if constexpr (DEC::kFastRuns && FAST) asm volatile("" : "+s"(slow_run));
       else slow_run = (int)rfl((u32)slow_run);  // (the careful instance, and the version 2 decoder, whose symbols come off the vector unit)
       if (SCPR_UNLIKELY(slow_run >= 0)) {
+#ifdef SCPR_PROFILE
+        if constexpr (std::is_same<DEC, WaveDec>::value) {
+          D.rprof[0]++;
+          D.rprof[1] += pt == 0, D.rprof[2] += pt == 1, D.rprof[3] += pt == 2, D.rprof[4] += pt == 3, D.rprof[5] += pt > 3;
+          D.rprof[6] += rem > 64;
+          D.rprof[7] += (u64)(rem > 0 ? rem : 0);
+        }
+#endif
         wave_fence();
         tile[pend_at] = pend_v;  // (the general forms work on the tile as it is and hand the last pixel over at once)
         wave_fence();
@@ -2572,6 +2581,7 @@ __global__ __launch_bounds__(HAS_P ? 512 : 128) void k_decode_gop_w(const u8* __
   if (lane == 0) {
     D.cprof[14] += D.dmiss_ticks, D.cprof[15] += D.dmiss;
     for (int i = 0; i < 16; i++) atomicAdd((unsigned long long*)&g_cprof[i], (unsigned long long)D.cprof[i]);
+    for (int i = 0; i < 8; i++) atomicAdd((unsigned long long*)&g_cprof[16 + i], (unsigned long long)D.rprof[i]);
   }
 #endif
 }

@@ -79,4 +79,7 @@ if True:
                    "events_per_frame": {nm: x / n for nm, x in zip(["colour symbols", "record cache misses", "dense-table symbols", "raw symbols", "small-table slow path", "runs", "literal runs", "dense-table cache misses"], ev)},
                    "extra_ticks_per_frame": {"rect write-back": ex[3] / n, "motion blocks": ex[4] / n, "run length end to end of single-row fill": ex[5] / n, "general fills": ex[6] / n},
                    "colour_classes": classes}, open(os.environ["SCPR_PROFILE_JSON"], "w"), indent=1)
+if IP:
+    rp = [x / n for x in cpv[16:24]]
+    print("P-frame runs through the general fills, per frame: %.0f (literal %.0f, left %.0f, above %.0f, previous frame %.0f, above-left / gradient %.0f; longer than 64: %.0f; %.1f pixels each)" % (rp[0], rp[1], rp[2], rp[3], rp[4], rp[5], rp[6], rp[7] / max(rp[0], 1)))
 print("P-frame, more sections (ticks/frame): rect write-back %.0f, motion blocks (symbols, hand-over) %.0f; after the run length to the end of the single-row fill %.0f, general fills %.0f ('runs' above is then the loop between runs)" % (ex[3] / n, ex[4] / n, ex[5] / n, ex[6] / n))
