@@ -53,6 +53,7 @@ def parse_args(argv=None):
     ap.add_argument("--c4-leg", action="store_true", help="run the configs[3] leg of an N > 1 run at N = 1 too (to rehearse it)")
     ap.add_argument("--c4-frames", type=int, default=None, help="frames of the configs[3] leg's stream (default 1200)")
     ap.add_argument("--no-others", action="store_true", help="N = 1: do not measure the other single-GPU configs")
+    ap.add_argument("--no-host-boundary", action="store_true", help="N = 1: skip config.host_boundary and the per-frame calls (profiling runs: their launches would mix into the per-kernel figures of the HBM-resident step)")
     ap.add_argument("--rehearse-one-gpu", action="store_true", help="N > 1 on a one-GPU box: every rank on GPU 0, collectives over gloo on CPU tensors (rehearses the multi-rank path with the real codecs; not a scaling measurement)")
     ap.add_argument("--selftest-launcher", action="store_true", help="no codec, no GPU: ranks exchange synthetic packets over gloo (tests the launcher, the sharding and the gather)")
     return ap.parse_args(argv)
@@ -781,7 +782,7 @@ def run_rank(args):
                   "stage_ms_per_step": {k: round(v, 3) for k, v in per_step.items()}}
         if world > 1 and head_gathered is not None:
             config["gathered_frames_rank0"], config["gathered_bytes_rank0"] = head_gathered
-        if world == 1 and frames is not None:
+        if world == 1 and frames is not None and not args.no_host_boundary:
             # The boundary hands over HOST buffers (ScreenCodec::CompressFrame takes host pointers, screencap.cpp:1632; DecompressFrame
             # :1695).  config.host_boundary: the same pass through scpr_compress_batch_host / scpr_decompress_batch_host - frames in
             # pinned host memory, packets into host memory, pictures back into host memory - where the transfers run beside the kernels
@@ -826,7 +827,7 @@ def run_rank(args):
                 del h_in, h_out, h_pk
             except Exception as e:  # noqa: BLE001
                 config["incl_host_transfer_MPix_s"] = f"not measured: {e}"
-        if world == 1 and frames is not None and (W, H) == (1920, 1080) and args.workload == "keys":
+        if world == 1 and frames is not None and (W, H) == (1920, 1080) and args.workload == "keys" and not args.no_host_boundary:
             try:
                 config["per_frame_api_ms"] = dict(per_frame_api_ms(local_rank, [f.reshape(-1) for f in frames[:8].cpu().numpy()], W, H, BPP),
                                                   note="ScreenCodec::CompressFrame / DecompressFrame one frame per call, host pointers, PCIe included (median of 8 frames: 2 key, 6 P)")

@@ -1807,6 +1807,11 @@ __device__ __forceinline__ void decode_intra_frame(DEC& D, const Geom& g, u8* __
       if (SCPR_UNLIKELY(D.oom)) lim = p;
     }
     D.template stamp<2>();
+#ifdef SCPR_PROFILE
+    if constexpr (std::is_same<DEC, WaveDec>::value) {  // key-frame runs by pixel type (slots 1.. of rprof: 0 1 2 [3] 4 5), and those longer than a pass
+      D.rprof[1] += t == 0, D.rprof[2] += t == 1, D.rprof[3] += t == 2, D.rprof[4] += t == 4, D.rprof[5] += t == 5, D.rprof[6] += n > 64, D.rprof[7] += (u64)n;
+    }
+#endif
     // an empty run, or one longer than what is left (of the header row), ends the frame like the type that does not exist
     const int tt = SCPR_UNLIKELY((u32)(n - 1) >= (u32)(lim - p)) ? 3 : t;
     const int nf = ((slow_types >> tt) & 1u) ? 0 : n;  // pixels of the run for the common path below

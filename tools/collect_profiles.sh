@@ -15,14 +15,14 @@ export TMPDIR=/tmp
 # while its own sources still have this digest)
 python3 -c "import sys, datetime; sys.path.insert(0, '$R'); import bench; print(bench.csrc_digest()); print(datetime.datetime.utcnow().strftime('%Y-%m-%dT%H:%MZ'))" > $OUT/csrc_sha256.txt
 cd /tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/stats -o run --output-format csv -- python3 $R/bench.py --no-others --steps 3 --warmup 1 --cpu-frames 24 > $OUT/bench_stats.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/stats -o run --output-format csv -- python3 $R/bench.py --no-others --no-host-boundary --steps 3 --warmup 1 --cpu-frames 24 > $OUT/bench_stats.log 2>&1
 echo stats done
-timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/stats_ip -o run --output-format csv -- python3 $R/bench.py --workload ip --gop 50 --no-cpu --steps 2 --warmup 1 > $OUT/bench_stats_ip.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/stats_ip -o run --output-format csv -- python3 $R/bench.py --workload ip --gop 50 --no-cpu --no-host-boundary --steps 2 --warmup 1 > $OUT/bench_stats_ip.log 2>&1
 echo ip stats done
-timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/stats_4k -o run --output-format csv -- python3 $R/bench.py --width 3840 --height 2160 --frames 150 --no-cpu --steps 2 --warmup 1 > $OUT/bench_stats_4k.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/stats_4k -o run --output-format csv -- python3 $R/bench.py --width 3840 --height 2160 --frames 150 --no-cpu --no-host-boundary --steps 2 --warmup 1 > $OUT/bench_stats_4k.log 2>&1
 echo 4k stats done
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c -d $OUT/pmc_$c -o run --output-format csv -- python3 $R/bench.py --no-others --steps 1 --warmup 0 --no-cpu > $OUT/bench_$c.log 2>&1
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c -d $OUT/pmc_$c -o run --output-format csv -- python3 $R/bench.py --no-others --no-host-boundary --steps 1 --warmup 0 --no-cpu > $OUT/bench_$c.log 2>&1
   echo $c done
 done
 cd $R

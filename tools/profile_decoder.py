@@ -79,6 +79,9 @@ if True:
                    "events_per_frame": {nm: x / n for nm, x in zip(["colour symbols", "record cache misses", "dense-table symbols", "raw symbols", "small-table slow path", "runs", "literal runs", "dense-table cache misses"], ev)},
                    "extra_ticks_per_frame": {"rect write-back": ex[3] / n, "motion blocks": ex[4] / n, "run length end to end of single-row fill": ex[5] / n, "general fills": ex[6] / n},
                    "colour_classes": classes}, open(os.environ["SCPR_PROFILE_JSON"], "w"), indent=1)
+if not IP:
+    rp = [x / n for x in cpv[16:24]]
+    print("key-frame runs by pixel type, per frame: literal %.0f, previous pixel %.0f, above %.0f, gradient %.0f, above-left %.0f; longer than 64 pixels: %.0f; %.1f pixels per run" % (rp[1], rp[2], rp[3], rp[4], rp[5], rp[6], rp[7] / max(rp[1] + rp[2] + rp[3] + rp[4] + rp[5], 1)))
 if IP:
     rp = [x / n for x in cpv[16:24]]
     print("P-frame runs through the general fills, per frame: %.0f (literal %.0f, left %.0f, above %.0f, previous frame %.0f, above-left / gradient %.0f; longer than 64: %.0f; %.1f pixels each)" % (rp[0], rp[1], rp[2], rp[3], rp[4], rp[5], rp[6], rp[7] / max(rp[0], 1)))
