@@ -16,6 +16,7 @@
 #include "../../include/scpr_amd.h"
 #include "scpr_kernels.hpp"
 #include "scpr_wave.hpp"
+#include "scpr_rans_s.hpp"
 #include "scpr_fixed.hpp"
 #include "scpr_v2.hpp"
 #include "scpr_inter.hpp"
@@ -110,7 +111,7 @@ struct scpr_codec {
   size_t tn_half = 0;
   // per-batch buffers
   DevBuf flags, slotlist, genlist, bases, totals, runs, runpos, keys[2], vals[2], cstart, sorttmp, entries, ranges;
-  DevBuf rblocks, rscratch, rsize, packets, pktoff, blkdst, outsizes, total64, arena, arena2, arena_top, err, rcp;  // (arena2: where compact_tables moves the live tables)
+  DevBuf rblocks, rscratch, rrec, rsize, packets, pktoff, blkdst, outsizes, total64, arena, arena2, arena_top, err, rcp;  // (arena2: where compact_tables moves the live tables)
   DevBuf decframes, decstates, hoststage_in, hoststage_out, chainlists, chaincounts;
   FixBufs fixr, fixm;  // run list / P-frame symbol list
   // P-frame buffers
@@ -564,6 +565,16 @@ static int fixed_chains(scpr_codec* c, hipStream_t s2, FixBufs& fb, const u32* e
   (void)c;
   return SCPR_OK;
 }
+// Blocks per call up to which the rANS stage runs one wave per block with the state on the scalar unit (k_rans_s,
+// scpr_rans_s.hpp).  A wave of that form alone on its SIMD takes ~67 cycles per entry (3.7 ms for a full block), two on one SIMD
+// take turns at the scalar unit (6.4 ms), three 9.0; k_rans' vector form takes 7.5 ms whatever the count.  The card has 1024
+// SIMDs and the workgroups (four waves, one per SIMD of a CU) spread evenly enough for 2040 blocks to stay at two per SIMD
+// (tools/exp_rans.py).  SCPR_RANS_SCALAR_MAX overrides it (0: always the vector form; tests and A/B timing).
+constexpr int kRansScalarMax = 2048;
+static int rans_scalar_max() {
+  const char* e = getenv("SCPR_RANS_SCALAR_MAX");
+  return e ? atoi(e) : kRansScalarMax;
+}
 static u64 chunk_total_limit() {  // SCPR_DEBUG_CHUNK_LIMIT: tests reach the re-cut of a chunk with small frames (read per chunk: a test may set it)
   const char* e = getenv("SCPR_DEBUG_CHUNK_LIMIT");
   return e ? strtoull(e, nullptr, 0) : kChunkTotalLimit;
@@ -912,7 +923,7 @@ void scpr_destroy(scpr_codec* c) {
   }
   DevBuf* all[] = {&c->hb_frames, &c->hb_packets, &c->hb_list, &c->snap_mvs, &c->snap_state, &c->planes, &c->tnmap, &c->exitmap, &c->entry, &c->runrec, &c->tilecnt, &c->tileoff, &c->hdrrec, &c->hdrcnt, &c->frametot, &c->flags, &c->slotlist, &c->genlist,
                    &c->bases, &c->totals, &c->runs, &c->runpos, &c->keys[0], &c->keys[1], &c->vals[0], &c->vals[1], &c->cstart, &c->sorttmp,
-                   &c->entries, &c->ranges, &c->rblocks, &c->rscratch, &c->rsize, &c->packets, &c->pktoff, &c->blkdst, &c->outsizes, &c->total64, &c->arena,
+                   &c->entries, &c->ranges, &c->rblocks, &c->rscratch, &c->rrec, &c->rsize, &c->packets, &c->pktoff, &c->blkdst, &c->outsizes, &c->total64, &c->arena,
                    &c->arena_top, &c->err, &c->rcp, &c->decframes, &c->decstates, &c->hoststage_in, &c->hoststage_out, &c->chainlists, &c->chaincounts, &c->fixr.cnt, &c->fixr.off, &c->fixr.tot, &c->fixr.sym, &c->fixr.pos, &c->fixr.gen, &c->fixm.cnt, &c->fixm.off, &c->fixm.tot, &c->fixm.sym, &c->fixm.pos, &c->fixm.gen, &c->kinds, &c->pidx, &c->fidx, &c->pframes, &c->pflag, &c->binfo, &c->smv, &c->btype, &c->bmv, &c->bcnt, &c->boff, &c->bflag, &c->pinfo, &c->ptot, &c->pbase, &c->misc, &c->miscpos, &c->miscranges, &c->mvs, &c->mvs_keep, &c->fixed_persist, &c->misc_persist, &c->colour_persist, &c->decgops, &c->decfixed, &c->dec_fixed_persist, &c->dec_colour_persist, &c->dec_arena, &c->dec_arena2, &c->arena2, &c->dec_arena_top, &c->mvdict, &c->mvpre, &c->gmask};
   for (DevBuf* b : all) b->release();
   for (int s = 0; s < ST_COUNT + 1; s++)
@@ -1311,8 +1322,14 @@ static int64_t compress_core(scpr_codec* c, const void* d_frames, int nframes, i
     HIPCHK(h2d(c, c->packets.p, pk.data(), (size_t)n * sizeof(Packet), st));
     if (nb) {
       stage_begin(c, ST_RANS);
-      hipLaunchKernelGGL(k_rans, dim3((nb + 63) / 64), dim3(256), 0, st, c->entries.as<u32>(), c->rblocks.as<RansBlock>(), nb, c->rcp.as<RansRcp>(), c->rscratch.as<u8>(),
-                         c->rsize.as<u32>(), c->err.as<u32>());
+      if (nb <= rans_scalar_max()) {
+        HIPCHK(c->rrec.reserve((size_t)nb * RANS_S_RING * RANS_S_TRIP * 16));  // a ring of records per block
+        hipLaunchKernelGGL(k_rans_s, dim3((nb + 3) / 4), dim3(256), 0, st, c->entries.as<u32>(), c->rblocks.as<RansBlock>(), c->rcp.as<RansRcp>(), c->rrec.as<uint4>(), nb,
+                           c->rscratch.as<u8>(), c->rsize.as<u32>(), c->err.as<u32>());
+      } else {
+        hipLaunchKernelGGL(k_rans, dim3((nb + 63) / 64), dim3(256), 0, st, c->entries.as<u32>(), c->rblocks.as<RansBlock>(), nb, c->rcp.as<RansRcp>(), c->rscratch.as<u8>(),
+                           c->rsize.as<u32>(), c->err.as<u32>());
+      }
       stage_end(c, ST_RANS);
     }
     stage_begin(c, ST_GATHER);

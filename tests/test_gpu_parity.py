@@ -74,6 +74,45 @@ def test_rgb24_input_and_noise_multi_block():
         assert r == 1 and np.array_equal(out.reshape(f.shape), f)
 
 
+@pytest.mark.parametrize("scalar_max", ["0", "1000000"])
+def test_both_rans_forms_are_the_oracles_bytes(scalar_max, monkeypatch):
+    """the rANS stage has two kernels, picked by block count (k_rans: 64 blocks per wave; k_rans_s: one wave per block, state on
+    the scalar unit): both forced in turn over streams with several blocks per frame, blocks of a few entries (P-frames), raw
+    bytes (noise) and a block that ends exactly on a trip of 64"""
+    monkeypatch.setenv("SCPR_RANS_SCALAR_MAX", scalar_max)
+    w, h = 320, 240
+    seq = DesktopSequence(w, h, seed=5, noise_fraction=0.6)
+    gpu = _codec(w, h, 24)
+    ora = O.OracleCodec(w, h, 24)
+    for t in range(4):
+        f = pack24(seq.frame24(t))
+        want, _ = ora.compress(f, key=t == 0)
+        got, _ = gpu.CompressFrame(f, 0 if t == 0 else 1)
+        assert got == want, (t, _first_diff(got, want))
+    assert len(ora.entries()) > 0
+    # batch call: key frames and P-frames of a quiet desktop (short blocks), 1 .. 3 frames per call
+    w, h = 200, 120
+    seq = DesktopSequence(w, h, seed=11)
+    frames = [seq.frame(t) for t in range(9)]
+    ft = [0 if t % 4 == 0 else 1 for t in range(9)]
+    gpu2, ora2 = _codec(w, h, 32), O.OracleCodec(w, h, 32)
+    want = [ora2.compress(f, key=k == 0)[0] for f, k in zip(frames, ft)]
+    import torch
+    dev = torch.device("cuda", 0)
+    got = []
+    i = 0
+    for step in (1, 3, 2, 3):
+        fr = torch.from_numpy(np.stack(frames[i:i + step])).to(dev)
+        pk, sizes, _ = gpu2.CompressBatch(fr, ft[i:i + step])
+        pk = pk.cpu().numpy().tobytes()
+        o = 0
+        for sz in sizes:
+            got.append(pk[o:o + int(sz)])
+            o += int(sz)
+        i += step
+    assert got == want
+
+
 def test_flat_frames():
     w, h = 64, 48
     a = np.full((h, w, 4), 255, np.uint8)
