@@ -1770,10 +1770,13 @@ int64_t scpr_compress_batch_host(scpr_codec* c, const void* h_frames, int nframe
     HIPCHK(c->hb_packets.reserve(dev_cap + 64));
     out_dev = c->hb_packets.p;
   }
-  // sub-batches: big enough that the coder's one serial chain per call (7.5 ms whatever the frames) is paid a few times only, small
-  // enough that the first one's transfer is not all of the wait: a third of the call, at least 16 frames
+  // sub-batches: the call ends one sub-batch's coding after the last upload, so the smaller the better - until a sub-batch's
+  // coding (its front end + ONE rANS block chain, 3.7 ms in the scalar form, + the call's read-backs: 0.045 ms per 1080p frame +
+  // 4.7 ms) takes longer than the next one's upload (0.145 ms per frame at 57 GB/s): about 400 MB of frames, 48 at 1080p, 12 at 4K
+  // (tools/exp_host.py: 300 frames of 1080p in sub-batches of 100 / 75 / 60 / 50 / 43 / 30: 52.8 / 52.0 / 51.2 / 50.9 / 54.4 / 68.3 ms)
   const int sub_env = getenv("SCPR_HOST_SUB") ? atoi(getenv("SCPR_HOST_SUB")) : 0;  // (tests and tuning: frames per sub-batch)
-  const int sub = std::max(1, std::min(nframes, sub_env > 0 ? sub_env : std::max(16, (nframes + 2) / 3)));
+  const int sub_auto = (int)std::min<size_t>((size_t)nframes, ((size_t)400 << 20) / frame_bytes + 1);
+  const int sub = std::max(1, std::min(nframes, sub_env > 0 ? sub_env : sub_auto));
   const int nsub = (nframes + sub - 1) / sub;
   HIPCHK(c->hb_frames.reserve((size_t)std::min(nframes, 2 * sub) * frame_bytes));
   EncTxn txn;
