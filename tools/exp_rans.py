@@ -26,13 +26,17 @@ def main():
                 pk, sizes, fts = c.CompressBatch(f[:n], [0] * n, out=out)
                 best = min(best, c.last_timing()[1]["rans"])
             tot = int(sum(sizes))
+            ne = int(c._L.scpr_debug_entries(c._h, None, 0))
             if pk0 is None:
                 pk0 = pk[:tot].clone()
             else:
                 assert torch.equal(pk0, pk[:tot]), "the two forms differ"
             row.append(best)
             del c
-        print("%4d key frames (~%5d blocks): vector %.2f ms, scalar %.2f ms" % (n, n * 6, row[0], row[1]), flush=True)
+        print("%4d key frames (~%5d blocks, %d coder entries): vector %.2f ms, scalar %.2f ms" % (n, n * 6, ne, row[0], row[1]), flush=True)
+        if os.environ.get("SCPR_RANS_JSON"):
+            import json
+            json.dump({"frames": n, "entries_per_encode": ne, "encodes_per_form": 3, "ms": {"vector": row[0], "scalar": row[1]}}, open(os.environ["SCPR_RANS_JSON"], "w"))
 
 
 if __name__ == "__main__":
