@@ -91,8 +91,15 @@ int scpr_decompress_frame(scpr_codec* c, const void* src, int src_len, void* dst
  * How: a chunk's packets are bounded before anything is coded (2 bytes per coder
  * entry + 4 per block of 131072 + headers); only when that bound exceeds the room
  * left is the state the chains are about to change copied aside first (models,
- * live dense tables, previous frame: ~10-30 MB device to device), so a call with
- * W*H*6 bytes per frame never pays for it. */
+ * live dense tables, previous frame: ~10-30 MB device to device).  A call that may
+ * be cut into several chunks (more than 512 frames, or a per-frame scratch limit)
+ * copies that state at its start unless out_capacity covers the closed-form worst
+ * case, about 10 bytes per pixel and frame; a call of one chunk - every call of the
+ * reference's shape, W*H*6 bytes per frame - pays only when the exact bound says so.
+ * Any OTHER error (< 0) from a compress call: if the call had kept that copy it is
+ * taken back whole as well; if not, the codec is left as the reference leaves
+ * itself after an exception (screencap.cpp:1634-1644): scpr_compress_* return 0
+ * for every later frame until scpr_init() is called again. */
 int64_t scpr_compress_batch(scpr_codec* c, const void* d_frames, int nframes, int* ftypes, int loss,
                             void* d_out, size_t out_capacity, uint32_t* sizes);
 
@@ -169,22 +176,6 @@ int scpr_import_mv_memory(scpr_codec* c, const int32_t* mx, const int32_t* my);
 int scpr_motion_prepass(scpr_codec* c, const void* d_frames, int nframes, const int* ftypes, int loss,
                         int32_t* mx, int32_t* my);
 
-/* ---- placement (addition) -------------------------------------------------- */
-/* Confines the codec's kernels to the compute units whose bits are set in
- * `mask` (`words` 32-bit words, bit i = compute unit i as the HIP runtime
- * numbers them; hipExtStreamCreateWithCUMask).  The codec's streams are made
- * again; call it between calls, not during one.  words = 0 lifts the limit.
- * For running two codecs side by side on one card - a decoder's chains (one
- * wave per GOP) beside another codec's encoder - without either taking the
- * other's LDS and issue slots.  Returns 0 or < 0.
- * Stream semantics change with a mask: hipExtStreamCreateWithCUMask takes no
- * flags, so the masked streams are BLOCKING streams - they synchronise
- * implicitly with the NULL stream (torch's default stream is the NULL stream),
- * where the codec's ordinary streams are hipStreamNonBlocking.  A caller that
- * wants two masked codecs side by side keeps its own work off the NULL stream
- * (torch: a non-default stream) while they run. */
-int scpr_set_cu_mask(scpr_codec* c, const uint32_t* mask, int words);
-
 /* ---- instrumentation ------------------------------------------------------ */
 /* Kernel time of the last batch call, measured with HIP events on the codec's
  * own stream: total milliseconds and, per stage, milliseconds in `stage_ms`
@@ -202,11 +193,20 @@ int64_t scpr_debug_entries(scpr_codec* c, uint16_t* out, int64_t cap);
  * the compress side and of the decompress side. */
 int scpr_debug_arena(scpr_codec* c, uint64_t* enc_bytes, uint64_t* dec_bytes);
 
-/* Test hook: the next scpr_compress_batch fails on purpose.  1: SCPR_E_DEVICE between
- * the read-backs of its results and their hand-over to the caller's variables (what a
- * HIP error there leaves queued); 2: two colour keys change places behind the radix
- * sort (an unsorted result: the call ends with SCPR_E_DEVICE, no chain is followed). */
+/* Test hook, inert (SCPR_E_PARAM) unless the codec was created with
+ * SCPR_ENABLE_DEBUG_INJECT=1 in the environment: the next scpr_compress_batch
+ * misbehaves on purpose.  1: SCPR_E_DEVICE between the read-backs of its results and
+ * their hand-over to the caller's variables (what a HIP error there leaves queued);
+ * 2: two colour keys change places in front of the chains (the order proof must end
+ * the call with SCPR_E_DEVICE, no chain is followed); 3: one trip's records of the
+ * scalar-unit rANS coder are not laid, i.e. the scalar unit reads a lap-old line
+ * (the coder's own check must notice, the call's blocks are coded again in the
+ * vector form and the call returns the right bytes). */
 int scpr_debug_inject(scpr_codec* c, int what);
+
+/* Test tap: how many compress calls of this codec had their rANS blocks coded a
+ * second time because the scalar-unit coder's check (see above) spoke. */
+int scpr_debug_rans_recoded(scpr_codec* c);
 
 /* Test hook: runs ONE colour context over `n` symbols through the wave-per-chain
  * encoder kernel and returns the coder entries ({freq, cum} pairs; freq 0 = raw). */

@@ -18,7 +18,7 @@ _LIB_PATH = os.environ.get("SCPR_AMD_LIB", os.path.join(_PKG, "libscpr_amd.so"))
 SCPR_OK, SCPR_E_DEVICE, SCPR_E_PARAM, SCPR_E_BAD_VERSION, SCPR_E_CAPACITY, SCPR_E_STREAM = 0, -1, -2, -3, -4, -5
 EXPORTS = ["scpr_create", "scpr_destroy", "scpr_init", "scpr_deinit", "scpr_crash_happened", "scpr_compress_frame",
            "scpr_decompress_frame", "scpr_compress_batch", "scpr_decompress_batch", "scpr_compress_batch_host", "scpr_decompress_batch_host", "scpr_host_pin", "scpr_host_unpin", "scpr_last_timing", "scpr_stage_name",
-           "scpr_seed_shard", "scpr_export_mv_memory", "scpr_import_mv_memory", "scpr_motion_prepass", "scpr_set_cu_mask", "scpr_debug_entries", "scpr_debug_arena", "scpr_debug_colour_chain", "scpr_debug_inject", "scpr_version",
+           "scpr_seed_shard", "scpr_export_mv_memory", "scpr_import_mv_memory", "scpr_motion_prepass", "scpr_debug_entries", "scpr_debug_arena", "scpr_debug_colour_chain", "scpr_debug_inject", "scpr_debug_rans_recoded", "scpr_version",
            # include/scpr_driver.h, include/scpr_avi.h
            "scpr_driver_open", "scpr_driver_close", "scpr_driver_configure", "scpr_driver_compress_query", "scpr_driver_compress_get_format",
            "scpr_driver_compress_get_size", "scpr_driver_compress_begin", "scpr_driver_compress_end", "scpr_driver_compress",
@@ -79,10 +79,10 @@ def load_library() -> C.CDLL:
         L.scpr_export_mv_memory.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.scpr_import_mv_memory.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.scpr_motion_prepass.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_void_p, C.c_void_p]
-        L.scpr_set_cu_mask.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_int]
         L.scpr_debug_arena.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.scpr_debug_colour_chain.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.scpr_debug_inject.argtypes = [C.c_void_p, C.c_int]
+        L.scpr_debug_rans_recoded.argtypes = [C.c_void_p]
         L.scpr_version.restype = C.c_char_p
         _lib = L
     return _lib
@@ -191,21 +191,6 @@ class ScreenCodec:
                                                       out.ctypes.data_as(C.c_void_p), pitch, ftype))
         return r, out
 
-    def SetCuMask(self, cus):
-        """scpr_set_cu_mask: the codec's kernels on these compute units only (an iterable of CU numbers; None lifts the limit)"""
-        if cus is None:
-            self._check(self._L.scpr_set_cu_mask(self._h, None, 0))
-            return self
-        cus = sorted(set(int(q) for q in cus))
-        if not cus or cus[0] < 0:
-            raise ValueError("SetCuMask: an empty (or negative) list of compute units; None lifts the limit")
-        words = cus[-1] // 32 + 1
-        m = (C.c_uint32 * words)()
-        for q in cus:
-            m[q // 32] |= 1 << (q % 32)
-        self._check(self._L.scpr_set_cu_mask(self._h, m, words))
-        return self
-
     # batch entry points: torch uint8 CUDA tensors in, out
     def CompressBatch(self, frames, ftypes, loss: int | None = None, out=None, sync: bool = True):
         """sync=False: the caller vouches that `frames` is complete (the C side works on the codec's own stream and waits for
@@ -305,8 +290,13 @@ class ScreenCodec:
         return tot.value, {self._L.scpr_stage_name(i).decode(): st[i] for i in range(k)}
 
     def debug_inject(self, what: int):
-        """scpr_debug_inject (tests): the next CompressBatch fails on purpose - 1 between read-back and hand-over, 2 unsorted keys"""
-        self._L.scpr_debug_inject(self._h, what)
+        """scpr_debug_inject (tests; the codec must have been created with SCPR_ENABLE_DEBUG_INJECT=1 in the environment): the next
+        CompressBatch misbehaves on purpose - 1 fails between read-back and hand-over, 2 unsorted keys, 3 a stale record in k_rans_s"""
+        self._check(self._L.scpr_debug_inject(self._h, what))
+
+    def debug_rans_recoded(self) -> int:
+        """calls whose rANS blocks were coded again by k_rans because k_rans_s' own check spoke"""
+        return int(self._L.scpr_debug_rans_recoded(self._h))
 
     def debug_arena(self):
         """(compress side, decompress side) bytes allocated for dense tables"""

@@ -167,6 +167,9 @@ struct scpr_codec {
   bool snap_taken = false;
   size_t snap_tables = 0;
   int dbg_inject = 0;  // scpr_debug_inject: tests make the next compress call fail at a chosen place
+  bool dbg_armed = false;  // ... only in a codec created with SCPR_ENABLE_DEBUG_INJECT=1 in the environment
+  int rans_scalar_max = 0;  // blocks per call up to which the coder is k_rans_s (SCPR_RANS_SCALAR_MAX at creation; 0 once its self-check has failed)
+  int rans_recoded = 0;     // calls whose blocks were coded a second time (k_rans) because k_rans_s' self-check spoke
   // the host-pointer batch calls (scpr_compress_batch_host / scpr_decompress_batch_host): a stream of its own for the copies that
   // run beside the kernels, staging on the device for two sub-batches of frames, and the host ranges this codec has registered
   // with the runtime (hipHostRegister: pinned and mapped into the device's address space; released by scpr_destroy)
@@ -571,10 +574,6 @@ static int fixed_chains(scpr_codec* c, hipStream_t s2, FixBufs& fb, const u32* e
 // SIMDs and the workgroups (four waves, one per SIMD of a CU) spread evenly enough for 2040 blocks to stay at two per SIMD
 // (tools/exp_rans.py).  SCPR_RANS_SCALAR_MAX overrides it (0: always the vector form; tests and A/B timing).
 constexpr int kRansScalarMax = 2048;
-static int rans_scalar_max() {
-  const char* e = getenv("SCPR_RANS_SCALAR_MAX");
-  return e ? atoi(e) : kRansScalarMax;
-}
 static u64 chunk_total_limit() {  // SCPR_DEBUG_CHUNK_LIMIT: tests reach the re-cut of a chunk with small frames (read per chunk: a test may set it)
   const char* e = getenv("SCPR_DEBUG_CHUNK_LIMIT");
   return e ? strtoull(e, nullptr, 0) : kChunkTotalLimit;
@@ -870,6 +869,12 @@ scpr_codec* scpr_create(int device) {
   for (int s = 0; s < ST_COUNT + 1; s++)
     for (int k = 0; k < 2; k++) (void)hipEventCreate(&c->ev[s][k]);
   timing_reset(c);
+  {  // read once, here: the form of the coder and whether the fault injections of the tests are armed
+    const char* e = getenv("SCPR_RANS_SCALAR_MAX");
+    c->rans_scalar_max = e ? atoi(e) : kRansScalarMax;
+    e = getenv("SCPR_ENABLE_DEBUG_INJECT");
+    c->dbg_armed = e && atoi(e) != 0;
+  }
   return c;
 }
 
@@ -912,6 +917,7 @@ void scpr_destroy(scpr_codec* c) {
   pin_reset(c);  // (read-backs a failed call left queued are dropped, not delivered: their destinations are gone)
   (void)hipStreamSynchronize(c->stream);
   (void)hipStreamSynchronize(c->stream2);
+  if (c->stream3) (void)hipStreamSynchronize(c->stream3);  // (before the ranges its copies read are unregistered)
   for (const auto& r : c->host_ranges)
     if (r.owned) (void)hipHostUnregister(r.base);  // (what scpr_host_pin registered and nobody took back)
   (void)hipGetLastError();
@@ -934,45 +940,6 @@ void scpr_destroy(scpr_codec* c) {
   (void)hipEventDestroy(c->ev_fork);
   (void)hipEventDestroy(c->ev_join);
   delete c;
-}
-
-int scpr_set_cu_mask(scpr_codec* c, const uint32_t* mask, int words) {
-  if (!c || words < 0 || (words > 0 && !mask)) return SCPR_E_PARAM;
-  if (hipSetDevice(c->device) != hipSuccess) return SCPR_E_DEVICE;
-  pin_reset(c);
-  HIPCHK(sync_out(c, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream2));
-  hipStream_t a = nullptr, b = nullptr;
-  if (words > 0) {
-    u32 any = 0;
-    for (int i = 0; i < words; i++) any |= mask[i];
-    if (!any) return SCPR_E_PARAM;
-    if (hipExtStreamCreateWithCUMask(&a, (uint32_t)words, mask) != hipSuccess) return SCPR_E_DEVICE;
-    if (hipExtStreamCreateWithCUMask(&b, (uint32_t)words, mask) != hipSuccess) {
-      (void)hipStreamDestroy(a);
-      return SCPR_E_DEVICE;
-    }
-  } else {
-    if (hipStreamCreateWithFlags(&a, hipStreamNonBlocking) != hipSuccess) return SCPR_E_DEVICE;
-    if (hipStreamCreateWithFlags(&b, hipStreamNonBlocking) != hipSuccess) {
-      (void)hipStreamDestroy(a);
-      return SCPR_E_DEVICE;
-    }
-  }
-  (void)hipStreamDestroy(c->stream);
-  (void)hipStreamDestroy(c->stream2);
-  c->stream = a;
-  c->stream2 = b;
-  {
-    int v = 0;
-    if (words > 0) {
-      for (int i = 0; i < words; i++) v += __builtin_popcount(mask[i]);
-    } else if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess) {
-      v = 0;
-    }
-    if (v > 0) c->ncu = v;
-  }
-  return SCPR_OK;
 }
 
 void scpr_crash_happened(scpr_codec* c) {
@@ -1156,14 +1123,29 @@ static int txn_begin(scpr_codec* c, EncTxn& t, const int* ftypes, int nframes, s
   HIPCHK(c->snap_mvs.reserve(nblk0 * 4));
   HIPCHK(hipMemcpyAsync(c->snap_mvs.p, c->mvs.p, nblk0 * 4, hipMemcpyDeviceToDevice, c->stream));
   // (at most 5 coder entries per pixel + 16 per block: Appendix A of SURVEY.md)
-  const u64 worst = packet_bound(4, 5ull * g.NP + 16ull * nblk0 + 16);
-  if (nframes > 1 && (u64)out_capacity < worst * (u64)nframes) return snap_take(c, t.hs0);
+  const u64 most_syms = 5ull * g.NP + 16ull * nblk0 + 16, worst = packet_bound(4, most_syms);
+  // a call that is certainly ONE chunk (frames, generations and symbol totals all within a chunk's limits) needs no snapshot
+  // here: encode_chunk bounds its packets exactly before anything is coded and keeps the state then, if at all
+  const bool one_chunk = nframes <= std::min(c->slots, kMaxChunkGens) && most_syms * (u64)nframes < chunk_total_limit();
+  if (nframes > 1 && !one_chunk && (u64)out_capacity < worst * (u64)nframes) return snap_take(c, t.hs0);
   return SCPR_OK;
 }
 static int64_t txn_refuse(scpr_codec* c, const EncTxn& t, int* ftypes, int code) {  // the codec as the call found it
   for (size_t i = 0; i < t.ftypes0.size(); i++) ftypes[i] = t.ftypes0[i];
   const int r2 = snap_restore(c, t.hs0);
   return (int64_t)(r2 != SCPR_OK ? r2 : code);
+}
+// Any OTHER failure inside a compress call (a HIP error, the dense-table arena, the sortedness proof, a stalled pipeline) finds the
+// codec half-way: frame count, flat-frame memory, ftypes, mvs[] and the fixed models already moved, the colour models and the
+// previous frame perhaps not.  If the call kept a snapshot it is taken back whole like a refused one; otherwise the codec is
+// marked as the reference marks itself after an exception in Compress (`crashed`, screencap.cpp:1634-1644): every later frame is
+// refused (0 bytes) until the caller calls Init again.  Never a codec that goes on coding P-frames against models that no
+// decoder will have.
+static int64_t enc_failed(scpr_codec* c, const EncTxn& t, int* ftypes, int64_t r) {
+  pin_reset(c);  // (read-backs the failed call left queued point into its stack)
+  if (c->snap_taken && txn_refuse(c, t, ftypes, (int)r) == r) return r;
+  c->crashed = true;
+  return r;
 }
 // frames resident on the device -> packets at d_out (device memory, or host memory mapped into the device's address space).
 // Returns the bytes written, or < 0; SCPR_E_CAPACITY leaves the taking back to the caller (txn_refuse).
@@ -1320,37 +1302,65 @@ static int64_t compress_core(scpr_codec* c, const void* d_frames, int nframes, i
     HIPCHK(c->outsizes.reserve((size_t)n * 4));
     if (nb) HIPCHK(h2d(c, c->rblocks.p, blocks.data(), (size_t)nb * sizeof(RansBlock), st));
     HIPCHK(h2d(c, c->packets.p, pk.data(), (size_t)n * sizeof(Packet), st));
-    if (nb) {
-      stage_begin(c, ST_RANS);
-      if (nb <= rans_scalar_max()) {
-        HIPCHK(c->rrec.reserve((size_t)nb * RANS_S_RING * RANS_S_TRIP * 16));  // a ring of records per block
-        hipLaunchKernelGGL(k_rans_s, dim3((nb + 3) / 4), dim3(256), 0, st, c->entries.as<u32>(), c->rblocks.as<RansBlock>(), c->rcp.as<RansRcp>(), c->rrec.as<uint4>(), nb,
-                           c->rscratch.as<u8>(), c->rsize.as<u32>(), c->err.as<u32>());
-      } else {
-        hipLaunchKernelGGL(k_rans, dim3((nb + 63) / 64), dim3(256), 0, st, c->entries.as<u32>(), c->rblocks.as<RansBlock>(), nb, c->rcp.as<RansRcp>(), c->rscratch.as<u8>(),
-                           c->rsize.as<u32>(), c->err.as<u32>());
-      }
-      stage_end(c, ST_RANS);
-    }
-    stage_begin(c, ST_GATHER);
-    hipLaunchKernelGGL(k_offsets, dim3(1), dim3(256), 0, st, c->packets.as<Packet>(), n, c->rsize.as<u32>(), c->outsizes.as<u32>(), c->pktoff.as<u64>(), c->blkdst.as<u64>(),
-                       c->total64.as<u64>());
-    hipLaunchKernelGGL(k_gather, dim3(nb + n), dim3(256), 0, st, c->packets.as<Packet>(), n, nb, c->rscratch.as<u8>(), c->rsize.as<u32>(), c->pktoff.as<u64>(),
-                       c->blkdst.as<u64>(), (u8*)d_out + written, (u64)(out_capacity - (size_t)written), c->err.as<u32>());
-    stage_end(c, ST_GATHER);
     u64 chunk_total = 0;
     u32 err = 0, atop = 0;
-    HIPCHK(d2h(c, &atop, c->arena_top.p, 4, st));
-    HIPCHK(d2h(c, sizes + f0, c->outsizes.p, (size_t)n * 4, st));
-    HIPCHK(d2h(c, &chunk_total, c->total64.p, 8, st));
-    HIPCHK(d2h(c, &err, c->err.p, 4, st));
-    if (c->dbg_inject == 1) {  // (tests: a failure between a read-back and its hand-over - the pool then holds pointers into this frame)
-      c->dbg_inject = 0;
-      return SCPR_E_DEVICE;
+    // the coder, the packets' assembly and the read-backs; scalar: k_rans_s (its hand-over is checked by the kernel itself: bit 64)
+    auto code_chunk = [&](bool scalar) -> int {
+      if (nb) {
+        stage_begin(c, ST_RANS);
+        if (scalar) {
+          HIPCHK(c->rrec.reserve((size_t)nb * RANS_S_RING * RANS_S_TRIP * sizeof(rans_rec_t)));  // a ring of records per block
+          size_t lds = 0;
+#ifdef SCPR_EXPERIMENT  // (tools/exp_rans.py: LDS nobody uses, so that a CU takes one workgroup only)
+          if (const char* e = getenv("SCPR_RANS_LDS")) lds = (size_t)atoi(e);
+          if (lds > 65536) HIPCHK(hipFuncSetAttribute((const void*)k_rans_s<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+#endif
+          if (c->dbg_inject == 3) {  // (tests: one trip's records are not laid - a stale line, as the scalar unit would see it)
+            c->dbg_inject = 0;
+            hipLaunchKernelGGL(k_rans_s<true>, dim3((nb + 3) / 4), dim3(256), lds, st, c->entries.as<u32>(), c->rblocks.as<RansBlock>(), c->rcp.as<RansRcp>(), c->rrec.as<rans_rec_t>(), nb,
+                               c->rscratch.as<u8>(), c->rsize.as<u32>(), c->err.as<u32>(), 9);
+          } else {
+            hipLaunchKernelGGL(k_rans_s<false>, dim3((nb + 3) / 4), dim3(256), lds, st, c->entries.as<u32>(), c->rblocks.as<RansBlock>(), c->rcp.as<RansRcp>(), c->rrec.as<rans_rec_t>(), nb,
+                               c->rscratch.as<u8>(), c->rsize.as<u32>(), c->err.as<u32>(), -1);
+          }
+        } else {
+          hipLaunchKernelGGL(k_rans, dim3((nb + 63) / 64), dim3(256), 0, st, c->entries.as<u32>(), c->rblocks.as<RansBlock>(), nb, c->rcp.as<RansRcp>(), c->rscratch.as<u8>(),
+                             c->rsize.as<u32>(), c->err.as<u32>());
+        }
+        stage_end(c, ST_RANS);
+      }
+      stage_begin(c, ST_GATHER);
+      hipLaunchKernelGGL(k_offsets, dim3(1), dim3(256), 0, st, c->packets.as<Packet>(), n, c->rsize.as<u32>(), c->outsizes.as<u32>(), c->pktoff.as<u64>(), c->blkdst.as<u64>(),
+                         c->total64.as<u64>());
+      hipLaunchKernelGGL(k_gather, dim3(nb + n), dim3(256), 0, st, c->packets.as<Packet>(), n, nb, c->rscratch.as<u8>(), c->rsize.as<u32>(), c->pktoff.as<u64>(),
+                         c->blkdst.as<u64>(), (u8*)d_out + written, (u64)(out_capacity - (size_t)written), c->err.as<u32>());
+      stage_end(c, ST_GATHER);
+      HIPCHK(d2h(c, &atop, c->arena_top.p, 4, st));
+      HIPCHK(d2h(c, sizes + f0, c->outsizes.p, (size_t)n * 4, st));
+      HIPCHK(d2h(c, &chunk_total, c->total64.p, 8, st));
+      HIPCHK(d2h(c, &err, c->err.p, 4, st));
+      if (c->dbg_inject == 1) {  // (tests: a failure between a read-back and its hand-over - the pool then holds pointers into this frame)
+        c->dbg_inject = 0;
+        return SCPR_E_DEVICE;
+      }
+      HIPCHK(sync_out(c, st));
+      HIPCHK(hipGetLastError());  // a kernel that could not be launched (the launches themselves are not checked one by one)
+      timing_collect(c);
+      return SCPR_OK;
+    };
+    const bool scalar_form = nb > 0 && nb <= c->rans_scalar_max;
+    if ((rc = code_chunk(scalar_form)) != SCPR_OK) return rc;
+    if (err & 64) {
+      // A step of the scalar form did not come out as its entry says (scpr_rans_s.hpp): the blocks are independent of everything
+      // but the entries, so the stage is simply run again in the vector form (whatever the first run wrote is overwritten:
+      // scratch, sizes, packets, the capacity verdict), and the codec stays with the vector form.
+      fprintf(stderr, "[scpr] k_rans_s: a record did not reach the scalar unit as it was laid; the call's blocks are coded again with k_rans, and this codec keeps to it\n");
+      c->rans_scalar_max = 0;
+      c->rans_recoded++;
+      const u32 keep = err & ~(64u | 2u);
+      HIPCHK(h2d(c, c->err.p, &keep, 4, st));
+      if ((rc = code_chunk(false)) != SCPR_OK) return rc;
     }
-    HIPCHK(sync_out(c, st));
-    HIPCHK(hipGetLastError());  // a kernel that could not be launched (the launches themselves are not checked one by one)
-    timing_collect(c);
     if (err & 32) {
       fprintf(stderr, "[scpr] the colour symbols came back from the radix sort out of order (rocPRIM; DESIGN.md 9): nothing was coded with them\n");
       return SCPR_E_DEVICE;
@@ -1392,7 +1402,8 @@ int64_t scpr_compress_batch(scpr_codec* c, const void* d_frames, int nframes, in
   EncTxn txn;
   if ((rc = txn_begin(c, txn, ftypes, nframes, out_capacity)) != SCPR_OK) return rc;
   const int64_t r = compress_core(c, d_frames, nframes, ftypes, d_out, out_capacity, sizes, txn.hs0);
-  return r == SCPR_E_CAPACITY ? txn_refuse(c, txn, ftypes, SCPR_E_CAPACITY) : r;
+  if (r == SCPR_E_CAPACITY) return txn_refuse(c, txn, ftypes, SCPR_E_CAPACITY);
+  return r < 0 ? enc_failed(c, txn, ftypes, r) : r;
 }
 
 // packets resident on the device -> frames at d_frames_out: device memory, or (out_is_host) the host's buffer mapped into the
@@ -1787,17 +1798,27 @@ int64_t scpr_compress_batch_host(scpr_codec* c, const void* h_frames, int nframe
     if (e == hipSuccess) e = hipEventRecord(c->ev_in[k & 1], c->stream3);
     return e;
   };
-  HIPCHK(upload(0));
+  // one way out for every failure from here on: the copy stream may still be reading the caller's frames, and sub-batches that
+  // were coded have moved the codec (enc_failed)
+  auto fail = [&](int64_t r) -> int64_t {
+    (void)hipStreamSynchronize(c->stream3);
+    return enc_failed(c, txn, ftypes, r);
+  };
+#define HB_CHK(x)                                          \
+  do {                                                     \
+    if ((x) != hipSuccess) return fail(SCPR_E_DEVICE);     \
+  } while (0)
+  HB_CHK(upload(0));
   int64_t written = 0;
   const size_t cap = out_mapped ? out_capacity : dev_cap;
   for (int k = 0; k < nsub; k++) {
     const int a = k * sub, n = std::min(sub, nframes - a);
-    if (k + 1 < nsub) HIPCHK(upload(k + 1));  // (its half of the staging was read by sub-batch k - 1, whose call has returned)
-    HIPCHK(hipStreamWaitEvent(c->stream, c->ev_in[k & 1], 0));
+    if (k + 1 < nsub) HB_CHK(upload(k + 1));  // (its half of the staging was read by sub-batch k - 1, whose call has returned)
+    HB_CHK(hipStreamWaitEvent(c->stream, c->ev_in[k & 1], 0));
     const int64_t r = compress_core(c, c->hb_frames.as<u8>() + (size_t)(k & 1) * sub * frame_bytes, n, ftypes + a, (u8*)out_dev + written, cap - (size_t)written, sizes + a, txn.hs0);
     if (r < 0) {
+      if (r != SCPR_E_CAPACITY) return fail(r);
       (void)hipStreamSynchronize(c->stream3);
-      if (r != SCPR_E_CAPACITY) return r;
       const int64_t r2 = txn_refuse(c, txn, ftypes, SCPR_E_CAPACITY);
       if (r2 != SCPR_E_CAPACITY || out_mapped || attempt || dev_cap >= out_capacity) return r2;
       written = -1;  // the device buffer was the limit, not the host's: once more with room for the worst case
@@ -1809,7 +1830,8 @@ int64_t scpr_compress_batch_host(scpr_codec* c, const void* h_frames, int nframe
     dev_cap = std::min(out_capacity, worst * (size_t)nframes);
     continue;
   }
-  if (!out_mapped && written > 0) HIPCHK(hipMemcpy(h_out, out_dev, (size_t)written, hipMemcpyDeviceToHost));
+  if (!out_mapped && written > 0) HB_CHK(hipMemcpy(h_out, out_dev, (size_t)written, hipMemcpyDeviceToHost));
+#undef HB_CHK
   return written;
   }
 }
@@ -1946,9 +1968,12 @@ int scpr_debug_colour_chain(int device, const uint8_t* syms, int n, int f0, uint
 // result, as rocPRIM's defect gives: the call must end with SCPR_E_DEVICE, not follow the chains).
 int scpr_debug_inject(scpr_codec* c, int what) {
   if (!c) return SCPR_E_PARAM;
+  if (!c->dbg_armed) return SCPR_E_PARAM;  // (a codec created without SCPR_ENABLE_DEBUG_INJECT=1 cannot be made to fail)
   c->dbg_inject = what;
   return SCPR_OK;
 }
+
+int scpr_debug_rans_recoded(scpr_codec* c) { return c ? c->rans_recoded : SCPR_E_PARAM; }
 
 int scpr_debug_arena(scpr_codec* c, uint64_t* enc_bytes, uint64_t* dec_bytes) {
   if (!c) return SCPR_E_PARAM;

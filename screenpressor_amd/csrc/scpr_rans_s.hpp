@@ -9,18 +9,24 @@
 // bias << 5 | shift }, store them (they stay in the L2 of the wave's own XCD), and two trips later the scalar unit reads them
 // back four at a time (s_load_dwordx16), eight entries ahead of the step that uses them.  The state before every step is
 // dropped into a lane of a vector register (v_writelane), and after the 64 steps the lanes work out what each step emitted
-// (0, 1 or 2 bytes, or a raw byte), scan the counts and store the bytes: the serial chain is 12 scalar instructions per entry.
+// (0, 1 or 2 bytes, or a raw byte), scan the counts and store the bytes: the serial chain is 9 scalar instructions per entry
+// (12 for the sets of eight entries that hold a freq below 16, the only ones whose step can emit two bytes).
 //
 // Two properties of the memory system shape the hand-over (tools/rans_sload2_bench.hip, rans_sload3_bench.hip):
 //  * a store to a line the L2 does not hold does not bring it in: records laid into fresh memory come back from HBM (116 cycles
-//    per entry instead of 57).  The records therefore live in a small RING per block (16 trips, 16 KB) whose lines stay in the
-//    L2 after the first lap;
-//  * the scalar data cache is not coherent with those stores: a lap later it may still hold the old records (a 4 KB or 16 KB
-//    ring without an invalidate ends in a wrong state, the tool shows it).  Every trip starts with s_dcache_inv (2 cycles per
-//    entry; each line is read once per lap anyway, there is nothing to lose).
-// The scalar data cache is filled at ~0.3 TB/s for the whole card (tools/rans_sload_bench.hip: 1024 waves streaming 32 bytes per
-// entry fall to 215-363 cycles per entry): this form is for calls with FEW blocks - the per-frame calls, I+P batches (a P-frame
-// is one short block) - and the host picks it by block count (scpr_amd.hip); a batch of key frames (1800 blocks) stays with k_rans.
+//    per entry instead of 57).  The records therefore live in a small RING per block whose lines stay in the L2 after the first
+//    lap: 4 trips, 4 KB (trip t reads slot t while it lays slot t + 2).  Round 4 had 16 trips: at 1020 blocks the rings (16.7 MB)
+//    no longer stayed in the L2s and the stage took 4.8 ms instead of 3.7; with 4 trips it is 3.65 (tools/r5/rans_matrix.sh);
+//  * the scalar data cache is not coherent with those stores: a lap later it may still hold the old records (a ring without an
+//    invalidate ends in a wrong state, the tool shows it).  Every trip starts with s_dcache_inv (2 cycles per entry; each line is
+//    read once per lap anyway, there is nothing to lose).  The loads' own GLC bit does the same and costs 60 % more time (5.98
+//    against 3.65 ms: every load then waits for the L2).
+// Neither property is specified, so the kernel does not rely on them for CORRECTNESS: every step is taken a second time by the
+// lanes, from the entry itself (see the end of the trip), and a call in which one differs is coded again by k_rans.
+// The scalar data cache is filled at ~0.3 TB/s for the whole card from HBM (tools/rans_sload_bench.hip); out of the L2-resident
+// rings 1800 waves draw ~0.6 TB/s without slowing down.  What bounds the stage is the scalar unit's issue rate: one instruction
+// per SIMD every four cycles, so a wave alone on its SIMD takes ~59 cycles per entry, two take ~97 each, three ~135 each
+// (3.2 / 5.3 / 7.4 ms for a full block); the host picks this form up to kRansScalarMax blocks per call (scpr_amd.hip).
 #pragma once
 #include "scpr_kernels.hpp"
 #include "scpr_wave.hpp"
@@ -28,7 +34,10 @@
 namespace scpr {
 
 constexpr int RANS_S_TRIP = 64;  // entries per trip: one lane of the hand-over register each
-constexpr int RANS_S_RING = 16;  // trips of records per block (a power of two)
+#ifndef SCPR_RANS_RING
+#define SCPR_RANS_RING 4
+#endif
+constexpr int RANS_S_RING = SCPR_RANS_RING;  // trips of records per block (a power of two, >= 4: trip t lays the records of trip t + 2)
 
 // the entry's record for the scalar step; a raw byte (freq 0) and the padding of the last trip (0xFFFFFFFF) leave the state as it is.
 // (The reciprocal is fetched a trip before the record is laid: rans_rcp_of; a lone wave pays every load it waits for.)
@@ -36,6 +45,40 @@ __device__ __forceinline__ uint2 rans_rcp_of(u32 v, const RansRcp* __restrict__ 
   const u32 fr = v & 0xFFFFu;
   return ((const uint2*)rcp_g)[fr - 1u < (u32)kProbScale ? fr : 1u];
 }
+#ifdef SCPR_RANS_REC8
+// experiment (tools/exp_rans.py): an 8-byte record { reciprocal, freq << 19 | bias << 5 | shift } - half the bytes
+// through the L2 and the scalar data cache, three more scalar instructions per entry to take the second word apart
+typedef uint2 rans_rec_t;
+__device__ __forceinline__ uint2 rans_record_s(u32 v, const uint2 r) {
+  const u32 fr = v & 0xFFFFu, cf = v >> 16;
+  const bool live = fr - 1u < (u32)kProbScale;
+  uint2 o;
+  o.x = live ? r.x : 0u;
+  o.y = live ? (fr << 19) | ((cf + (r.y >> 16)) << 5) | (r.y & 0xFFFFu) : 0xFFF80000u;  // bias <= 8190 < 2^14; no state reaches 0xFFF80000
+  return o;
+}
+#define SCPR_RS_ENT(RC, W, K)                                                                                                     \
+  "s_and_b32 s24, s" #W ", 0xfff80000\n\ts_cmp_ge_u32 %[x], s24\n\ts_cselect_b32 s20, 8, 0\n\tv_writelane_b32 %[vo], %[x], " #K "\n\t"   \
+  "s_lshr_b32 s21, %[x], s20\n\ts_cmp_ge_u32 s21, s24\n\ts_cselect_b32 s20, 8, 0\n\ts_lshr_b32 s25, s" #W ", 19\n\t"               \
+  "s_lshr_b32 s21, s21, s20\n\ts_mul_hi_u32 s22, s21, s" #RC "\n\ts_sub_u32 s25, 0x1000, s25\n\ts_lshr_b32 s22, s22, s" #W "\n\t"    \
+  "s_bfe_u32 s23, s" #W ", 0xe0005\n\ts_mul_i32 s22, s22, s25\n\ts_add_u32 s21, s21, s23\n\ts_add_u32 %[x], s22, s21\n\t"
+#define SCPR_RS_ENTF SCPR_RS_ENT
+#define SCPR_RS_SET_A(E, K0, K1, K2, K3, K4, K5, K6, K7) E(36, 37, K0) E(38, 39, K1) E(40, 41, K2) E(42, 43, K3) E(44, 45, K4) E(46, 47, K5) E(48, 49, K6) E(50, 51, K7)
+#define SCPR_RS_SET_B(E, K0, K1, K2, K3, K4, K5, K6, K7) E(52, 53, K0) E(54, 55, K1) E(56, 57, K2) E(58, 59, K3) E(60, 61, K4) E(62, 63, K5) E(64, 65, K6) E(66, 67, K7)
+#define SCPR_RS_LOAD_A(I) "s_waitcnt lgkmcnt(0)\n\ts_load_dwordx16 s[36:51], %[p], " SCPR_RS_OFF8(I) SCPR_RS_GLC "\n\t"
+#define SCPR_RS_LOAD_B(I) "s_waitcnt lgkmcnt(0)\n\ts_load_dwordx16 s[52:67], %[p], " SCPR_RS_OFF8(I) SCPR_RS_GLC "\n\t"
+#define SCPR_RS_OFF8(I) SCPR_RS_OFF8_##I
+#define SCPR_RS_OFF8_0 "0x0"
+#define SCPR_RS_OFF8_1 "0x40"
+#define SCPR_RS_OFF8_2 "0x80"
+#define SCPR_RS_OFF8_3 "0xc0"
+#define SCPR_RS_OFF8_4 "0x100"
+#define SCPR_RS_OFF8_5 "0x140"
+#define SCPR_RS_OFF8_6 "0x180"
+#define SCPR_RS_OFF8_7 "0x1c0"
+#define SCPR_RS_CLOBBERS "s20", "s21", "s22", "s23", "s24", "s25", "scc", "memory", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67"
+#else
+typedef uint4 rans_rec_t;
 __device__ __forceinline__ uint4 rans_record_s(u32 v, const uint2 r) {
   const u32 fr = v & 0xFFFFu, cf = v >> 16;
   const bool live = fr - 1u < (u32)kProbScale;
@@ -47,21 +90,66 @@ __device__ __forceinline__ uint4 rans_record_s(u32 v, const uint2 r) {
   return o;
 }
 
-// one entry: state in %[x], its record in four scalar registers, the state before the step to lane K of %[vo]
+// one entry: state in %[x], its record in four scalar registers, the state before the step to lane K of %[vo].
+// SCPR_RS_ENT is the whole step (12 scalar instructions); SCPR_RS_ENTF leaves the second renormalisation test out (9): a state
+// below 2^31 passes freq << 27 only when freq < 16, and the lanes know which sets of eight entries hold such a freq (1.1 % of a
+// key frame's entries, 7 % of the sets) - the trip branches per set.
 #define SCPR_RS_ENT(XM, RC, ML, BS, K)                                                                                          \
   "s_cmp_ge_u32 %[x], s" #XM "\n\ts_cselect_b32 s20, 8, 0\n\tv_writelane_b32 %[vo], %[x], " #K "\n\ts_lshr_b32 s21, %[x], s20\n\t"     \
   "s_cmp_ge_u32 s21, s" #XM "\n\ts_cselect_b32 s20, 8, 0\n\ts_lshr_b32 s23, s" #BS ", 5\n\ts_lshr_b32 s21, s21, s20\n\t"           \
   "s_mul_hi_u32 s22, s21, s" #RC "\n\ts_lshr_b32 s22, s22, s" #BS "\n\ts_mul_i32 s22, s22, s" #ML "\n\ts_add_u32 s21, s21, s23\n\t"  \
   "s_add_u32 %[x], s22, s21\n\t"
-#define SCPR_RS_SET_A(K0, K1, K2, K3, K4, K5, K6, K7) SCPR_RS_ENT(36, 37, 38, 39, K0) SCPR_RS_ENT(40, 41, 42, 43, K1) SCPR_RS_ENT(44, 45, 46, 47, K2) SCPR_RS_ENT(48, 49, 50, 51, K3) SCPR_RS_ENT(52, 53, 54, 55, K4) SCPR_RS_ENT(56, 57, 58, 59, K5) SCPR_RS_ENT(60, 61, 62, 63, K6) SCPR_RS_ENT(64, 65, 66, 67, K7)
-#define SCPR_RS_SET_B(K0, K1, K2, K3, K4, K5, K6, K7) SCPR_RS_ENT(68, 69, 70, 71, K0) SCPR_RS_ENT(72, 73, 74, 75, K1) SCPR_RS_ENT(76, 77, 78, 79, K2) SCPR_RS_ENT(80, 81, 82, 83, K3) SCPR_RS_ENT(84, 85, 86, 87, K4) SCPR_RS_ENT(88, 89, 90, 91, K5) SCPR_RS_ENT(92, 93, 94, 95, K6) SCPR_RS_ENT(96, 97, 98, 99, K7)
-#define SCPR_RS_LOAD_A(OFF0, OFF1) "s_waitcnt lgkmcnt(0)\n\ts_load_dwordx16 s[36:51], %[p], " #OFF0 "\n\ts_load_dwordx16 s[52:67], %[p], " #OFF1 "\n\t"
-#define SCPR_RS_LOAD_B(OFF0, OFF1) "s_waitcnt lgkmcnt(0)\n\ts_load_dwordx16 s[68:83], %[p], " #OFF0 "\n\ts_load_dwordx16 s[84:99], %[p], " #OFF1 "\n\t"
+#define SCPR_RS_ENTF(XM, RC, ML, BS, K)                                                                                         \
+  "s_cmp_ge_u32 %[x], s" #XM "\n\ts_cselect_b32 s20, 8, 0\n\tv_writelane_b32 %[vo], %[x], " #K "\n\ts_lshr_b32 s23, s" #BS ", 5\n\t"   \
+  "s_lshr_b32 s21, %[x], s20\n\ts_mul_hi_u32 s22, s21, s" #RC "\n\ts_lshr_b32 s22, s22, s" #BS "\n\ts_mul_i32 s22, s22, s" #ML "\n\t" \
+  "s_add_u32 s21, s21, s23\n\ts_add_u32 %[x], s22, s21\n\t"
+#define SCPR_RS_SET_A(E, K0, K1, K2, K3, K4, K5, K6, K7) E(36, 37, 38, 39, K0) E(40, 41, 42, 43, K1) E(44, 45, 46, 47, K2) E(48, 49, 50, 51, K3) E(52, 53, 54, 55, K4) E(56, 57, 58, 59, K5) E(60, 61, 62, 63, K6) E(64, 65, 66, 67, K7)
+#define SCPR_RS_SET_B(E, K0, K1, K2, K3, K4, K5, K6, K7) E(68, 69, 70, 71, K0) E(72, 73, 74, 75, K1) E(76, 77, 78, 79, K2) E(80, 81, 82, 83, K3) E(84, 85, 86, 87, K4) E(88, 89, 90, 91, K5) E(92, 93, 94, 95, K6) E(96, 97, 98, 99, K7)
+#define SCPR_RS_LOAD_A(I) "s_waitcnt lgkmcnt(0)\n\ts_load_dwordx16 s[36:51], %[p], " SCPR_RS_OFF16A(I) SCPR_RS_GLC "\n\ts_load_dwordx16 s[52:67], %[p], " SCPR_RS_OFF16B(I) SCPR_RS_GLC "\n\t"
+#define SCPR_RS_LOAD_B(I) "s_waitcnt lgkmcnt(0)\n\ts_load_dwordx16 s[68:83], %[p], " SCPR_RS_OFF16A(I) SCPR_RS_GLC "\n\ts_load_dwordx16 s[84:99], %[p], " SCPR_RS_OFF16B(I) SCPR_RS_GLC "\n\t"
+#define SCPR_RS_OFF16A(I) SCPR_RS_OFF16A_##I
+#define SCPR_RS_OFF16B(I) SCPR_RS_OFF16B_##I
+#define SCPR_RS_OFF16A_0 "0x0"
+#define SCPR_RS_OFF16B_0 "0x40"
+#define SCPR_RS_OFF16A_1 "0x80"
+#define SCPR_RS_OFF16B_1 "0xc0"
+#define SCPR_RS_OFF16A_2 "0x100"
+#define SCPR_RS_OFF16B_2 "0x140"
+#define SCPR_RS_OFF16A_3 "0x180"
+#define SCPR_RS_OFF16B_3 "0x1c0"
+#define SCPR_RS_OFF16A_4 "0x200"
+#define SCPR_RS_OFF16B_4 "0x240"
+#define SCPR_RS_OFF16A_5 "0x280"
+#define SCPR_RS_OFF16B_5 "0x2c0"
+#define SCPR_RS_OFF16A_6 "0x300"
+#define SCPR_RS_OFF16B_6 "0x340"
+#define SCPR_RS_OFF16A_7 "0x380"
+#define SCPR_RS_OFF16B_7 "0x3c0"
 #define SCPR_RS_CLOBBERS "s20", "s21", "s22", "s23", "scc", "memory", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99"
+#endif
+// how the scalar loads get past a lap-old line of the scalar data cache: s_dcache_inv in front of the trip's loads, or
+// (SCPR_RANS_GLC, experiment) the loads' own GLC bit
+#ifdef SCPR_RANS_GLC
+#define SCPR_RS_GLC " glc"
+#define SCPR_RS_INV ""
+#else
+#define SCPR_RS_GLC ""
+#define SCPR_RS_INV "s_dcache_inv\n\t"
+#endif
+
+// a set of eight entries: the short step unless the trip's mask has a bit of the set (the long form sits behind the trip)
+#ifdef SCPR_RANS_NOFAST  // (A/B timing: every set takes the whole step)
+#define SCPR_RS_TRY(M, BITS, S)
+#else
+#define SCPR_RS_TRY(M, BITS, S) "s_and_b32 s20, %[" #M "], " #BITS "\n\ts_cbranch_scc1 .Lrs_slow" #S "_%=\n\t"
+#endif
+#define SCPR_RS_JOIN(S) ".Lrs_join" #S "_%=:\n\t"
+#define SCPR_RS_SLOW(S, SET) ".Lrs_slow" #S "_%=:\n\t" SET "s_branch .Lrs_join" #S "_%=\n\t"
 
 // one wave per block, four per workgroup.  rec: the records' rings (RANS_S_RING * RANS_S_TRIP records per block); everything else as k_rans.
-__global__ __launch_bounds__(256) void k_rans_s(const u32* __restrict__ entries, const RansBlock* __restrict__ blocks, const RansRcp* __restrict__ rcp_g, uint4* __restrict__ rec,
-                                               int nblocks, u8* __restrict__ scratch, u32* __restrict__ blksize, const u32* __restrict__ err) {
+template <bool POISON>  // POISON: the tests' instance (scpr_debug_inject 3), which leaves the records of trip `poison_trip` unlaid
+__global__ __launch_bounds__(256) void k_rans_s(const u32* __restrict__ entries, const RansBlock* __restrict__ blocks, const RansRcp* __restrict__ rcp_g, rans_rec_t* __restrict__ rec,
+                                               int nblocks, u8* __restrict__ scratch, u32* __restrict__ blksize, u32* __restrict__ err, int poison_trip) {
   // four blocks per workgroup: its waves go to the four SIMDs of a CU, and two such waves on ONE SIMD would take turns at the
   // scalar unit (tools/exp_rans.py: 3.7 ms with one wave per SIMD, 6.3 with two, 9.0 with three - whatever the number of blocks)
   const int b = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6))), lane = threadIdx.x & 63;
@@ -73,7 +161,7 @@ __global__ __launch_bounds__(256) void k_rans_s(const u32* __restrict__ entries,
   const RansBlock blk = blocks[b];
   const int len = (int)blk.len, trips = (len + RANS_S_TRIP - 1) / RANS_S_TRIP;
   const u32* e = entries + blk.begin;
-  uint4* const r0 = rec + (size_t)b * (RANS_S_RING * RANS_S_TRIP);
+  rans_rec_t* const r0 = rec + (size_t)b * (RANS_S_RING * RANS_S_TRIP);
   auto slot = [&](int t) { return r0 + (size_t)(t & (RANS_S_RING - 1)) * RANS_S_TRIP; };
   u8* const base = scratch + (size_t)b * RANS_SCRATCH;
   // entry of trip t in this lane, in coding order (last entry first); past the block's first entry: padding
@@ -84,33 +172,54 @@ __global__ __launch_bounds__(256) void k_rans_s(const u32* __restrict__ entries,
   // the records of trips 0 and 1 before anything is coded; from then on trip t lays the records of trip t + 2 (their
   // reciprocals were asked for during trip t - 1, their entries during trip t - 2) while it runs
   u32 ev0 = entry_of(0), ev1 = entry_of(1), ev2 = entry_of(2), ev3 = entry_of(3);
-  slot(0)[lane] = rans_record_s(ev0, rans_rcp_of(ev0, rcp_g));
-  slot(1)[lane] = rans_record_s(ev1, rans_rcp_of(ev1, rcp_g));
+  uint2 rc0 = rans_rcp_of(ev0, rcp_g), rc1 = rans_rcp_of(ev1, rcp_g);
+  slot(0)[lane] = rans_record_s(ev0, rc0);
+  slot(1)[lane] = rans_record_s(ev1, rc1);
   uint2 rc2 = rans_rcp_of(ev2, rcp_g);
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(ev2), "+v"(ev3), "+v"(rc2.x), "+v"(rc2.y) : : "memory");  // (nothing is on its way when the loop is entered: see the wait inside it)
   u32 x = kRansL, off = RANS_SCRATCH;
+  u64 wrong = 0;
   for (int t = 0; t < trips; t++) {
-    slot(t + 2)[lane] = rans_record_s(ev2, rc2);  // (read last by trip t - 14)
+    // (read last by trip t + 2 - RANS_S_RING.  poison_trip, tests only: the records of one trip are NOT laid - the scalar unit
+    // then reads what the ring held a lap before, which is what a stale line of the scalar data cache would hand it)
+    if (!POISON || t + 2 != poison_trip) slot(t + 2)[lane] = rans_record_s(ev2, rc2);
     uint2 rc3 = rans_rcp_of(ev3, rcp_g);
     u32 ev4 = entry_of(t + 4);
     u32 vout = 0;
-    const uint4* p = slot(t);
-  asm volatile("s_dcache_inv\n\t" SCPR_RS_LOAD_A(0x0, 0x40)
-               SCPR_RS_LOAD_B(0x80, 0xc0) SCPR_RS_SET_A(0, 1, 2, 3, 4, 5, 6, 7)
-               SCPR_RS_LOAD_A(0x100, 0x140) SCPR_RS_SET_B(8, 9, 10, 11, 12, 13, 14, 15)
-               SCPR_RS_LOAD_B(0x180, 0x1c0) SCPR_RS_SET_A(16, 17, 18, 19, 20, 21, 22, 23)
-               SCPR_RS_LOAD_A(0x200, 0x240) SCPR_RS_SET_B(24, 25, 26, 27, 28, 29, 30, 31)
-               SCPR_RS_LOAD_B(0x280, 0x2c0) SCPR_RS_SET_A(32, 33, 34, 35, 36, 37, 38, 39)
-               SCPR_RS_LOAD_A(0x300, 0x340) SCPR_RS_SET_B(40, 41, 42, 43, 44, 45, 46, 47)
-               SCPR_RS_LOAD_B(0x380, 0x3c0) SCPR_RS_SET_A(48, 49, 50, 51, 52, 53, 54, 55)
-               "s_waitcnt lgkmcnt(0)\n\t" SCPR_RS_SET_B(56, 57, 58, 59, 60, 61, 62, 63)
-               : [x] "+s"(x), [vo] "+v"(vout) : [p] "s"(p) : SCPR_RS_CLOBBERS);
+    const rans_rec_t* p = slot(t);
+    // which sets of eight hold an entry whose freq is below 16 (the only ones a second byte can come from)
+    const u32 fr0 = ev0 & 0xFFFFu;
+    const u64 two = __ballot(fr0 - 1u < 15u);
+    const u32 mlo = (u32)two, mhi = (u32)(two >> 32);
+#ifdef SCPR_RANS_NOFAST
+#define SCPR_RS_E SCPR_RS_ENT
+#else
+#define SCPR_RS_E SCPR_RS_ENTF
+#endif
+    asm volatile(SCPR_RS_INV SCPR_RS_LOAD_A(0)
+                 SCPR_RS_LOAD_B(1) SCPR_RS_TRY(mlo, 0xff, 0) SCPR_RS_SET_A(SCPR_RS_E, 0, 1, 2, 3, 4, 5, 6, 7) SCPR_RS_JOIN(0)
+                 SCPR_RS_LOAD_A(2) SCPR_RS_TRY(mlo, 0xff00, 1) SCPR_RS_SET_B(SCPR_RS_E, 8, 9, 10, 11, 12, 13, 14, 15) SCPR_RS_JOIN(1)
+                 SCPR_RS_LOAD_B(3) SCPR_RS_TRY(mlo, 0xff0000, 2) SCPR_RS_SET_A(SCPR_RS_E, 16, 17, 18, 19, 20, 21, 22, 23) SCPR_RS_JOIN(2)
+                 SCPR_RS_LOAD_A(4) SCPR_RS_TRY(mlo, 0xff000000, 3) SCPR_RS_SET_B(SCPR_RS_E, 24, 25, 26, 27, 28, 29, 30, 31) SCPR_RS_JOIN(3)
+                 SCPR_RS_LOAD_B(5) SCPR_RS_TRY(mhi, 0xff, 4) SCPR_RS_SET_A(SCPR_RS_E, 32, 33, 34, 35, 36, 37, 38, 39) SCPR_RS_JOIN(4)
+                 SCPR_RS_LOAD_A(6) SCPR_RS_TRY(mhi, 0xff00, 5) SCPR_RS_SET_B(SCPR_RS_E, 40, 41, 42, 43, 44, 45, 46, 47) SCPR_RS_JOIN(5)
+                 SCPR_RS_LOAD_B(7) SCPR_RS_TRY(mhi, 0xff0000, 6) SCPR_RS_SET_A(SCPR_RS_E, 48, 49, 50, 51, 52, 53, 54, 55) SCPR_RS_JOIN(6)
+                 "s_waitcnt lgkmcnt(0)\n\t" SCPR_RS_TRY(mhi, 0xff000000, 7) SCPR_RS_SET_B(SCPR_RS_E, 56, 57, 58, 59, 60, 61, 62, 63) SCPR_RS_JOIN(7)
+#ifndef SCPR_RANS_NOFAST
+                 "s_branch .Lrs_end_%=\n\t"
+                 SCPR_RS_SLOW(0, SCPR_RS_SET_A(SCPR_RS_ENT, 0, 1, 2, 3, 4, 5, 6, 7)) SCPR_RS_SLOW(1, SCPR_RS_SET_B(SCPR_RS_ENT, 8, 9, 10, 11, 12, 13, 14, 15))
+                 SCPR_RS_SLOW(2, SCPR_RS_SET_A(SCPR_RS_ENT, 16, 17, 18, 19, 20, 21, 22, 23)) SCPR_RS_SLOW(3, SCPR_RS_SET_B(SCPR_RS_ENT, 24, 25, 26, 27, 28, 29, 30, 31))
+                 SCPR_RS_SLOW(4, SCPR_RS_SET_A(SCPR_RS_ENT, 32, 33, 34, 35, 36, 37, 38, 39)) SCPR_RS_SLOW(5, SCPR_RS_SET_B(SCPR_RS_ENT, 40, 41, 42, 43, 44, 45, 46, 47))
+                 SCPR_RS_SLOW(6, SCPR_RS_SET_A(SCPR_RS_ENT, 48, 49, 50, 51, 52, 53, 54, 55)) SCPR_RS_SLOW(7, SCPR_RS_SET_B(SCPR_RS_ENT, 56, 57, 58, 59, 60, 61, 62, 63))
+                 ".Lrs_end_%=:\n\t"
+#endif
+                 : [x] "+s"(x), [vo] "+v"(vout) : [p] "s"(p), [mlo] "s"(mlo), [mhi] "s"(mhi) : SCPR_RS_CLOBBERS);
     // this trip's stores and loads were issued 64 steps ago: the records are in the L2 before a scalar load asks for them, and the
     // compiler's own wait for the loaded values lands HERE - not behind the byte stores below, whose way to memory it would pay
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(ev4), "+v"(rc3.x), "+v"(rc3.y) : : "memory");
     // what the 64 steps emitted: the renormalisation's bytes (the low bytes of the state before the step, first byte at the
     // higher address: the block is written from its end), or the raw byte itself
-    const u32 fr = ev0 & 0xFFFFu, xm = fr << 19;
+    const u32 fr = fr0, xm = fr << 19;
     const bool live = fr - 1u < (u32)kProbScale, raw = fr == 0u;
     const int n = live ? (int)(vout >= xm) + (int)((vout >> 8) >= xm) : (raw ? 1 : 0);
     const u32 b0 = raw ? (ev0 >> 16) & 255u : vout & 255u, b1 = (vout >> 8) & 255u;
@@ -119,8 +228,23 @@ __global__ __launch_bounds__(256) void k_rans_s(const u32* __restrict__ entries,
     if (n >= 1) base[o - 1] = (u8)b0;
     if (n == 2) base[o - 2] = (u8)b1;
     off -= rdl((u32)incl, 63);
-    ev0 = ev1, ev1 = ev2, ev2 = ev3, ev3 = ev4, rc2 = rc3;
+    // The hand-over is CHECKED, not trusted: every lane takes its entry's step again, from the entry itself and the state the
+    // scalar unit started that step from, and must arrive at the state the next step started from (lane 63: the state the
+    // trip ended with).  A record that did not reach the scalar unit as it was laid (scpr_rans_s.hpp's two measured, unspecified
+    // properties of the memory system) shows here unless it changes nothing; the host then codes the call's blocks again with
+    // k_rans (scpr_amd.hip).  ~25 vector instructions per trip, none on the scalar chain.
+#ifndef SCPR_RANS_NOCHECK  // (A/B timing only)
+    {
+      const u32 xr = live ? vout >> (8 * n) : vout;
+      const u32 q = __umulhi(xr, rc0.x) >> (rc0.y & 31u);
+      const u32 want = live ? xr + (ev0 >> 16) + (rc0.y >> 16) + q * ((u32)kProbScale - fr) : vout;
+      const u32 next = (u32)__builtin_amdgcn_update_dpp((int)x, (int)vout, 0x130, 0xf, 0xf, false);  // wave_shl:1 - lane i reads lane i + 1, lane 63 keeps x
+      wrong |= __ballot(want != next);
+    }
+#endif
+    ev0 = ev1, ev1 = ev2, ev2 = ev3, ev3 = ev4, rc0 = rc1, rc1 = rc2, rc2 = rc3;
   }
+  if (wrong && lane == 0) atomicOr(err, 64u);
   if (lane == 0) {  // RansEncFlush, rans_byte.h:90-102
     u8* q = base + off - 4;
     q[0] = (u8)x, q[1] = (u8)(x >> 8), q[2] = (u8)(x >> 16), q[3] = (u8)(x >> 24);

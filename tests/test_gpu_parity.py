@@ -948,29 +948,3 @@ print("RECUT_OK", int(sizes.sum()))
     env = dict(os.environ, SCPR_DEBUG_CHUNK_LIMIT="50000")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
     assert "RECUT_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
-
-
-def test_codec_confined_to_some_compute_units_codes_the_same_bytes():
-    """scpr_set_cu_mask (include/scpr_amd.h): the codec's streams are made again with a CU mask - between calls, with live
-    models - and nothing of what it writes changes; an empty mask is refused, words = 0 lifts the limit"""
-    import ctypes as C
-    import torch
-    w, h, n = 320, 240, 6
-    seq = DesktopSequence(w, h, seed=5)
-    frames = np.stack([seq.frame(t) for t in range(n)])
-    ora = O.OracleCodec(w, h, 32)
-    want = [ora.compress(frames[t], key=(t == 0))[0] for t in range(n)]
-    gpu, dec = _codec(w, h), _codec(w, h)
-    fr = torch.from_numpy(frames).cuda().reshape(n, -1)
-    gpu.SetCuMask(range(0, 64))
-    pk, sizes, ft = gpu.CompressBatch(fr[:3], [0, 1, 1])
-    gpu.SetCuMask([q for q in range(256) if q % 8 >= 5])   # (the live generation goes on under another mask)
-    pk2, sizes2, ft2 = gpu.CompressBatch(fr[3:], [1, 1, 1])
-    gpu.SetCuMask(None)
-    got = bytes(pk.cpu().numpy()) + bytes(pk2.cpu().numpy())
-    assert got == b"".join(want)
-    dec.SetCuMask(range(32, 96))
-    r, out = dec.DecompressBatch(torch.cat([pk, pk2]), np.concatenate([sizes, sizes2]), ft + ft2)
-    assert r == n and torch.equal(out.reshape(n, -1), fr)
-    zero = (C.c_uint32 * 2)(0, 0)
-    assert gpu._L.scpr_set_cu_mask(gpu._h, zero, 2) < 0

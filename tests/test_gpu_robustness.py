@@ -98,11 +98,14 @@ def test_multi_chunk_call_that_does_not_fit_is_taken_back_whole(monkeypatch):
     assert pk.cpu().numpy().tobytes() == b"".join(p for p, _ in ref)
 
 
-def test_keys_that_come_back_unsorted_end_the_call_with_an_error():
-    """rocPRIM 4.2's radix sort has returned unsorted output; the chunk-size rule keeps the encoder off that path,
-    and k_chain_starts proves the order on every call: two keys out of place (scpr_debug_inject) -> SCPR_E_DEVICE, no chain is
-    followed, the process lives, a fresh codec codes the oracle's bytes"""
+def test_keys_out_of_order_end_the_call_with_an_error_and_the_codec_refuses_until_init(monkeypatch):
+    """the colour chains rely on their symbols being grouped by context in stream order; k_chain_starts proves that order on every
+    call: two keys out of place (scpr_debug_inject 2) -> SCPR_E_DEVICE, no chain is followed, the process lives.  The failed call
+    had moved the codec half-way (frame count, fixed models, mvs[]): it must not go on coding against that state - like the
+    reference after an exception in Compress (`crashed`, screencap.cpp:1634-1644) it refuses every frame until Init, and after
+    Init the SAME codec codes the oracle's bytes"""
     import torch
+    monkeypatch.setenv("SCPR_ENABLE_DEBUG_INJECT", "1")
     w, h, n = 128, 96, 4
     frames = _noisy_sequence(w, h, n, seed=2)
     dev = torch.from_numpy(frames).cuda().reshape(n, -1)
@@ -110,17 +113,79 @@ def test_keys_that_come_back_unsorted_end_the_call_with_an_error():
     enc.debug_inject(2)
     with pytest.raises(RuntimeError, match="scpr error -1"):
         enc.CompressBatch(dev, [0] * n)
-    enc.close()
+    pk, sizes, fts = enc.CompressBatch(dev, [1] * n)  # P-frames on top of the failed call: refused, nothing written
+    assert int(np.sum(sizes)) == 0 and len(pk) == 0
+    got, ft = enc.CompressFrame(frames[0], 1)
+    assert got == b""
+    enc.Init(w, h, 32)
     ora = O.OracleCodec(w, h, 32)
-    ref = [ora.compress(f, key=True) for f in frames]
-    pk, sizes, fts = _codec(w, h).CompressBatch(dev, [0] * n)
+    ref = [ora.compress(f, key=(t == 0)) for t, f in enumerate(frames)]
+    pk, sizes, fts = enc.CompressBatch(dev, [1] * n)  # (the first frame after Init is a key frame whatever is asked)
     assert pk.cpu().numpy().tobytes() == b"".join(p for p, _ in ref)
 
 
-def test_a_call_that_failed_between_read_back_and_hand_over_leaves_nothing_queued():
+def test_a_failed_call_that_had_kept_its_snapshot_is_taken_back_whole(monkeypatch):
+    """a call that failed for another reason than room AFTER keeping the state it was about to change (a buffer below the exact
+    bound) is taken back like a refused one: same codec, same call with room -> the oracle's bytes, P-frames included"""
+    import torch
+    monkeypatch.setenv("SCPR_ENABLE_DEBUG_INJECT", "1")
+    w, h, n = 128, 96, 5
+    frames = _noisy_sequence(w, h, n, seed=3)
+    dev = torch.from_numpy(frames).cuda().reshape(n, -1)
+    ora = O.OracleCodec(w, h, 32)
+    ref = [ora.compress(f, key=(t == 0)) for t, f in enumerate(frames)]
+    enc = _codec(w, h)
+    pk0, s0, _ = enc.CompressBatch(dev[:2], [0, 1])
+    # room for the packets themselves but not for their bound (2 bytes per coder entry): the state is kept before anything is coded
+    small = torch.empty(sum(len(p) for p, _ in ref[2:]) + 16, dtype=torch.uint8, device="cuda")
+    enc.debug_inject(2)
+    with pytest.raises(RuntimeError, match="scpr error -1"):
+        enc.CompressBatch(dev[2:], [1, 1, 1], out=small)
+    pk1, s1, _ = enc.CompressBatch(dev[2:], [1, 1, 1])
+    assert pk0.cpu().numpy().tobytes() + pk1.cpu().numpy().tobytes() == b"".join(p for p, _ in ref)
+
+
+def test_a_stale_record_in_the_scalar_rans_coder_is_noticed_and_the_call_returns_the_right_bytes(monkeypatch):
+    """k_rans_s hands every entry's constants from its lanes to the scalar unit through memory (a ring in the L2, read back through
+    the scalar data cache, s_dcache_inv per trip); that the scalar unit then sees what was laid rests on measured, unspecified
+    behaviour.  So the kernel checks every step (the lanes take it again from the entry itself).  scpr_debug_inject 3 leaves one
+    trip's records unlaid - the scalar unit reads what the ring held a lap before: the check must speak, the host must code the
+    call's blocks again with k_rans, and the caller must get the oracle's bytes; the codec then stays with k_rans"""
+    import torch
+    monkeypatch.setenv("SCPR_ENABLE_DEBUG_INJECT", "1")
+    monkeypatch.setenv("SCPR_RANS_SCALAR_MAX", "1000000")
+    w, h, n = 320, 240, 3
+    seq = DesktopSequence(w, h, seed=5, noise_fraction=0.3)
+    frames = np.stack([seq.frame(t) for t in range(n)])
+    dev = torch.from_numpy(frames).cuda().reshape(n, -1)
+    ora = O.OracleCodec(w, h, 32)
+    ref = [ora.compress(f, key=(t == 0)) for t, f in enumerate(frames)]
+    enc = _codec(w, h)
+    assert enc.debug_rans_recoded() == 0
+    enc.debug_inject(3)
+    pk, sizes, fts = enc.CompressBatch(dev[:2], [0, 1])
+    assert enc.debug_rans_recoded() == 1, "the stale trip went unnoticed"
+    pk2, sizes2, _ = enc.CompressBatch(dev[2:], [1])
+    assert enc.debug_rans_recoded() == 1
+    assert pk.cpu().numpy().tobytes() + pk2.cpu().numpy().tobytes() == b"".join(p for p, _ in ref)
+    # and without the injection nothing is coded twice
+    enc2 = _codec(w, h)
+    pk3, _, _ = enc2.CompressBatch(dev, [0, 1, 1])
+    assert enc2.debug_rans_recoded() == 0 and pk3.cpu().numpy().tobytes() == b"".join(p for p, _ in ref)
+
+
+def test_fault_injection_is_inert_unless_armed_at_creation(monkeypatch):
+    monkeypatch.delenv("SCPR_ENABLE_DEBUG_INJECT", raising=False)
+    enc = _codec(64, 48)
+    with pytest.raises(RuntimeError):
+        enc.debug_inject(1)
+
+
+def test_a_call_that_failed_between_read_back_and_hand_over_leaves_nothing_queued(monkeypatch):
     """a HIP error between d2h() and sync_out() used to leave read-backs queued whose destinations were the failed call's stack
     variables; the next entry point's sync_out() then wrote there.  Every entry point now drops what is queued first."""
     import torch
+    monkeypatch.setenv("SCPR_ENABLE_DEBUG_INJECT", "1")
     w, h, n = 64, 48, 3
     frames = np.stack([DesktopSequence(w, h, seed=4).frame(t) for t in range(n)])
     dev = torch.from_numpy(frames).cuda().reshape(n, -1)
@@ -160,9 +225,3 @@ def test_reinit_with_another_picture_size_on_the_same_strides(first, second):
         assert r == n and torch.equal(out.reshape(n, -1), dev), (w, h)
         enc.Deinit()
         dec.Deinit()
-
-
-def test_an_empty_cu_list_is_refused():
-    enc = _codec(64, 48)
-    with pytest.raises(ValueError):
-        enc.SetCuMask([])
