@@ -462,7 +462,9 @@ def per_frame_api_ms(local_rank, frames_host, w, h, bpp):
         r, _ = dec.DecompressFrame(p, ft)
         assert r == 1
         rows.setdefault("decode_key" if ft == 0 else "decode_p", []).append((time.perf_counter() - t0) * 1e3)
-    return {k: round(statistics.median(v), 2) for k, v in sorted(rows.items())}
+    out = {k: round(statistics.median(v), 2) for k, v in sorted(rows.items())}
+    out["samples_ms"] = {k: [round(x, 2) for x in v] for k, v in sorted(rows.items())}
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ a rank ---

@@ -10,14 +10,13 @@
 #include <vector>
 
 #include <hip/hip_runtime.h>
-#include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_scan.hpp>
 
 #include "../../include/scpr_amd.h"
 #include "scpr_kernels.hpp"
 #include "scpr_wave.hpp"
 #include "scpr_rans_s.hpp"
 #include "scpr_fixed.hpp"
+#include "scpr_ctxsort.hpp"
 #include "scpr_v2.hpp"
 #include "scpr_inter.hpp"
 
@@ -110,7 +109,7 @@ struct scpr_codec {
   DevBuf planes, exitmap, entry, runrec, tilecnt, tileoff, hdrrec, hdrcnt, frametot, tnmap;
   size_t tn_half = 0;
   // per-batch buffers
-  DevBuf flags, slotlist, genlist, bases, totals, runs, runpos, keys[2], vals[2], cstart, sorttmp, entries, ranges;
+  DevBuf flags, slotlist, genlist, bases, totals, runs, runpos, keys[2], vals[2], cstart, csblocks, cssegs, cscnt, csoff, entries, ranges;
   DevBuf rblocks, rscratch, rrec, rsize, packets, pktoff, blkdst, outsizes, total64, arena, arena2, arena_top, err, rcp;  // (arena2: where compact_tables moves the live tables)
   DevBuf decframes, decstates, hoststage_in, hoststage_out, chainlists, chaincounts;
   FixBufs fixr, fixm;  // run list / P-frame symbol list
@@ -578,7 +577,7 @@ static u64 chunk_total_limit() {  // SCPR_DEBUG_CHUNK_LIMIT: tests reach the re-
   const char* e = getenv("SCPR_DEBUG_CHUNK_LIMIT");
   return e ? strtoull(e, nullptr, 0) : kChunkTotalLimit;
 }
-constexpr int kMaxChunkGens = 512;  // generations per encode chunk (see scpr_compress_batch)
+constexpr int kMaxChunkGens = 1023;  // generations per encode chunk: a colour key names its generation in ten bits (emit_colour)
 constexpr int kRecut = 1;  // encode_chunk: the chunk's symbol totals pass 32 bits - nothing has been coded, *nfit frames would fit
 static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int ngens, bool load_first, std::vector<FrameBase>& hb, std::vector<u32>& pchanged, int* nfit, u64 room,
                         const EncHostState& hs0) {
@@ -663,6 +662,33 @@ static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int n
   HIPCHK(sync_out(c, st));
   *nfit = (int)tot[4];
   if (*nfit < n) return kRecut;  // (the 32-bit bases of the frames past *nfit have wrapped: the caller cuts the chunk there)
+  // Where the colour pairs go (scpr_ctxsort.hpp): a generation's share of the pair arrays is three PLANE arrays of L pairs each
+  // (L = its literals: frames of a generation are consecutive, so its pairs are [col_base of its first frame, + 3 L)); a frame
+  // writes its literals behind those of the generation's earlier frames.  pad0 = the frame's first pair, pad1 = L.
+  std::vector<CsSeg> segs;
+  std::vector<CsBlock> cblocks;
+  {
+    std::vector<u32> gbase(ngens, 0), glit(ngens, 0);
+    std::vector<bool> seen(ngens, false);
+    for (int i = 0; i < n; i++) {
+      const int gq = cf[i].gen;
+      if (gq < 0 || cf[i].kind == 1 || hb[i].ncol == 0) continue;
+      if (!seen[gq]) gbase[gq] = hb[i].col_base, seen[gq] = true;
+      hb[i].pad0 = gbase[gq] + glit[gq];
+      glit[gq] += hb[i].ncol / 3;
+    }
+    for (int i = 0; i < n; i++)
+      if (cf[i].gen >= 0 && cf[i].kind != 1) hb[i].pad1 = glit[cf[i].gen];
+    for (int gq = 0; gq < ngens; gq++)
+      for (u32 p = 0; p < 3 && glit[gq]; p++) {
+        const u32 base = gbase[gq] + p * glit[gq];
+        CsSeg sg{(u32)cblocks.size(), 0, base, 0};
+        for (u32 o = 0; o < glit[gq]; o += CS_B) cblocks.push_back(CsBlock{base + o, std::min<u32>(CS_B, glit[gq] - o), (u32)segs.size(), 0});
+        sg.blk_end = (u32)cblocks.size();
+        segs.push_back(sg);
+      }
+    HIPCHK(h2d(c, c->bases.p, hb.data(), n * sizeof(FrameBase), st));
+  }
   {  // may the chunk's packets not fit?  Then the state the chains are about to change is kept first (nothing has changed it yet).
     u64 bound = 0;
     for (int i = 0; i < n; i++) bound += packet_bound(cf[i].hdr_len, cf[i].kind == 1 ? 0 : hb[i].nsyms);
@@ -708,7 +734,7 @@ static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int n
     std::vector<PBase> pbv(np);
     for (int k = 0; k < np; k++) {
       const FrameBase& b = hb[pfidx[k]];
-      pbv[k] = PBase{b.run_base, b.sym_base, b.col_base, b.misc_base, b.nbt, (u32)pgen[k], 0, 0};
+      pbv[k] = PBase{b.run_base, b.sym_base, b.pad0, b.misc_base, b.nbt, (u32)pgen[k], b.pad1, 0};
     }
     HIPCHK(h2d(c, c->pbase.p, pbv.data(), np * sizeof(PBase), st));
     hipLaunchKernelGGL(k_pemit, dim3((nblocks + 63) / 64 + 1, np), dim3(64), 0, st, planes, g, c->pframes.as<PFrame>(), c->pbase.as<PBase>(), c->binfo.as<u32>(), c->btype.as<u8>(),
@@ -733,27 +759,38 @@ static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int n
   }
   stage_begin(c, ST_SORT);
   {
-    int genbits = 1;
-    while ((1 << genbits) < ngens) genbits++;
+    // stable partition of every (generation, plane) segment by its 12 context bits: two counting passes of six bits, least
+    // significant first (scpr_ctxsort.hpp); keys[0] -> keys[1] -> keys[0]
     if (Ctot > 0) {
-      size_t stmp = 0;
-      HIPCHK(rocprim::radix_sort_pairs(nullptr, stmp, c->keys[0].as<u32>(), c->keys[1].as<u32>(), c->vals[0].as<u32>(), c->vals[1].as<u32>(), Ctot, 8, 22 + genbits, st));
-      HIPCHK(c->sorttmp.reserve(stmp));
-      HIPCHK(rocprim::radix_sort_pairs(c->sorttmp.p, stmp, c->keys[0].as<u32>(), c->keys[1].as<u32>(), c->vals[0].as<u32>(), c->vals[1].as<u32>(), Ctot, 8, 22 + genbits, st));
+      const unsigned nsb = (unsigned)cblocks.size(), nsg = (unsigned)segs.size();
+      HIPCHK(c->csblocks.reserve((size_t)nsb * sizeof(CsBlock)));
+      HIPCHK(c->cssegs.reserve((size_t)nsg * sizeof(CsSeg)));
+      HIPCHK(c->cscnt.reserve((size_t)nsb * 64 * 4));
+      HIPCHK(c->csoff.reserve((size_t)nsb * 64 * 4));
+      HIPCHK(h2d(c, c->csblocks.p, cblocks.data(), (size_t)nsb * sizeof(CsBlock), st));
+      HIPCHK(h2d(c, c->cssegs.p, segs.data(), (size_t)nsg * sizeof(CsSeg), st));
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cs_count<8>), dim3(nsb), dim3(256), 0, st, c->keys[0].as<u32>(), c->csblocks.as<CsBlock>(), c->cscnt.as<u32>());
+      hipLaunchKernelGGL(k_cs_scan, dim3(nsg), dim3(64), 0, st, c->cssegs.as<CsSeg>(), c->cscnt.as<u32>(), c->csoff.as<u32>());
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cs_scatter<8>), dim3(nsb), dim3(256), 0, st, c->keys[0].as<u32>(), c->vals[0].as<u32>(), c->csblocks.as<CsBlock>(), c->csoff.as<u32>(),
+                         c->keys[1].as<u32>(), c->vals[1].as<u32>());
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cs_count<14>), dim3(nsb), dim3(256), 0, st, c->keys[1].as<u32>(), c->csblocks.as<CsBlock>(), c->cscnt.as<u32>());
+      hipLaunchKernelGGL(k_cs_scan, dim3(nsg), dim3(64), 0, st, c->cssegs.as<CsSeg>(), c->cscnt.as<u32>(), c->csoff.as<u32>());
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cs_scatter<14>), dim3(nsb), dim3(256), 0, st, c->keys[1].as<u32>(), c->vals[1].as<u32>(), c->csblocks.as<CsBlock>(), c->csoff.as<u32>(),
+                         c->keys[0].as<u32>(), c->vals[0].as<u32>());
     }
-    // (tests: two keys of the sorted array change places - what rocPRIM's defect looks like from here)
+    // (tests: two keys of the partitioned array change places - the order proof below must end the call)
     if (c->dbg_inject == 2 && Ctot > 1) {
       c->dbg_inject = 0;
-      hipLaunchKernelGGL(k_debug_swap, dim3(1), dim3(1), 0, st, c->keys[1].as<u32>(), 0u, (u32)Ctot - 1u);
+      hipLaunchKernelGGL(k_debug_swap, dim3(1), dim3(1), 0, st, c->keys[0].as<u32>(), 0u, (u32)Ctot - 1u);
     }
     // chain starts from the sorted keys - and the proof that they ARE sorted: a pair out of order sets bit 5 of the error word, which
     // keeps the chain kernels from following chain lengths made of garbage (k_colour_chain_w, k_chain_lists) and ends the call
-    hipLaunchKernelGGL(k_chain_starts, dim3((unsigned)((Ctot + 256) / 256)), dim3(256), 0, st, c->keys[1].as<u32>(), (u32)Ctot, (u32)nchains, c->cstart.as<u32>(), c->err.as<u32>());
+    hipLaunchKernelGGL(k_chain_starts, dim3((unsigned)((Ctot + 256) / 256)), dim3(256), 0, st, c->keys[0].as<u32>(), (u32)Ctot, (u32)nchains, c->cstart.as<u32>(), c->err.as<u32>());
   }
   stage_end(c, ST_SORT);
   if (getenv("SCPR_DEBUG_KEYS") && Ctot) {
     std::vector<u32> hk(Ctot), hc(nchains + 1);
-    HIPCHK(d2h(c, hk.data(), c->keys[1].p, Ctot * 4, st));
+    HIPCHK(d2h(c, hk.data(), c->keys[0].p, Ctot * 4, st));
     HIPCHK(d2h(c, hc.data(), c->cstart.p, (nchains + 1) * 4, st));
     HIPCHK(sync_out(c, st));
     size_t unsorted = 0, firstu = 0, badc = 0, firstc = 0;
@@ -834,7 +871,7 @@ static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int n
                        c->chaincounts.as<u32>());
     const unsigned grid = (unsigned)std::min<u32>(cap, 24576u);
     if (grid)
-      hipLaunchKernelGGL(k_colour_chain_w, dim3(grid), dim3(64), 0, st, c->keys[1].as<u32>(), c->vals[1].as<u32>(), c->cstart.as<u32>(), c->chainlists.as<u32>(),
+      hipLaunchKernelGGL(k_colour_chain_w, dim3(grid), dim3(64), 0, st, c->keys[0].as<u32>(), c->vals[0].as<u32>(), c->cstart.as<u32>(), c->chainlists.as<u32>(),
                          c->chaincounts.as<u32>(), cap, c->f0, ar, cp, c->entries.as<u32>());
   }
   stage_end(c, ST_COLOUR);
@@ -928,7 +965,7 @@ void scpr_destroy(scpr_codec* c) {
     for (int k = 0; k < 2; k++) (void)hipEventDestroy(c->ev_in[k]);
   }
   DevBuf* all[] = {&c->hb_frames, &c->hb_packets, &c->hb_list, &c->snap_mvs, &c->snap_state, &c->planes, &c->tnmap, &c->exitmap, &c->entry, &c->runrec, &c->tilecnt, &c->tileoff, &c->hdrrec, &c->hdrcnt, &c->frametot, &c->flags, &c->slotlist, &c->genlist,
-                   &c->bases, &c->totals, &c->runs, &c->runpos, &c->keys[0], &c->keys[1], &c->vals[0], &c->vals[1], &c->cstart, &c->sorttmp,
+                   &c->bases, &c->totals, &c->runs, &c->runpos, &c->keys[0], &c->keys[1], &c->vals[0], &c->vals[1], &c->cstart, &c->csblocks, &c->cssegs, &c->cscnt, &c->csoff,
                    &c->entries, &c->ranges, &c->rblocks, &c->rscratch, &c->rrec, &c->rsize, &c->packets, &c->pktoff, &c->blkdst, &c->outsizes, &c->total64, &c->arena,
                    &c->arena_top, &c->err, &c->rcp, &c->decframes, &c->decstates, &c->hoststage_in, &c->hoststage_out, &c->chainlists, &c->chaincounts, &c->fixr.cnt, &c->fixr.off, &c->fixr.tot, &c->fixr.sym, &c->fixr.pos, &c->fixr.gen, &c->fixm.cnt, &c->fixm.off, &c->fixm.tot, &c->fixm.sym, &c->fixm.pos, &c->fixm.gen, &c->kinds, &c->pidx, &c->fidx, &c->pframes, &c->pflag, &c->binfo, &c->smv, &c->btype, &c->bmv, &c->bcnt, &c->boff, &c->bflag, &c->pinfo, &c->ptot, &c->pbase, &c->misc, &c->miscpos, &c->miscranges, &c->mvs, &c->mvs_keep, &c->fixed_persist, &c->misc_persist, &c->colour_persist, &c->decgops, &c->decfixed, &c->dec_fixed_persist, &c->dec_colour_persist, &c->dec_arena, &c->dec_arena2, &c->arena2, &c->dec_arena_top, &c->mvdict, &c->mvpre, &c->gmask};
   for (DevBuf* b : all) b->release();
@@ -1202,10 +1239,8 @@ static int64_t compress_core(scpr_codec* c, const void* d_frames, int nframes, i
         ChunkFrame& fr = cf[i];
         const bool flat = hflags[i] == 0;
         const u32 rgb = hflags[npacked + i] & 0xFFFFFFu;
-        // The colour symbols are partitioned by a radix sort over (generation, context): bits 8 .. 22 + log2(generations).
-        // rocPRIM 4.2 (ROCm 7.2) returns UNSORTED output for a bit range that ends at bit 32 when the input has ~10^5 elements
-        // (its merge-sort path: tools/rocprim_sort_check.hip; 10^3 and 2*10^6 elements are fine), so a chunk stops before its
-        // 513th generation and the sort never sees bit 31.
+        // (a chunk stops before its 1024th generation: kMaxChunkGens.  Rounds 1-4 stopped at 512 to keep rocPRIM's radix sort off a
+        // bit range on which it returned unsorted output, tools/rocprim_sort_check.hip; the sort is the repo's own now.)
         const bool starts_gen = flat ? !(c->last_flat && c->last_flat_rgb == rgb) : !(c->frames_done && ftypes[f0 + i]);
         if (starts_gen && ngens == kMaxChunkGens) {
           n = i;
@@ -1362,7 +1397,7 @@ static int64_t compress_core(scpr_codec* c, const void* d_frames, int nframes, i
       if ((rc = code_chunk(false)) != SCPR_OK) return rc;
     }
     if (err & 32) {
-      fprintf(stderr, "[scpr] the colour symbols came back from the radix sort out of order (rocPRIM; DESIGN.md 9): nothing was coded with them\n");
+      fprintf(stderr, "[scpr] the colour symbols are not grouped by context in front of the chains (k_chain_starts' proof): nothing was coded with them\n");
       return SCPR_E_DEVICE;
     }
     if (err & 2) return SCPR_E_CAPACITY;  // (the bound said this could happen: the state was kept - the caller takes the call back)
@@ -1964,8 +1999,8 @@ int scpr_debug_colour_chain(int device, const uint8_t* syms, int n, int f0, uint
 }
 
 // Test hook: the next scpr_compress_batch fails on purpose.  1: returns SCPR_E_DEVICE between the read-backs of its results and
-// their hand-over (what a HIP error there leaves behind); 2: two colour keys change places behind the radix sort (an unsorted
-// result, as rocPRIM's defect gives: the call must end with SCPR_E_DEVICE, not follow the chains).
+// their hand-over (what a HIP error there leaves behind); 2: two colour keys change places behind the partition by context (the
+// order proof of k_chain_starts must end the call with SCPR_E_DEVICE, no chain is followed); 3: see scpr_rans_s.hpp.
 int scpr_debug_inject(scpr_codec* c, int what) {
   if (!c) return SCPR_E_PARAM;
   if (!c->dbg_armed) return SCPR_E_PARAM;  // (a codec created without SCPR_ENABLE_DEBUG_INJECT=1 cannot be made to fail)

@@ -885,15 +885,15 @@ __global__ __launch_bounds__(64) void k_pemit(const u8* __restrict__ planes, Geo
     pg = px[1];
     pbv = px[2];
   }
-  u32 ri = fb.run_base + o.run, ci = fb.col_base + o.col;
+  u32 ri = fb.run_base + o.run, ci = fb.col_base + o.col / 3u;  // (col_base: the frame's first literal in its generation's plane arrays; pad0: their stride)
   int lastt = 0;
   walk_rect_runs(cur, prv, g.S, r, [&](int type, int n, int first, int lasti) {
     runs[ri] = make_run(type, lastt, n, false);
     runpos[ri] = pos;
     ri++;
     if (type == 0) {
-      emit_colour(fb.gen, ld3(cur + first), pg, pbv, pos + 1, ci, keys, vals);
-      ci += 3;
+      emit_colour(fb.gen, ld3(cur + first), pg, pbv, pos + 1, ci, fb.pad0, keys, vals);
+      ci += 1;
     }
     pos += 2 + (type == 0 ? 3 : 0);
     lastt = type;

@@ -576,7 +576,7 @@ __global__ __launch_bounds__(256) void k_scan_tiles(const u32* __restrict__ tile
 // per batch: frame bases (one thread).  kinds: 0 key frame, 1 flat (no symbols), 2 P-frame
 constexpr u64 kChunkTotalLimit = 0xFFFF0000ull;  // runs / coder entries / colour symbols / P-frame symbols of one encode chunk (32-bit positions)
 struct FrameBase {
-  u32 run_base, sym_base, col_base, misc_base, nruns, nsyms, ncol, nmisc, hdr_runs, nbt, pad0, pad1;
+  u32 run_base, sym_base, col_base, misc_base, nruns, nsyms, ncol, nmisc, hdr_runs, nbt, pad0, pad1;  // pad0 / pad1: where the frame's literals go in its generation's plane arrays, and their stride (the host fills them in: encode_chunk)
 };
 __global__ void k_bases(const int* __restrict__ kinds, const int* __restrict__ pidx, int nfr, const u32* __restrict__ frametot,
                         const u32* __restrict__ hdrcnt, const u32* __restrict__ ptot, FrameBase* __restrict__ bases, u32* __restrict__ totals, u64 limit) {
@@ -624,26 +624,30 @@ __global__ void k_bases(const int* __restrict__ kinds, const int* __restrict__ p
 }
 
 // colour context ids from the two previous bytes (SC_CXSHIFT = 2, MAKECX1,
-// screencap.h:35-36; WritePixel/EncodeRGB, screencap.cpp:609-643)
-__device__ __forceinline__ void emit_colour(u32 gen, u32 pix, u32 prev_g, u32 prev_b, u32 pos, u32 idx, u32* __restrict__ keys, u32* __restrict__ vals) {
+// screencap.h:35-36; WritePixel/EncodeRGB, screencap.cpp:609-643).  The three pairs of a literal go to the three PLANE arrays of
+// its generation (idx, idx + stride, idx + 2 * stride; stride = the generation's literals): scpr_ctxsort.hpp sorts each plane's
+// share by context and needs generation and plane from nobody.
+__device__ __forceinline__ void emit_colour(u32 gen, u32 pix, u32 prev_g, u32 prev_b, u32 pos, u32 idx, u32 stride, u32* __restrict__ keys, u32* __restrict__ vals) {
   const u32 c0 = pix & 255, c1 = (pix >> 8) & 255, c2 = (pix >> 16) & 255;
   const u32 cx0 = (prev_b >> 2) | ((prev_g >> 2) << 6);
   const u32 cx1 = (c0 >> 2) | ((prev_b >> 2) << 6);
   const u32 cx2 = (c1 >> 2) | ((c0 >> 2) << 6);
   const u32 k0 = cx0, k1 = 4096 + cx1, k2 = 8192 + cx2;
   keys[idx] = (gen << 22) | (k0 << 8) | c0;
-  keys[idx + 1] = (gen << 22) | (k1 << 8) | c1;
-  keys[idx + 2] = (gen << 22) | (k2 << 8) | c2;
+  keys[idx + stride] = (gen << 22) | (k1 << 8) | c1;
+  keys[idx + 2 * stride] = (gen << 22) | (k2 << 8) | c2;
   vals[idx] = pos;
-  vals[idx + 1] = pos + 1;
-  vals[idx + 2] = pos + 2;
+  vals[idx + stride] = pos + 1;
+  vals[idx + 2 * stride] = pos + 2;
 }
+
 // Chain offsets from the sorted keys: cstart[q] = first sorted position whose chain id (generation * NCOLCTX +
 // plane/context) is >= q, for q = 0 .. nchains (so cstart[nchains] = n).  One thread per sorted position plus a
 // sentinel; a thread fills the (usually empty) gap of chains between its predecessor and itself.  This replaces a
 // histogram of one global atomic per colour symbol, most of them on a handful of hot contexts.
-// The same pass proves the order it relies on (the sort is rocPRIM's, and rocPRIM 4.2 has returned unsorted output: DESIGN.md 9):
-// a key below its predecessor - or one that names no chain of this call - sets bit 5 of *err and writes nothing.
+// The same pass proves the order it relies on (free here: both keys are in registers anyway; rounds 1-4 sorted with rocPRIM,
+// which has returned unsorted output, and the proof stayed when scpr_ctxsort.hpp took over): a key below its predecessor - or
+// one that names no chain of this call - sets bit 5 of *err and writes nothing.
 __global__ __launch_bounds__(256) void k_chain_starts(const u32* __restrict__ skeys, u32 n, u32 nchains, u32* __restrict__ cstart, u32* __restrict__ err) {
   const u32 i = blockIdx.x * 256 + threadIdx.x;
   if (i > n) return;
@@ -689,7 +693,7 @@ __global__ __launch_bounds__(256) void k_symbols(const u8* __restrict__ planes, 
         pg = pp[1];
         pb = pp[2];
       }
-      emit_colour(gen, ld3(px), pg, pb, pos, fb.col_base + 3 * j, keys, vals);
+      emit_colour(gen, ld3(px), pg, pb, pos, fb.pad0 + j, fb.pad1, keys, vals);
     }
     return;
   }
@@ -724,7 +728,7 @@ __global__ __launch_bounds__(256) void k_symbols(const u8* __restrict__ planes, 
         const int y = p / g.W, x = p - y * g.W;
         const u8* px = plane + (size_t)y * g.S + x * 3;
         const u8* pp = x > 0 ? px - 3 : plane + (size_t)(y - 1) * g.S + (g.W - 1) * 3;
-        emit_colour(gen, ld3(px), pp[1], pp[2], pos + 1, fb.col_base + 3 * (Hr + litidx), keys, vals);
+        emit_colour(gen, ld3(px), pp[1], pp[2], pos + 1, fb.pad0 + Hr + litidx, fb.pad1, keys, vals);
       }
     }
     lit_run += tl;
