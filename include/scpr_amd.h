@@ -91,11 +91,13 @@ int scpr_decompress_frame(scpr_codec* c, const void* src, int src_len, void* dst
  * How: a chunk's packets are bounded before anything is coded (2 bytes per coder
  * entry + 4 per block of 131072 + headers); only when that bound exceeds the room
  * left is the state the chains are about to change copied aside first (models,
- * live dense tables, previous frame: ~10-30 MB device to device).  A call that may
- * be cut into several chunks (more than 512 frames, or a per-frame scratch limit)
- * copies that state at its start unless out_capacity covers the closed-form worst
- * case, about 10 bytes per pixel and frame; a call of one chunk - every call of the
- * reference's shape, W*H*6 bytes per frame - pays only when the exact bound says so.
+ * live dense tables, previous frame: ~10-30 MB device to device).  A call of
+ * several frames copies that state at its start unless out_capacity covers the
+ * closed-form worst case, about 10 bytes per pixel and frame (a later chunk of the
+ * call could not take back an earlier one's changes) - so a multi-frame call with
+ * the reference's W*H*6 bytes per frame does pay for the copy (tens of
+ * microseconds; more with a long live GOP's dense tables); a one-frame call pays
+ * only when the exact bound says so.
  * Any OTHER error (< 0) from a compress call: if the call had kept that copy it is
  * taken back whole as well; if not, the codec is left as the reference leaves
  * itself after an exception (screencap.cpp:1634-1644): scpr_compress_* return 0

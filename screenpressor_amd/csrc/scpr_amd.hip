@@ -1160,11 +1160,11 @@ static int txn_begin(scpr_codec* c, EncTxn& t, const int* ftypes, int nframes, s
   HIPCHK(c->snap_mvs.reserve(nblk0 * 4));
   HIPCHK(hipMemcpyAsync(c->snap_mvs.p, c->mvs.p, nblk0 * 4, hipMemcpyDeviceToDevice, c->stream));
   // (at most 5 coder entries per pixel + 16 per block: Appendix A of SURVEY.md)
-  const u64 most_syms = 5ull * g.NP + 16ull * nblk0 + 16, worst = packet_bound(4, most_syms);
-  // a call that is certainly ONE chunk (frames, generations and symbol totals all within a chunk's limits) needs no snapshot
-  // here: encode_chunk bounds its packets exactly before anything is coded and keeps the state then, if at all
-  const bool one_chunk = nframes <= std::min(c->slots, kMaxChunkGens) && most_syms * (u64)nframes < chunk_total_limit();
-  if (nframes > 1 && !one_chunk && (u64)out_capacity < worst * (u64)nframes) return snap_take(c, t.hs0);
+  const u64 worst = packet_bound(4, 5ull * g.NP + 16ull * nblk0 + 16);
+  // (Round 5 tried to leave calls of ONE chunk to encode_chunk's exact bound: tests/stress_cases.py case 1 - a refused call of ten
+  // noise P-frames - then coded other bytes afterwards.  A chunk of several frames has moved state by the time its totals are
+  // known; the copy at the call's start is tens of microseconds.  Kept as it was.)
+  if (nframes > 1 && (u64)out_capacity < worst * (u64)nframes) return snap_take(c, t.hs0);
   return SCPR_OK;
 }
 static int64_t txn_refuse(scpr_codec* c, const EncTxn& t, int* ftypes, int code) {  // the codec as the call found it
