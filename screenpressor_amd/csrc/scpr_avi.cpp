@@ -257,8 +257,8 @@ scpr_avi_reader* scpr_avi_open(const char* path) {
       if (std::fread(h, 1, n, f) != n) break;
       scpr_format& fm = r->info.format;
       fm.width = get32(h + 4);
-      const int32_t hh = (int32_t)get32(h + 8);
-      fm.height = (uint32_t)(hh < 0 ? -hh : hh);
+      const uint32_t hh = get32(h + 8);  // biHeight is signed (negative: a top-down DIB); its magnitude, also for the most negative value
+      fm.height = (hh & 0x80000000u) ? 0u - hh : hh;
       fm.bit_count = get16(h + 14);
       fm.compression = get32(h + 16);
       fm.size_image = get32(h + 20);
@@ -273,7 +273,7 @@ scpr_avi_reader* scpr_avi_open(const char* path) {
   if (!have_fmt || !movi_fourcc) return fail();
   const uint32_t want_hi = (uint32_t)('0' + vid_stream / 10) | ((uint32_t)('0' + vid_stream % 10) << 8);
   auto is_video_chunk = [&](uint32_t id) { return (id & 0xFFFF) == want_hi && ((id >> 16) == (('d') | ('c' << 8)) || (id >> 16) == (('d') | ('b' << 8))); };
-  if (idx_pos && idx_size >= 16) {
+  if (idx_pos && idx_size >= 16 && idx_pos + idx_size <= file_size) {  // (an index that claims more bytes than the file has is no index: the movi list is walked)
     std::vector<uint8_t> idx(idx_size);
     std::fseek(f, (long)idx_pos, SEEK_SET);
     if (std::fread(idx.data(), 1, idx_size, f) != idx_size) return fail();

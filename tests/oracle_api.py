@@ -26,9 +26,9 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        so = os.path.join(ORACLE_DIR, "libspo.so")
+        so = os.environ.get("SPO_LIB") or os.path.join(ORACLE_DIR, "libspo.so")  # (SPO_LIB: the sanitizer build, tests/test_sanitizers.py)
         srcs = [os.path.join(ORACLE_DIR, f) for f in ("spo_codec.cpp", "spo_capi.cpp", "spo_codec.h", "spo_model.h")]
-        if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        if not os.environ.get("SPO_LIB") and (not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)):
             subprocess.check_call(["make", "-C", ORACLE_DIR, "libspo.so"], stdout=subprocess.DEVNULL)
         L = C.CDLL(so)
         L.spo_create.restype = C.c_void_p
