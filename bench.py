@@ -53,6 +53,7 @@ def parse_args(argv=None):
     ap.add_argument("--c4-leg", action="store_true", help="run the configs[3] leg of an N > 1 run at N = 1 too (to rehearse it)")
     ap.add_argument("--c4-frames", type=int, default=None, help="frames of the configs[3] leg's stream (default 1200)")
     ap.add_argument("--no-others", action="store_true", help="N = 1: do not measure the other single-GPU configs")
+    ap.add_argument("--no-n8", action="store_true", help="N = 1: do not time the 8 x 300-frame stream set an N = 8 headline run shards (config.others' same-stream denominator; ~1.5 min of host rendering)")
     ap.add_argument("--no-host-boundary", action="store_true", help="N = 1: skip config.host_boundary and the per-frame calls (profiling runs: their launches would mix into the per-kernel figures of the HBM-resident step)")
     ap.add_argument("--rehearse-one-gpu", action="store_true", help="N > 1 on a one-GPU box: every rank on GPU 0, collectives over gloo on CPU tensors (rehearses the multi-rank path with the real codecs; not a scaling measurement)")
     ap.add_argument("--selftest-launcher", action="store_true", help="no codec, no GPU: ranks exchange synthetic packets over gloo (tests the launcher, the sharding and the gather)")
@@ -169,7 +170,7 @@ def make_frames(w, h, seed, bpp, t0, t1, dev=None, world=1):
     import multiprocessing as mp
     import numpy as np
     n = t1 - t0
-    nproc = max(1, min(8, host_cores(world), n // 4))
+    nproc = max(1, min(16 if n > 600 else 8, host_cores(world), n // 4))
     pitch = w * 4 if bpp == 32 else (w * 3 + 3) & ~3
     if dev is not None:
         import torch
@@ -441,6 +442,33 @@ def other_config(runner_cache, dev, local_rank, label, wl, frames, gop, cpu_fram
             res["cpu_baseline"]["all_cores"] = cpu["all_cores"]
         res["parity"] = {"vs": "oracle (CPU restatement; pinned to the reference only for rANS)", "frames_checked": nf, "ok": parity_of(host, r["sizes"], one, nf)}
     return res
+
+
+def n8_same_stream_entry(dev, local_rank, w, h, n, headline_ms, headline_sha):
+    """The default multi-GPU workload is WEAK scaling of the headline: rank r codes the 300 key frames of synthetic desktop seed 1 + r.
+    This times the work of an N = 8 run - the eight streams, 2400 key frames - through the same Runner.step on ONE GPU, so that a
+    later SCALE line has a same-stream denominator: (value at N = 8) / (this value) is the strong-scaling speed-up of the job the
+    eight ranks do together.  (One GPU holds 1024 key-frame chains at once, one per SIMD: 2400 chains are two and a bit rounds, so
+    the figure to expect is well below 8 x 300 frames' time.)"""
+    import torch
+    ranks = 8
+    frames = torch.empty((ranks * n, h * w * 4), dtype=torch.uint8, device=dev)
+    for r in range(ranks):
+        frames[r * n:(r + 1) * n] = make_frames(w, h, 1 + r, 32, 0, n, dev)
+    runner = Runner(dev, local_rank, w, h, 32, ranks * n)
+    wl = Workload("8 x %d key frames" % n, w, h, 32, 1, 0, ranks * n, [0] * (ranks * n), "weak", ranks * n)
+    m = measure(runner, wl, frames, 2, 1)
+    host = m["out"].cpu().numpy()
+    first = int(sum(int(x) for x in m["sizes"][:n]))
+    pix = w * h * ranks * n / 1e6
+    ms = m["elapsed"] / 2 * 1e3
+    return {"config": "the N = 8 headline run's work on ONE GPU: 8 streams (synthetic desktop seeds 1..8) x %d key frames of %dx%d RGB32, one CompressBatch + one DecompressBatch" % (n, w, h),
+            "frames": ranks * n, "passes": 2, "ms_per_step": round(ms, 2), "combined_MPix_s": round(pix / (ms * 1e-3), 1), "enc_MPix_s": round(pix / m["t_enc"], 1),
+            "dec_MPix_s": round(pix / m["t_dec"], 1), "stage_ms": {k: round(v, 2) for k, v in m["stage_ms"].items()}, "lossless_roundtrip": True,
+            "first_stream_is_the_headline_stream": stream_sha256(host[:first]) == headline_sha, "compressed_bytes": int(host.size),
+            "time_vs_one_stream": round(ms / headline_ms, 2),
+            "use": "same-stream denominator for the driver's N = 8 line: strong-scaling speed-up = (N = 8 value) / combined_MPix_s; time_vs_one_stream is how many "
+                   "headline steps these 8 streams cost one GPU (8 would be no overlap at all)"}
 
 
 def per_frame_api_ms(local_rank, frames_host, w, h, bpp):
@@ -860,6 +888,14 @@ def run_rank(args):
             f4k = make_frames(3840, 2160, 1, 32, 0, 150, dev)
             sub("configs[3], one GPU's share of 8: 3840x2160 RGB32, 150 frames as key frames (a frame-sharded stream)", 3840, 2160, 32, 150, [0] * 150, f4k, 1, 10, "stream_4k_keys_150", host_cores())
             sub("configs[3], one GPU's share of 8: 3840x2160 RGB32, ONE GOP of 150 frames (key frame every 150)", 3840, 2160, 32, 150, [0] + [1] * 149, f4k, 150, 10, "stream_4k_ip_k150_1200", host_cores())
+            del f4k
+            cache.clear()
+            torch.cuda.empty_cache()
+            if not args.no_n8:
+                try:
+                    others.append(n8_same_stream_entry(dev, local_rank, W, H, N, ms_per_step, parity["sha256"]))
+                except Exception as e:  # noqa: BLE001
+                    others.append({"config": "the N = 8 headline run's streams on ONE GPU", "error": repr(e)})
             config["others"] = others
         # north_star's target - at least 10x the host-CPU encoder on 4K RGB32 at one GPU, bit-identical output - as ONE field, from the
         # 4K entries above (the CPU side is the oracle port, kind "port": the reference itself cannot be built here)

@@ -43,3 +43,29 @@ int ref_rans_decode_values(const uint8_t* in, const uint16_t* entries, int n, ui
     }
     return (int)(p - in);
 }
+
+/* The reference's OTHER form of the encoder step (rans_byte.h:171-241, :255-278: RansEncSymbolInit / RansEncPutSymbol, which the
+ * reference ships and never calls): the algebra the product's rANS kernels implement (csrc/scpr_model.hpp rans_rcp, k_rans, k_rans_s).
+ * out = { x_max, rcp_freq, bias, cmpl_freq, rcp_shift } */
+void ref_enc_symbol_init(uint32_t start, uint32_t freq, uint32_t* out)
+{
+    RansEncSymbol s;
+    RansEncSymbolInit(&s, start, freq, 12);
+    out[0] = s.x_max; out[1] = s.rcp_freq; out[2] = s.bias; out[3] = s.cmpl_freq; out[4] = s.rcp_shift;
+}
+
+/* one RansEncPutSymbol from state x: returns the new state, the bytes it emitted to bytes[0..*n) in emission order */
+uint32_t ref_enc_put_symbol(uint32_t x, uint32_t start, uint32_t freq, uint8_t* bytes, int* n)
+{
+    RansEncSymbol s;
+    RansState r = x;
+    uint8_t buf[8];
+    uint8_t* p = buf + 8;
+    int i, k;
+    RansEncSymbolInit(&s, start, freq, 12);
+    RansEncPutSymbol(&r, &p, &s);
+    k = (int)(buf + 8 - p);
+    for (i = 0; i < k; i++) bytes[i] = buf[7 - i];   /* the byte written first sits at the highest address */
+    *n = k;
+    return r;
+}

@@ -68,6 +68,23 @@ int hm_chain_fixed_dec(int nsym, const uint16_t* ivl, const uint16_t* expect, in
   return bad;
 }
 
+// the table entry the rANS kernels read for `freq` (rans_rcp, scpr_model.hpp): { rcp, shift, pad }
+void hm_rans_params(uint32_t freq, uint32_t* out) {
+  const RansRcp r = rans_rcp(freq);
+  out[0] = r.rcp, out[1] = r.shift, out[2] = r.pad;
+}
+// one encoder step in the kernels' algebra (k_rans / k_rans_s: x_max = freq << 19, at most two bytes leave the state, then
+// x + start + pad + (x / freq by the reciprocal) * (4096 - freq)); bytes in emission order
+uint32_t hm_rans_step(uint32_t x, uint32_t start, uint32_t freq, uint8_t* bytes, int* n) {
+  const RansRcp r = rans_rcp(freq);
+  const uint32_t xm = freq << 19;
+  int k = 0;
+  while (x >= xm && k < 2) bytes[k++] = (uint8_t)x, x >>= 8;
+  *n = k;
+  const uint32_t q = (uint32_t)(((uint64_t)x * r.rcp) >> 32) >> r.shift;
+  return x + start + r.pad + q * ((uint32_t)kProbScale - freq);
+}
+
 // exact-division check of the reciprocal used by the rANS kernel
 uint64_t hm_rcp_mismatches(uint32_t freq, const uint32_t* xs, int n) {
   RansRcp r = rans_rcp(freq);

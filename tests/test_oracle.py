@@ -52,6 +52,37 @@ def test_rans_block_matches_reference_header(n):
     assert np.array_equal(vals[~coded], e[~coded, 1])
 
 
+@pytest.mark.skipif(not os.path.exists(REF_SO), reason="oracle/_ref not built (no reference tree and no prebuilt copy)")
+def test_product_rans_algebra_is_the_reference_headers_symbol_form():
+    """rans_byte.h:171-241, :255-278 (RansEncSymbolInit / RansEncPutSymbol, compiled in place) against the table and the step the
+    product's rANS kernels implement (csrc/scpr_model.hpp rans_rcp; k_rans / k_rans_s): for EVERY freq 1..4096 the reciprocal,
+    the shift, bias - start, x_max and 4096 - freq are the header's, and one step from a spread of states and starts gives the
+    header's new state and bytes.  (The kernels themselves are compared with the oracle on the GPU; this moves their arithmetic
+    from "equals the oracle, which equals the header's other form" to "equals the header".)"""
+    from screenpressor_amd import build as B
+    hm = C.CDLL(B.build_host_harness())
+    ref = C.CDLL(REF_SO)
+    ref.ref_enc_put_symbol.restype = C.c_uint32
+    hm.hm_rans_step.restype = C.c_uint32
+    rng = np.random.default_rng(7)
+    r5, h3 = (C.c_uint32 * 5)(), (C.c_uint32 * 3)()
+    rb, hb = (C.c_uint8 * 8)(), (C.c_uint8 * 8)()
+    rn, hn = C.c_int(), C.c_int()
+    edge_states = [1 << 23, (1 << 23) + 1, (1 << 31) - 1, (1 << 31) - 256, 1 << 30, (1 << 27) - 1, 1 << 27]
+    for freq in range(1, 4097):
+        hm.hm_rans_params(freq, h3)
+        for start in {0, 4096 - freq, int(rng.integers(0, 4096 - freq + 1))}:
+            ref.ref_enc_symbol_init(start, freq, r5)
+            x_max, rcp, bias, cmpl, shift = list(r5)
+            assert (x_max, rcp, shift, bias - start, cmpl) == ((freq << 19) & 0xFFFFFFFF, h3[0], h3[1], h3[2], 4096 - freq), (freq, start)
+            states = edge_states + [(freq << 19) - 1, freq << 19, min((freq << 27) - 1, (1 << 31) - 1), min(freq << 27, (1 << 31) - 1)] + rng.integers(1 << 23, 1 << 31, 6).tolist()
+            for x in states:
+                x = int(max(1 << 23, min(x, (1 << 31) - 1)))
+                a = ref.ref_enc_put_symbol(x, start, freq, rb, C.byref(rn))
+                b = hm.hm_rans_step(x, start, freq, hb, C.byref(hn))
+                assert (a, rn.value, bytes(rb[:rn.value])) == (b, hn.value, bytes(hb[:hn.value])), (freq, start, x)
+
+
 def test_survey_known_answers():
     """SURVEY.md §8c, observed on the compiled reference: an I-frame starts with
     three raw bytes of pixel 0 then N[0](1) = (16,16); a P-frame with one
