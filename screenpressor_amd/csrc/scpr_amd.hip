@@ -1352,10 +1352,10 @@ static int64_t compress_core(scpr_codec* c, const void* d_frames, int nframes, i
 #endif
           if (c->dbg_inject == 3) {  // (tests: one trip's records are not laid - a stale line, as the scalar unit would see it)
             c->dbg_inject = 0;
-            hipLaunchKernelGGL(k_rans_s<true>, dim3((nb + 3) / 4), dim3(256), lds, st, c->entries.as<u32>(), c->rblocks.as<RansBlock>(), c->rcp.as<RansRcp>(), c->rrec.as<rans_rec_t>(), nb,
+            hipLaunchKernelGGL(k_rans_s<true>, dim3((nb + 3) / 4), dim3(512), lds, st, c->entries.as<u32>(), c->rblocks.as<RansBlock>(), c->rcp.as<RansRcp>(), c->rrec.as<rans_rec_t>(), nb,
                                c->rscratch.as<u8>(), c->rsize.as<u32>(), c->err.as<u32>(), 9);
           } else {
-            hipLaunchKernelGGL(k_rans_s<false>, dim3((nb + 3) / 4), dim3(256), lds, st, c->entries.as<u32>(), c->rblocks.as<RansBlock>(), c->rcp.as<RansRcp>(), c->rrec.as<rans_rec_t>(), nb,
+            hipLaunchKernelGGL(k_rans_s<false>, dim3((nb + 3) / 4), dim3(512), lds, st, c->entries.as<u32>(), c->rblocks.as<RansBlock>(), c->rcp.as<RansRcp>(), c->rrec.as<rans_rec_t>(), nb,
                                c->rscratch.as<u8>(), c->rsize.as<u32>(), c->err.as<u32>(), -1);
           }
         } else {

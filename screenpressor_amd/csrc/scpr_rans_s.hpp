@@ -45,39 +45,6 @@ __device__ __forceinline__ uint2 rans_rcp_of(u32 v, const RansRcp* __restrict__ 
   const u32 fr = v & 0xFFFFu;
   return ((const uint2*)rcp_g)[fr - 1u < (u32)kProbScale ? fr : 1u];
 }
-#ifdef SCPR_RANS_REC8
-// experiment (tools/exp_rans.py): an 8-byte record { reciprocal, freq << 19 | bias << 5 | shift } - half the bytes
-// through the L2 and the scalar data cache, three more scalar instructions per entry to take the second word apart
-typedef uint2 rans_rec_t;
-__device__ __forceinline__ uint2 rans_record_s(u32 v, const uint2 r) {
-  const u32 fr = v & 0xFFFFu, cf = v >> 16;
-  const bool live = fr - 1u < (u32)kProbScale;
-  uint2 o;
-  o.x = live ? r.x : 0u;
-  o.y = live ? (fr << 19) | ((cf + (r.y >> 16)) << 5) | (r.y & 0xFFFFu) : 0xFFF80000u;  // bias <= 8190 < 2^14; no state reaches 0xFFF80000
-  return o;
-}
-#define SCPR_RS_ENT(RC, W, K)                                                                                                     \
-  "s_and_b32 s24, s" #W ", 0xfff80000\n\ts_cmp_ge_u32 %[x], s24\n\ts_cselect_b32 s20, 8, 0\n\tv_writelane_b32 %[vo], %[x], " #K "\n\t"   \
-  "s_lshr_b32 s21, %[x], s20\n\ts_cmp_ge_u32 s21, s24\n\ts_cselect_b32 s20, 8, 0\n\ts_lshr_b32 s25, s" #W ", 19\n\t"               \
-  "s_lshr_b32 s21, s21, s20\n\ts_mul_hi_u32 s22, s21, s" #RC "\n\ts_sub_u32 s25, 0x1000, s25\n\ts_lshr_b32 s22, s22, s" #W "\n\t"    \
-  "s_bfe_u32 s23, s" #W ", 0xe0005\n\ts_mul_i32 s22, s22, s25\n\ts_add_u32 s21, s21, s23\n\ts_add_u32 %[x], s22, s21\n\t"
-#define SCPR_RS_ENTF SCPR_RS_ENT
-#define SCPR_RS_SET_A(E, K0, K1, K2, K3, K4, K5, K6, K7) E(36, 37, K0) E(38, 39, K1) E(40, 41, K2) E(42, 43, K3) E(44, 45, K4) E(46, 47, K5) E(48, 49, K6) E(50, 51, K7)
-#define SCPR_RS_SET_B(E, K0, K1, K2, K3, K4, K5, K6, K7) E(52, 53, K0) E(54, 55, K1) E(56, 57, K2) E(58, 59, K3) E(60, 61, K4) E(62, 63, K5) E(64, 65, K6) E(66, 67, K7)
-#define SCPR_RS_LOAD_A(I) "s_waitcnt lgkmcnt(0)\n\ts_load_dwordx16 s[36:51], %[p], " SCPR_RS_OFF8(I) SCPR_RS_GLC "\n\t"
-#define SCPR_RS_LOAD_B(I) "s_waitcnt lgkmcnt(0)\n\ts_load_dwordx16 s[52:67], %[p], " SCPR_RS_OFF8(I) SCPR_RS_GLC "\n\t"
-#define SCPR_RS_OFF8(I) SCPR_RS_OFF8_##I
-#define SCPR_RS_OFF8_0 "0x0"
-#define SCPR_RS_OFF8_1 "0x40"
-#define SCPR_RS_OFF8_2 "0x80"
-#define SCPR_RS_OFF8_3 "0xc0"
-#define SCPR_RS_OFF8_4 "0x100"
-#define SCPR_RS_OFF8_5 "0x140"
-#define SCPR_RS_OFF8_6 "0x180"
-#define SCPR_RS_OFF8_7 "0x1c0"
-#define SCPR_RS_CLOBBERS "s20", "s21", "s22", "s23", "s24", "s25", "scc", "memory", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67"
-#else
 typedef uint4 rans_rec_t;
 __device__ __forceinline__ uint4 rans_record_s(u32 v, const uint2 r) {
   const u32 fr = v & 0xFFFFu, cf = v >> 16;
@@ -106,7 +73,8 @@ __device__ __forceinline__ uint4 rans_record_s(u32 v, const uint2 r) {
 #define SCPR_RS_SET_A(E, K0, K1, K2, K3, K4, K5, K6, K7) E(36, 37, 38, 39, K0) E(40, 41, 42, 43, K1) E(44, 45, 46, 47, K2) E(48, 49, 50, 51, K3) E(52, 53, 54, 55, K4) E(56, 57, 58, 59, K5) E(60, 61, 62, 63, K6) E(64, 65, 66, 67, K7)
 #define SCPR_RS_SET_B(E, K0, K1, K2, K3, K4, K5, K6, K7) E(68, 69, 70, 71, K0) E(72, 73, 74, 75, K1) E(76, 77, 78, 79, K2) E(80, 81, 82, 83, K3) E(84, 85, 86, 87, K4) E(88, 89, 90, 91, K5) E(92, 93, 94, 95, K6) E(96, 97, 98, 99, K7)
 #define SCPR_RS_LOAD_A(I) "s_waitcnt lgkmcnt(0)\n\ts_load_dwordx16 s[36:51], %[p], " SCPR_RS_OFF16A(I) SCPR_RS_GLC "\n\ts_load_dwordx16 s[52:67], %[p], " SCPR_RS_OFF16B(I) SCPR_RS_GLC "\n\t"
-#define SCPR_RS_LOAD_B(I) "s_waitcnt lgkmcnt(0)\n\ts_load_dwordx16 s[68:83], %[p], " SCPR_RS_OFF16A(I) SCPR_RS_GLC "\n\ts_load_dwordx16 s[84:99], %[p], " SCPR_RS_OFF16B(I) SCPR_RS_GLC "\n\t"
+#define SCPR_RS_LOAD_B_NOWAIT(I) "s_load_dwordx16 s[68:83], %[p], " SCPR_RS_OFF16A(I) SCPR_RS_GLC "\n\ts_load_dwordx16 s[84:99], %[p], " SCPR_RS_OFF16B(I) SCPR_RS_GLC "\n\t"
+#define SCPR_RS_LOAD_B(I) "s_waitcnt lgkmcnt(0)\n\t" SCPR_RS_LOAD_B_NOWAIT(I)
 #define SCPR_RS_OFF16A(I) SCPR_RS_OFF16A_##I
 #define SCPR_RS_OFF16B(I) SCPR_RS_OFF16B_##I
 #define SCPR_RS_OFF16A_0 "0x0"
@@ -125,8 +93,9 @@ __device__ __forceinline__ uint4 rans_record_s(u32 v, const uint2 r) {
 #define SCPR_RS_OFF16B_6 "0x340"
 #define SCPR_RS_OFF16A_7 "0x380"
 #define SCPR_RS_OFF16B_7 "0x3c0"
-#define SCPR_RS_CLOBBERS "s20", "s21", "s22", "s23", "scc", "memory", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99"
-#endif
+// (s[36:67], the A set, is not in this list: it is an operand pinned to those registers - it carries the first eight records of
+// the NEXT trip over the loop's back edge, see the kernel)
+#define SCPR_RS_CLOBBERS "s20", "s21", "s22", "s23", "scc", "memory", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99"
 // how the scalar loads get past a lap-old line of the scalar data cache: s_dcache_inv in front of the trip's loads, or
 // (SCPR_RANS_GLC, experiment) the loads' own GLC bit
 #ifdef SCPR_RANS_GLC
@@ -136,6 +105,11 @@ __device__ __forceinline__ uint4 rans_record_s(u32 v, const uint2 r) {
 #define SCPR_RS_GLC ""
 #define SCPR_RS_INV "s_dcache_inv\n\t"
 #endif
+
+// the first eight records of the next trip (slot at %[pn]), asked for while this trip's last eight steps are taken: a trip then
+// starts on records that have arrived instead of waiting a scalar-load round trip (~10 % of a trip) for them
+#define SCPR_RS_LOAD_NEXT SCPR_RS_INV "s_load_dwordx16 s[36:51], %[pn], 0x0" SCPR_RS_GLC "\n\ts_load_dwordx16 s[52:67], %[pn], 0x40" SCPR_RS_GLC "\n\t"
+typedef u32 rans_sgpr16 __attribute__((ext_vector_type(16)));
 
 // a set of eight entries: the short step unless the trip's mask has a bit of the set (the long form sits behind the trip)
 #ifdef SCPR_RANS_NOFAST  // (A/B timing: every set takes the whole step)
@@ -147,79 +121,123 @@ __device__ __forceinline__ uint4 rans_record_s(u32 v, const uint2 r) {
 #define SCPR_RS_SLOW(S, SET) ".Lrs_slow" #S "_%=:\n\t" SET "s_branch .Lrs_join" #S "_%=\n\t"
 
 // one wave per block, four per workgroup.  rec: the records' rings (RANS_S_RING * RANS_S_TRIP records per block); everything else as k_rans.
+// Four blocks per workgroup, TWO waves per block.  Waves 0-3 are the chains (one per SIMD of the CU): entries in, records out,
+// the 64 scalar steps of a trip, and the states before the steps dropped into LDS.  Waves 4-7 are their writers, a trip behind:
+// they turn the states into bytes (0, 1 or 2 per step, or the raw byte), store them, and take every step again from the entry
+// itself (the check below).  Round 5: with everything in one wave the ~100 vector instructions of a trip's tail sat in the
+// chain's own in-order instruction stream (3.44 ms for a full block alone on its SIMD, 5.42 with two blocks per SIMD); in a
+// second wave they issue beside the chain's scalar instructions.  The two meet at ONE workgroup barrier per trip (a wave that
+// waits at a barrier issues nothing, unlike one that polls), so the four chains of a workgroup run their trips in step and all
+// eight waves run the trips of the workgroup's longest block - a shorter block's surplus trips are padding, which leaves the
+// state alone and emits nothing.
 template <bool POISON>  // POISON: the tests' instance (scpr_debug_inject 3), which leaves the records of trip `poison_trip` unlaid
-__global__ __launch_bounds__(256) void k_rans_s(const u32* __restrict__ entries, const RansBlock* __restrict__ blocks, const RansRcp* __restrict__ rcp_g, rans_rec_t* __restrict__ rec,
+__global__ __launch_bounds__(512) void k_rans_s(const u32* __restrict__ entries, const RansBlock* __restrict__ blocks, const RansRcp* __restrict__ rcp_g, rans_rec_t* __restrict__ rec,
                                                int nblocks, u8* __restrict__ scratch, u32* __restrict__ blksize, u32* __restrict__ err, int poison_trip) {
-  // four blocks per workgroup: its waves go to the four SIMDs of a CU, and two such waves on ONE SIMD would take turns at the
-  // scalar unit (tools/exp_rans.py: 3.7 ms with one wave per SIMD, 6.3 with two, 9.0 with three - whatever the number of blocks)
-  const int b = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6))), lane = threadIdx.x & 63;
-  if (b >= nblocks) return;
-  if (*err & 32u) {  // (see k_rans)
-    if (lane == 0) blksize[b] = 0;
-    return;
-  }
-  const RansBlock blk = blocks[b];
-  const int len = (int)blk.len, trips = (len + RANS_S_TRIP - 1) / RANS_S_TRIP;
+  __shared__ u32 s_state[4][2][RANS_S_TRIP];  // chain -> writer: the state before each step of a trip, two trips
+  __shared__ u32 s_after[4][2];               //                  and after its last step
+  __shared__ int s_trips[4];
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), cw = wv & 3, lane = threadIdx.x & 63;
+  const bool writer = wv >= 4;
+  const int b = (int)blockIdx.x * 4 + cw;
+  const bool none = b >= nblocks || (*err & 32u) != 0;  // (bit 5: see k_rans - nothing to code, the block is given the size 0)
+  RansBlock blk{0, 0};
+  if (!none) blk = blocks[b];
+  const int len = (int)blk.len;
+  if (!writer && lane == 0) s_trips[cw] = (len + RANS_S_TRIP - 1) / RANS_S_TRIP;
+  __syncthreads();
+  const int trips = max(max(s_trips[0], s_trips[1]), max(s_trips[2], s_trips[3]));
   const u32* e = entries + blk.begin;
-  rans_rec_t* const r0 = rec + (size_t)b * (RANS_S_RING * RANS_S_TRIP);
-  auto slot = [&](int t) { return r0 + (size_t)(t & (RANS_S_RING - 1)) * RANS_S_TRIP; };
-  u8* const base = scratch + (size_t)b * RANS_SCRATCH;
   // entry of trip t in this lane, in coding order (last entry first); past the block's first entry: padding
   auto entry_of = [&](int t) -> u32 {
     const int i = len - 1 - (t * RANS_S_TRIP + lane);
     return i >= 0 ? e[i] : 0xFFFFFFFFu;
   };
-  // the records of trips 0 and 1 before anything is coded; from then on trip t lays the records of trip t + 2 (their
-  // reciprocals were asked for during trip t - 1, their entries during trip t - 2) while it runs
-  u32 ev0 = entry_of(0), ev1 = entry_of(1), ev2 = entry_of(2), ev3 = entry_of(3);
-  uint2 rc0 = rans_rcp_of(ev0, rcp_g), rc1 = rans_rcp_of(ev1, rcp_g);
-  slot(0)[lane] = rans_record_s(ev0, rc0);
-  slot(1)[lane] = rans_record_s(ev1, rc1);
-  uint2 rc2 = rans_rcp_of(ev2, rcp_g);
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(ev2), "+v"(ev3), "+v"(rc2.x), "+v"(rc2.y) : : "memory");  // (nothing is on its way when the loop is entered: see the wait inside it)
-  u32 x = kRansL, off = RANS_SCRATCH;
-  u64 wrong = 0;
-  for (int t = 0; t < trips; t++) {
-    // (read last by trip t + 2 - RANS_S_RING.  poison_trip, tests only: the records of one trip are NOT laid - the scalar unit
-    // then reads what the ring held a lap before, which is what a stale line of the scalar data cache would hand it)
-    if (!POISON || t + 2 != poison_trip) slot(t + 2)[lane] = rans_record_s(ev2, rc2);
-    uint2 rc3 = rans_rcp_of(ev3, rcp_g);
-    u32 ev4 = entry_of(t + 4);
-    u32 vout = 0;
-    const rans_rec_t* p = slot(t);
-    // which sets of eight hold an entry whose freq is below 16 (the only ones a second byte can come from)
-    const u32 fr0 = ev0 & 0xFFFFu;
-    const u64 two = __ballot(fr0 - 1u < 15u);
-    const u32 mlo = (u32)two, mhi = (u32)(two >> 32);
+  if (!writer) {
+    rans_rec_t* const r0 = rec + (size_t)(none ? 0 : b) * (RANS_S_RING * RANS_S_TRIP);
+    auto slot = [&](int t) { return r0 + (size_t)(t & (RANS_S_RING - 1)) * RANS_S_TRIP; };
+    // the records of trips 0 and 1 before anything is coded; from then on trip t lays the records of trip t + 2 (their
+    // reciprocals were asked for during trip t - 1, their entries during trip t - 2) while it runs
+    u32 ev0 = entry_of(0), ev1 = entry_of(1), ev2 = entry_of(2), ev3 = entry_of(3);
+    if (!none) {
+      slot(0)[lane] = rans_record_s(ev0, rans_rcp_of(ev0, rcp_g));
+      slot(1)[lane] = rans_record_s(ev1, rans_rcp_of(ev1, rcp_g));
+    }
+    uint2 rc2 = rans_rcp_of(ev2, rcp_g);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(ev2), "+v"(ev3), "+v"(rc2.x), "+v"(rc2.y) : : "memory");  // (nothing is on its way when the loop is entered: see the wait inside it)
+    u32 x = kRansL;
+    rans_sgpr16 alo, ahi;  // s[36:51], s[52:67]: the A set of the trip's scalar code, alive from one trip to the next
+    {
+      const rans_rec_t* pn = slot(0);
+      if (!none) asm volatile(SCPR_RS_LOAD_NEXT : "={s[36:51]}"(alo), "={s[52:67]}"(ahi) : [pn] "s"(pn) : "memory");
+    }
+    for (int t = 0; t < trips; t++) {
+      // (read last by trip t + 2 - RANS_S_RING.  poison_trip, tests only: the records of one trip are NOT laid - the scalar unit
+      // then reads what the ring held a lap before, which is what a stale line of the scalar data cache would hand it)
+      if (!none && (!POISON || t + 2 != poison_trip)) slot(t + 2)[lane] = rans_record_s(ev2, rc2);
+      uint2 rc3 = rans_rcp_of(ev3, rcp_g);
+      u32 ev4 = entry_of(t + 4);
+      u32 vout = 0;
+      const rans_rec_t* p = slot(t);
+      const rans_rec_t* pn = slot(t + 1);
+      // which sets of eight hold an entry whose freq is below 16 (the only ones a second byte can come from)
+      const u64 two = __ballot((ev0 & 0xFFFFu) - 1u < 15u);
+      const u32 mlo = (u32)two, mhi = (u32)(two >> 32);
 #ifdef SCPR_RANS_NOFAST
 #define SCPR_RS_E SCPR_RS_ENT
 #else
 #define SCPR_RS_E SCPR_RS_ENTF
 #endif
-    asm volatile(SCPR_RS_INV SCPR_RS_LOAD_A(0)
-                 SCPR_RS_LOAD_B(1) SCPR_RS_TRY(mlo, 0xff, 0) SCPR_RS_SET_A(SCPR_RS_E, 0, 1, 2, 3, 4, 5, 6, 7) SCPR_RS_JOIN(0)
-                 SCPR_RS_LOAD_A(2) SCPR_RS_TRY(mlo, 0xff00, 1) SCPR_RS_SET_B(SCPR_RS_E, 8, 9, 10, 11, 12, 13, 14, 15) SCPR_RS_JOIN(1)
-                 SCPR_RS_LOAD_B(3) SCPR_RS_TRY(mlo, 0xff0000, 2) SCPR_RS_SET_A(SCPR_RS_E, 16, 17, 18, 19, 20, 21, 22, 23) SCPR_RS_JOIN(2)
-                 SCPR_RS_LOAD_A(4) SCPR_RS_TRY(mlo, 0xff000000, 3) SCPR_RS_SET_B(SCPR_RS_E, 24, 25, 26, 27, 28, 29, 30, 31) SCPR_RS_JOIN(3)
-                 SCPR_RS_LOAD_B(5) SCPR_RS_TRY(mhi, 0xff, 4) SCPR_RS_SET_A(SCPR_RS_E, 32, 33, 34, 35, 36, 37, 38, 39) SCPR_RS_JOIN(4)
-                 SCPR_RS_LOAD_A(6) SCPR_RS_TRY(mhi, 0xff00, 5) SCPR_RS_SET_B(SCPR_RS_E, 40, 41, 42, 43, 44, 45, 46, 47) SCPR_RS_JOIN(5)
-                 SCPR_RS_LOAD_B(7) SCPR_RS_TRY(mhi, 0xff0000, 6) SCPR_RS_SET_A(SCPR_RS_E, 48, 49, 50, 51, 52, 53, 54, 55) SCPR_RS_JOIN(6)
-                 "s_waitcnt lgkmcnt(0)\n\t" SCPR_RS_TRY(mhi, 0xff000000, 7) SCPR_RS_SET_B(SCPR_RS_E, 56, 57, 58, 59, 60, 61, 62, 63) SCPR_RS_JOIN(7)
+      if (none) __syncthreads();  // (a wave without a block keeps the barriers' company and nothing else: its ring was never laid)
+      else
+      // The trip begins with the wait every trip needs anyway - for its first records, asked for a trip ago - and that wait also
+      // covers the LDS stores that handed the previous trip to the writer: the workgroup's barrier sits right behind it, inside
+      // the scalar code.  (__syncthreads() after those stores would wait for the scalar loads just issued as well: LDS and
+      // scalar memory share one counter.)
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier\n\t" SCPR_RS_LOAD_B_NOWAIT(1) SCPR_RS_TRY(mlo, 0xff, 0) SCPR_RS_SET_A(SCPR_RS_E, 0, 1, 2, 3, 4, 5, 6, 7) SCPR_RS_JOIN(0)
+                   SCPR_RS_LOAD_A(2) SCPR_RS_TRY(mlo, 0xff00, 1) SCPR_RS_SET_B(SCPR_RS_E, 8, 9, 10, 11, 12, 13, 14, 15) SCPR_RS_JOIN(1)
+                   SCPR_RS_LOAD_B(3) SCPR_RS_TRY(mlo, 0xff0000, 2) SCPR_RS_SET_A(SCPR_RS_E, 16, 17, 18, 19, 20, 21, 22, 23) SCPR_RS_JOIN(2)
+                   SCPR_RS_LOAD_A(4) SCPR_RS_TRY(mlo, 0xff000000, 3) SCPR_RS_SET_B(SCPR_RS_E, 24, 25, 26, 27, 28, 29, 30, 31) SCPR_RS_JOIN(3)
+                   SCPR_RS_LOAD_B(5) SCPR_RS_TRY(mhi, 0xff, 4) SCPR_RS_SET_A(SCPR_RS_E, 32, 33, 34, 35, 36, 37, 38, 39) SCPR_RS_JOIN(4)
+                   SCPR_RS_LOAD_A(6) SCPR_RS_TRY(mhi, 0xff00, 5) SCPR_RS_SET_B(SCPR_RS_E, 40, 41, 42, 43, 44, 45, 46, 47) SCPR_RS_JOIN(5)
+                   SCPR_RS_LOAD_B(7) SCPR_RS_TRY(mhi, 0xff0000, 6) SCPR_RS_SET_A(SCPR_RS_E, 48, 49, 50, 51, 52, 53, 54, 55) SCPR_RS_JOIN(6)
+                   "s_waitcnt lgkmcnt(0)\n\t" SCPR_RS_LOAD_NEXT SCPR_RS_TRY(mhi, 0xff000000, 7) SCPR_RS_SET_B(SCPR_RS_E, 56, 57, 58, 59, 60, 61, 62, 63) SCPR_RS_JOIN(7)
 #ifndef SCPR_RANS_NOFAST
-                 "s_branch .Lrs_end_%=\n\t"
-                 SCPR_RS_SLOW(0, SCPR_RS_SET_A(SCPR_RS_ENT, 0, 1, 2, 3, 4, 5, 6, 7)) SCPR_RS_SLOW(1, SCPR_RS_SET_B(SCPR_RS_ENT, 8, 9, 10, 11, 12, 13, 14, 15))
-                 SCPR_RS_SLOW(2, SCPR_RS_SET_A(SCPR_RS_ENT, 16, 17, 18, 19, 20, 21, 22, 23)) SCPR_RS_SLOW(3, SCPR_RS_SET_B(SCPR_RS_ENT, 24, 25, 26, 27, 28, 29, 30, 31))
-                 SCPR_RS_SLOW(4, SCPR_RS_SET_A(SCPR_RS_ENT, 32, 33, 34, 35, 36, 37, 38, 39)) SCPR_RS_SLOW(5, SCPR_RS_SET_B(SCPR_RS_ENT, 40, 41, 42, 43, 44, 45, 46, 47))
-                 SCPR_RS_SLOW(6, SCPR_RS_SET_A(SCPR_RS_ENT, 48, 49, 50, 51, 52, 53, 54, 55)) SCPR_RS_SLOW(7, SCPR_RS_SET_B(SCPR_RS_ENT, 56, 57, 58, 59, 60, 61, 62, 63))
-                 ".Lrs_end_%=:\n\t"
+                   "s_branch .Lrs_end_%=\n\t"
+                   SCPR_RS_SLOW(0, SCPR_RS_SET_A(SCPR_RS_ENT, 0, 1, 2, 3, 4, 5, 6, 7)) SCPR_RS_SLOW(1, SCPR_RS_SET_B(SCPR_RS_ENT, 8, 9, 10, 11, 12, 13, 14, 15))
+                   SCPR_RS_SLOW(2, SCPR_RS_SET_A(SCPR_RS_ENT, 16, 17, 18, 19, 20, 21, 22, 23)) SCPR_RS_SLOW(3, SCPR_RS_SET_B(SCPR_RS_ENT, 24, 25, 26, 27, 28, 29, 30, 31))
+                   SCPR_RS_SLOW(4, SCPR_RS_SET_A(SCPR_RS_ENT, 32, 33, 34, 35, 36, 37, 38, 39)) SCPR_RS_SLOW(5, SCPR_RS_SET_B(SCPR_RS_ENT, 40, 41, 42, 43, 44, 45, 46, 47))
+                   SCPR_RS_SLOW(6, SCPR_RS_SET_A(SCPR_RS_ENT, 48, 49, 50, 51, 52, 53, 54, 55)) SCPR_RS_SLOW(7, SCPR_RS_SET_B(SCPR_RS_ENT, 56, 57, 58, 59, 60, 61, 62, 63))
+                   ".Lrs_end_%=:\n\t"
 #endif
-                 : [x] "+s"(x), [vo] "+v"(vout) : [p] "s"(p), [mlo] "s"(mlo), [mhi] "s"(mhi) : SCPR_RS_CLOBBERS);
-    // this trip's stores and loads were issued 64 steps ago: the records are in the L2 before a scalar load asks for them, and the
-    // compiler's own wait for the loaded values lands HERE - not behind the byte stores below, whose way to memory it would pay
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(ev4), "+v"(rc3.x), "+v"(rc3.y) : : "memory");
+                   : [x] "+s"(x), [vo] "+v"(vout), "+{s[36:51]}"(alo), "+{s[52:67]}"(ahi) : [p] "s"(p), [pn] "s"(pn), [mlo] "s"(mlo), [mhi] "s"(mhi) : SCPR_RS_CLOBBERS);
+      // this trip's stores and loads were issued 64 steps ago: the records are in the L2 before a scalar load asks for them, and the
+      // compiler's own wait for the loaded values lands HERE, where everything has long arrived
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(ev4), "+v"(rc3.x), "+v"(rc3.y) : : "memory");
+      // trip t is the writer's at the NEXT barrier (the start of trip t + 1, or the one behind the loop); this half of the buffers is
+      // written again at the end of trip t + 2, behind the barrier after that, which the writer reaches when it is done with trip t
+      s_state[cw][t & 1][lane] = vout;
+      if (lane == 0) s_after[cw][t & 1] = x;
+      ev0 = ev1, ev1 = ev2, ev2 = ev3, ev3 = ev4, rc2 = rc3;
+    }
+    __syncthreads();
+    return;
+  }
+  // ---- the writer ----
+  u8* const base = scratch + (size_t)(none ? 0 : b) * RANS_SCRATCH;
+  u32 ev0 = entry_of(0);
+  uint2 rc0 = rans_rcp_of(ev0, rcp_g);
+  u32 off = RANS_SCRATCH, x = kRansL;
+  u64 wrong = 0;
+  __syncthreads();  // (the barrier at the start of the chains' trip 0: nothing to take over yet)
+  for (int t = 0; t < trips; t++) {
+    const u32 ev1 = entry_of(t + 1);  // (on their way while this trip is waited for and written)
+    const uint2 rc1 = rans_rcp_of(ev1, rcp_g);
+    __syncthreads();
+    const u32 vout = s_state[cw][t & 1][lane];
+    x = s_after[cw][t & 1];
     // what the 64 steps emitted: the renormalisation's bytes (the low bytes of the state before the step, first byte at the
     // higher address: the block is written from its end), or the raw byte itself
-    const u32 fr = fr0, xm = fr << 19;
+    const u32 fr = ev0 & 0xFFFFu, xm = fr << 19;
     const bool live = fr - 1u < (u32)kProbScale, raw = fr == 0u;
     const int n = live ? (int)(vout >= xm) + (int)((vout >> 8) >= xm) : (raw ? 1 : 0);
     const u32 b0 = raw ? (ev0 >> 16) & 255u : vout & 255u, b1 = (vout >> 8) & 255u;
@@ -230,9 +248,9 @@ __global__ __launch_bounds__(256) void k_rans_s(const u32* __restrict__ entries,
     off -= rdl((u32)incl, 63);
     // The hand-over is CHECKED, not trusted: every lane takes its entry's step again, from the entry itself and the state the
     // scalar unit started that step from, and must arrive at the state the next step started from (lane 63: the state the
-    // trip ended with).  A record that did not reach the scalar unit as it was laid (scpr_rans_s.hpp's two measured, unspecified
-    // properties of the memory system) shows here unless it changes nothing; the host then codes the call's blocks again with
-    // k_rans (scpr_amd.hip).  ~25 vector instructions per trip, none on the scalar chain.
+    // trip ended with).  A record that did not reach the scalar unit as it was laid (the two measured, unspecified properties
+    // of the memory system at the top of this file) shows here unless it changes nothing; the host then codes the call's blocks
+    // again with k_rans (scpr_amd.hip).
 #ifndef SCPR_RANS_NOCHECK  // (A/B timing only)
     {
       const u32 xr = live ? vout >> (8 * n) : vout;
@@ -242,7 +260,11 @@ __global__ __launch_bounds__(256) void k_rans_s(const u32* __restrict__ entries,
       wrong |= __ballot(want != next);
     }
 #endif
-    ev0 = ev1, ev1 = ev2, ev2 = ev3, ev3 = ev4, rc0 = rc1, rc1 = rc2, rc2 = rc3;
+    ev0 = ev1, rc0 = rc1;
+  }
+  if (none) {
+    if (b < nblocks && lane == 0) blksize[b] = 0;
+    return;
   }
   if (wrong && lane == 0) atomicOr(err, 64u);
   if (lane == 0) {  // RansEncFlush, rans_byte.h:90-102

@@ -111,8 +111,11 @@ def test_keys_out_of_order_end_the_call_with_an_error_and_the_codec_refuses_unti
     dev = torch.from_numpy(frames).cuda().reshape(n, -1)
     enc = _codec(w, h)
     enc.debug_inject(2)
+    # (room for the closed-form worst case, ~10 bytes per pixel: the call keeps no copy of the state it could be taken back to -
+    # the next test is the one with such a copy)
+    roomy = torch.empty(n * (w * h * 11 + 4096), dtype=torch.uint8, device="cuda")
     with pytest.raises(RuntimeError, match="scpr error -1"):
-        enc.CompressBatch(dev, [0] * n)
+        enc.CompressBatch(dev, [0] * n, out=roomy)
     pk, sizes, fts = enc.CompressBatch(dev, [1] * n)  # P-frames on top of the failed call: refused, nothing written
     assert int(np.sum(sizes)) == 0 and len(pk) == 0
     got, ft = enc.CompressFrame(frames[0], 1)
