@@ -757,6 +757,54 @@ static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int n
     fprintf(stderr, "[scpr debug] chunk n=%d ngens=%d ni=%d np=%d Ctot=%zu bad keys=%zu first=%zu key=%08x\n", n, ngens, ni, np, (size_t)Ctot, bad, first, bad ? hk[first] : 0u);
     if (bad) return SCPR_E_DEVICE;
   }
+  // per-generation ranges of the run list and of the misc list (frames of a generation are consecutive)
+  std::vector<GenRange>& rg = c->h_ranges;
+  std::vector<MiscRange>& mr = c->h_miscranges;
+  rg.assign(ngens, GenRange{0, 0});
+  mr.assign(ngens, MiscRange{0, 0});
+  {
+    std::vector<bool> seen(ngens, false);
+    for (int i = 0; i < n; i++) {
+      const int gq = cf[i].gen;
+      if (gq < 0 || cf[i].kind == 1) continue;
+      if (!seen[gq]) {
+        rg[gq].run_begin = hb[i].run_base;
+        mr[gq].begin = hb[i].misc_base;
+        seen[gq] = true;
+      }
+      rg[gq].run_end = hb[i].run_base + hb[i].nruns;
+      mr[gq].end = hb[i].misc_base + hb[i].nmisc;
+    }
+  }
+  HIPCHK(h2d(c, c->ranges.p, rg.data(), ngens * sizeof(GenRange), st));
+  HIPCHK(h2d(c, c->miscranges.p, mr.data(), ngens * sizeof(MiscRange), st));
+  // The fixed-model chains (run lengths, pixel types, P-frame symbols) and the colour chains read the same lists
+  // and write disjoint coder entries: they run side by side on two streams and join before the coder.  The fork is in front of
+  // the colour symbols' partition since round 5 (the fixed models need the run list only): beside rocPRIM's radix sort the fork
+  // had cost more than it gave (rounds 2 and 3: the sort took twice as long, 3.7 -> 7.2 ms at 4K); the repo's own partition is a
+  // third of that traffic, and the fixed branch was the longer one by 1.4 ms (kernel trace of the headline, profiles/r5b).
+  const int buf_in = c->live_buf, buf_out = ngens > 1 ? 1 - c->live_buf : c->live_buf;
+  {
+    hipStream_t s2 = getenv("SCPR_SERIAL_CHAINS") ? st : c->stream2;  // (design aid: the two chain stages one after the other, to time each alone)
+    HIPCHK(hipEventRecord(c->ev_fork, st));
+    HIPCHK(hipStreamWaitEvent(s2, c->ev_fork, 0));
+    stage_begin(c, ST_FIXED, s2);
+    // the run list, then the list of P-frame symbols: partitioned by model (scpr_fixed.hpp), one wave per (generation, model)
+    {
+      int rc = fixed_chains<RunItems, 256>(c, s2, c->fixr, c->runs.as<u32>(), c->runpos.as<u32>(), Rtot, (const uint2*)c->ranges.p, ngens, load_first,
+                                           c->fixed_persist.as<FixedPersist>() + buf_in * 12, c->fixed_persist.as<FixedPersist>() + buf_out * 12);
+      if (rc != SCPR_OK) return rc;
+      if (Mtot) {
+        rc = fixed_chains<MiscItems, 512>(c, s2, c->fixm, c->misc.as<u32>(), c->miscpos.as<u32>(), Mtot, (const uint2*)c->miscranges.p, ngens, load_first,
+                                          c->misc_persist.as<FixedPersist>() + buf_in * MC_COUNT, c->misc_persist.as<FixedPersist>() + buf_out * MC_COUNT);
+        if (rc != SCPR_OK) return rc;
+      } else if (!(load_first && ngens == 1)) {  // a new generation without any P-frame symbol: its P-frame models are the renewed ones, not the kept ones
+        HIPCHK(hipMemsetAsync(c->misc_persist.as<FixedPersist>() + buf_out * MC_COUNT, 0, MC_COUNT * sizeof(FixedPersist), s2));
+      }
+    }
+    stage_end(c, ST_FIXED, s2);
+    HIPCHK(hipEventRecord(c->ev_join, s2));
+  }
   stage_begin(c, ST_SORT);
   {
     // stable partition of every (generation, plane) segment by its 12 context bits: two counting passes of six bits, least
@@ -809,53 +857,6 @@ static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int n
     if (unsorted || badc) return SCPR_E_DEVICE;
   }
 
-  // per-generation ranges of the run list and of the misc list (frames of a generation are consecutive)
-  std::vector<GenRange>& rg = c->h_ranges;
-  std::vector<MiscRange>& mr = c->h_miscranges;
-  rg.assign(ngens, GenRange{0, 0});
-  mr.assign(ngens, MiscRange{0, 0});
-  {
-    std::vector<bool> seen(ngens, false);
-    for (int i = 0; i < n; i++) {
-      const int gq = cf[i].gen;
-      if (gq < 0 || cf[i].kind == 1) continue;
-      if (!seen[gq]) {
-        rg[gq].run_begin = hb[i].run_base;
-        mr[gq].begin = hb[i].misc_base;
-        seen[gq] = true;
-      }
-      rg[gq].run_end = hb[i].run_base + hb[i].nruns;
-      mr[gq].end = hb[i].misc_base + hb[i].nmisc;
-    }
-  }
-  HIPCHK(h2d(c, c->ranges.p, rg.data(), ngens * sizeof(GenRange), st));
-  HIPCHK(h2d(c, c->miscranges.p, mr.data(), ngens * sizeof(MiscRange), st));
-  // The fixed-model chains (run lengths, pixel types, P-frame symbols) and the colour chains read the same lists
-  // and write disjoint coder entries: they run side by side on two streams and join before the coder.  (Forking before the sort -
-  // the fixed models need the run list only - was tried again with round 3's partition kernels: the sort beside them still takes
-  // twice as long, 3.7 -> 7.2 ms at 4K, and the encode gains nothing.)
-  const int buf_in = c->live_buf, buf_out = ngens > 1 ? 1 - c->live_buf : c->live_buf;
-  {
-    hipStream_t s2 = getenv("SCPR_SERIAL_CHAINS") ? st : c->stream2;  // (design aid: the two chain stages one after the other, to time each alone)
-    HIPCHK(hipEventRecord(c->ev_fork, st));
-    HIPCHK(hipStreamWaitEvent(s2, c->ev_fork, 0));
-    stage_begin(c, ST_FIXED, s2);
-    // the run list, then the list of P-frame symbols: partitioned by model (scpr_fixed.hpp), one wave per (generation, model)
-    {
-      int rc = fixed_chains<RunItems, 256>(c, s2, c->fixr, c->runs.as<u32>(), c->runpos.as<u32>(), Rtot, (const uint2*)c->ranges.p, ngens, load_first,
-                                           c->fixed_persist.as<FixedPersist>() + buf_in * 12, c->fixed_persist.as<FixedPersist>() + buf_out * 12);
-      if (rc != SCPR_OK) return rc;
-      if (Mtot) {
-        rc = fixed_chains<MiscItems, 512>(c, s2, c->fixm, c->misc.as<u32>(), c->miscpos.as<u32>(), Mtot, (const uint2*)c->miscranges.p, ngens, load_first,
-                                          c->misc_persist.as<FixedPersist>() + buf_in * MC_COUNT, c->misc_persist.as<FixedPersist>() + buf_out * MC_COUNT);
-        if (rc != SCPR_OK) return rc;
-      } else if (!(load_first && ngens == 1)) {  // a new generation without any P-frame symbol: its P-frame models are the renewed ones, not the kept ones
-        HIPCHK(hipMemsetAsync(c->misc_persist.as<FixedPersist>() + buf_out * MC_COUNT, 0, MC_COUNT * sizeof(FixedPersist), s2));
-      }
-    }
-    stage_end(c, ST_FIXED, s2);
-    HIPCHK(hipEventRecord(c->ev_join, s2));
-  }
   stage_begin(c, ST_COLOUR);
   {
     Arena ar{c->arena.as<DenseTab>(), c->arena_top.as<u32>(), (u32)arena_cap - 1u, c->err.as<u32>()};  // (the last table allocated is the sink)

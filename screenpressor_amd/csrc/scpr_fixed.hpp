@@ -112,30 +112,33 @@ __global__ __launch_bounds__(256) void k_part_count(const u32* __restrict__ el, 
 // blkoff[c][b] = items of model c before block b (b = nblk: the model's total, also written to ctotal[c])
 constexpr int SCAN_T = 1024;
 __global__ __launch_bounds__(SCAN_T) void k_part_scan(const u32* __restrict__ blkcnt, u32* __restrict__ blkoff, u32 nblk, u32* __restrict__ ctotal) {
-  __shared__ u32 part[SCAN_T];
-  const int c = blockIdx.x, t = threadIdx.x;
+  // tiles of SCAN_T counts, read and written side by side (round 5: a thread used to walk its own run of ~32 counts, 128 bytes
+  // apart from its neighbour's - 0.46 ms for the headline's 33 000 blocks per model, on the longer of the encoder's two branches)
+  __shared__ u32 wtot[SCAN_T / 64];
+  const int c = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
   const u32* in = blkcnt + (size_t)c * (nblk + 1);
   u32* out = blkoff + (size_t)c * (nblk + 1);
-  const u32 per = (nblk + SCAN_T - 1) / SCAN_T, a = min(nblk, t * per), b = min(nblk, a + per);
-  u32 s = 0;
-  for (u32 i = a; i < b; i++) s += in[i];
-  part[t] = s;
-  __syncthreads();
-  for (int d = 1; d < SCAN_T; d <<= 1) {
-    const u32 v = t >= d ? part[t - d] : 0;
+  u32 carry = 0;
+  for (u32 base = 0; base < nblk; base += SCAN_T) {
+    const u32 i = base + (u32)t;
+    const u32 v = i < nblk ? in[i] : 0u;
+    const u32 incl = (u32)wave_incl_scan((int)v);
+    if (lane == 63) wtot[w] = incl;
     __syncthreads();
-    part[t] += v;
+    u32 before = 0, all = 0;
+#pragma unroll
+    for (int q = 0; q < SCAN_T / 64; q++) {
+      const u32 x = wtot[q];
+      before += q < w ? x : 0u;
+      all += x;
+    }
+    if (i < nblk) out[i] = carry + before + incl - v;
+    carry += all;
     __syncthreads();
   }
-  u32 run = part[t] - s;
-  for (u32 i = a; i < b; i++) {
-    const u32 v = in[i];
-    out[i] = run;
-    run += v;
-  }
-  if (t == SCAN_T - 1) {
-    out[nblk] = part[SCAN_T - 1];
-    ctotal[c] = part[SCAN_T - 1];
+  if (t == 0) {
+    out[nblk] = carry;
+    ctotal[c] = carry;
   }
 }
 
