@@ -17,7 +17,9 @@ Workloads (config.workload names the one measured):
         contiguous GOP range per rank (screenpressor_amd.sharding.shard_gops), strong scaling.
 With N = 1 and no --no-others the line also carries config.others: configs[2] (K = 50 and one 300-frame GOP),
 configs[3]'s one-GPU share (4K x 150, as key frames and as one GOP) and configs[4], each with encode / decode /
-combined MPix/s, compressed bytes, sha256 of the stream, a bounded CPU sample and the parity flag against it.
+combined MPix/s, compressed bytes, sha256 of the stream, a bounded CPU sample and the parity flag against it; and
+(unless --no-n8) the work of an N = 8 headline run - the eight 300-frame streams of seeds 1..8 - timed on this one
+GPU: the same-stream denominator for the driver's N = 8 line (n8_same_stream_entry).
 
 Launching: `--gpus N` with N > 1 and no WORLD_SIZE in the environment makes THIS process a launcher: it starts N
 ranks (one process per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set) before anything touches the GPU and

@@ -782,7 +782,10 @@ static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int n
   // and write disjoint coder entries: they run side by side on two streams and join before the coder.  The fork is in front of
   // the colour symbols' partition since round 5 (the fixed models need the run list only): beside rocPRIM's radix sort the fork
   // had cost more than it gave (rounds 2 and 3: the sort took twice as long, 3.7 -> 7.2 ms at 4K); the repo's own partition is a
-  // third of that traffic, and the fixed branch was the longer one by 1.4 ms (kernel trace of the headline, profiles/r5b).
+  // third of that traffic, and the fixed branch was the longer one by 1.4 ms (kernel trace of the headline).  1080p encode
+  // 18.0 -> 17.25 ms; with only the chains forked and the run list's partition in front of the colour one on the main stream:
+  // 17.5 (k_fixed_chain2's waves wait for each other within their window and cost the partition beside them 0.9 ms); a higher
+  // stream priority for the main stream changes nothing (tools/r5/enc_stages.sh).
   const int buf_in = c->live_buf, buf_out = ngens > 1 ? 1 - c->live_buf : c->live_buf;
   {
     hipStream_t s2 = getenv("SCPR_SERIAL_CHAINS") ? st : c->stream2;  // (design aid: the two chain stages one after the other, to time each alone)

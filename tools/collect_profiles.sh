@@ -28,4 +28,7 @@ done
 cd $R
 tools/decoder_pmc2.sh 16 prof/$TAG/dec > $OUT/decoder_pmc.log 2>&1
 echo decoder pmc done
+# the same counters over ONE GOP of 40 frames, the chain's wave alone (tools/split_ip_pmc.py <tag> turns the two into P-frame figures)
+tools/decoder_pmc2.sh 40 ${TAG}_decpmc_ip --ip > $OUT/decoder_pmc_ip.log 2>&1
+echo decoder ip pmc done
 tail -1 $OUT/bench_stats.log | head -c 400
