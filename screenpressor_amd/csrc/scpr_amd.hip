@@ -1451,6 +1451,8 @@ int64_t scpr_compress_batch(scpr_codec* c, const void* d_frames, int nframes, in
 // other pixel formats or of a version 2 stream) is unpacked afterwards, by kernels that write to the host directly.
 static int decompress_core(scpr_codec* c, const void* d_packets, const uint32_t* sizes, const int* ftypes, int nframes, void* d_frames_out, int pitch, bool out_is_host) {
   hipStream_t st = c->stream;
+  // SCPR_DEV_STREAMER=0: the device-resident output never goes through the row streamer (A/B timing; see rows_by_streamer below)
+  static const bool dev_streamer = !(getenv("SCPR_DEV_STREAMER") && atoi(getenv("SCPR_DEV_STREAMER")) == 0);
   timing_reset(c);
   // first bytes of every packet decide version / flat / coded (screencap.cpp:1700, :1536)
   std::vector<u64> offs(nframes + 1, 0);
@@ -1488,6 +1490,7 @@ static int decompress_core(scpr_codec* c, const void* d_packets, const uint32_t*
     const bool host_crashed = c->crashed, host_flat = c->last_flat;
     const u32 host_flat_rgb = c->last_flat_rgb, host_frames_done = c->frames_done;
     u32 errv[8] = {0};
+    bool rows_by_streamer = out_is_host;  // (decided per chunk, below)
     for (int attempt = 0;; attempt++) {
     c->crashed = host_crashed, c->last_flat = host_flat, c->last_flat_rgb = host_flat_rgb, c->frames_done = host_frames_done;
     std::vector<DecFrame> fr;
@@ -1525,6 +1528,13 @@ static int decompress_core(scpr_codec* c, const void* d_packets, const uint32_t*
       gop_bytes += sizes[fi];
     }
     const size_t ng = gops.size();
+    // Key frames of RGB32 output leave through their workgroup's row streamer (a second wave that converts the rows the chain has
+    // finished, scpr_wave.hpp) while the chain runs: always when the pictures go to the host (round 4), and since round 5 also
+    // when they stay on the device, as long as the chunk's workgroups are at most two to a CU - chain and streamer then have a
+    // SIMD each, the decode launch takes what it took (114.9 ms) and k_unpack32's 0.8 ms behind it are gone (headline 133.1 ->
+    // 132.1 ms).  With three workgroups on a CU (more than 512 chains in the chunk) streamers share SIMDs with chains and cost
+    // more than the kernel they spare (2400 key frames: 449.8 ms against 422.9 + 6.1): those chunks are unpacked afterwards.
+    rows_by_streamer = out_is_host || (dev_streamer && ng <= 512);
     if (ng) {
       HIPCHK(c->decframes.reserve(fr.size() * sizeof(DecFrame)));
       HIPCHK(c->decgops.reserve(ng * sizeof(DecGop)));
@@ -1606,7 +1616,7 @@ static int decompress_core(scpr_codec* c, const void* d_packets, const uint32_t*
       const u8* pk = (const u8*)d_packets;
       const u8* pk_end = pk + offs[nframes];  // nothing is read at or past this address (the reader supplies 0xFF there)
       // the chunk's frames in the host's buffer, for the chains to send their rows to (RGB32 of version 3 / 4 streams)
-      u8* hout = (out_is_host && c->bpp == 4 && !v2) ? (u8*)d_frames_out + (size_t)f0 * pitch * g.H : nullptr;
+      u8* hout = (rows_by_streamer && c->bpp == 4 && !v2) ? (u8*)d_frames_out + (size_t)f0 * pitch * g.H : nullptr;
       if (v2) {
         auto kern = has_p ? k_decode_gop_v2<true> : k_decode_gop_v2<false>;
         HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
@@ -1662,7 +1672,7 @@ static int decompress_core(scpr_codec* c, const void* d_packets, const uint32_t*
     HIPCHK(hipMemcpyAsync(c->planes.as<u8>() + (size_t)c->pslot * g.plane_stride, c->planes.as<u8>() + (size_t)(n - 1) * g.plane_stride, g.plane_stride, hipMemcpyDeviceToDevice, st));
     stage_begin(c, ST_UNPACK);
     u8* out = (u8*)d_frames_out + (size_t)f0 * pitch * g.H;
-    if (c->bpp == 4 && out_is_host && c->version != 2) {
+    if (c->bpp == 4 && rows_by_streamer && c->version != 2) {
       // a chunk of key frames only: the coded ones are at the host already (their workgroups' row streamers sent them); a chunk
       // with P-frames runs the workgroup form of the kernel, which sends nothing
       bool chunk_has_p = false;
