@@ -1363,6 +1363,7 @@ static int64_t compress_core(scpr_codec* c, const void* d_frames, int nframes, i
                                c->rscratch.as<u8>(), c->rsize.as<u32>(), c->err.as<u32>(), -1);
           }
         } else {
+          if (c->dbg_inject == 3) c->dbg_inject = 0;  // (nothing to poison in the vector form)
           hipLaunchKernelGGL(k_rans, dim3((nb + 63) / 64), dim3(256), 0, st, c->entries.as<u32>(), c->rblocks.as<RansBlock>(), nb, c->rcp.as<RansRcp>(), c->rscratch.as<u8>(),
                              c->rsize.as<u32>(), c->err.as<u32>());
         }
