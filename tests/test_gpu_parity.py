@@ -948,3 +948,36 @@ print("RECUT_OK", int(sizes.sum()))
     env = dict(os.environ, SCPR_DEBUG_CHUNK_LIMIT="50000")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
     assert "RECUT_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("w,h,extra", [(100, 37, 0), (100, 37, 44), (321, 50, 12)])
+def test_key_frame_rows_written_by_the_row_streamer_stay_inside_their_rows(w, h, extra):
+    """Since round 5 the RGB32 rows of coded key frames that stay on the device are written by the workgroup's row streamer while
+    the chain runs (chunks of at most 512 chains), not by k_unpack32 afterwards.  A batch of key frames with a flat frame, a repeat
+    of it and a picture after them, decoded at the natural pitch and at wider ones: every row is the picture's, the bytes between
+    the rows are left alone, and the next call's P-frame finds the last plane where a P-frame expects it."""
+    import torch
+    seq = DesktopSequence(w, h, seed=9, sparkles=15)
+    frames = [seq.frame(t) for t in range(6)]
+    flat = np.full((h, w, 4), 255, np.uint8)
+    flat[..., :3] = (7, 99, 200)
+    frames[2] = flat
+    frames[3] = flat.copy()
+    frames = np.stack(frames)
+    n = len(frames)
+    dev = torch.from_numpy(frames).cuda().reshape(n, -1)
+    enc, dec = _codec(w, h), _codec(w, h)
+    ora = O.OracleCodec(w, h, 32)
+    ref = [ora.compress(f, key=True) for f in frames[:5]] + [ora.compress(frames[5], key=False)]
+    pk, sizes, fts = enc.CompressBatch(dev[:5], [0] * 5)
+    assert pk.cpu().numpy().tobytes() == b"".join(p for p, _ in ref[:5])
+    pitch = w * 4 + extra
+    out = torch.full((5 * pitch * h,), 0xA5, dtype=torch.uint8, device="cuda")
+    r, out = dec.DecompressBatch(pk, sizes, fts, pitch=pitch, out=out)
+    got = out.cpu().numpy().reshape(5, h, pitch)
+    assert r == 5 and np.array_equal(got[:, :, : w * 4].reshape(5, h, w, 4), frames[:5])
+    assert np.all(got[:, :, w * 4:] == 0xA5)
+    pk2, sizes2, fts2 = enc.CompressBatch(dev[5:], [1])
+    assert pk2.cpu().numpy().tobytes() == ref[5][0]
+    r, out2 = dec.DecompressBatch(pk2, sizes2, fts2)
+    assert r == 1 and torch.equal(out2.reshape(1, -1), dev[5:])
