@@ -1,6 +1,8 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (round 5): the rANS stage of n 1080p key frames for each variant library
-# (tools/build_variant.sh: ring 16 / 4, 8-byte records, GLC loads), with and without the LDS allocation that leaves one workgroup per CU.
+# (tools/build_variant.sh NAME -DSCPR_EXPERIMENT [-DSCPR_RANS_RING=16] [-DSCPR_RANS_GLC] [-DSCPR_RANS_NOFAST] [-DSCPR_RANS_NOCHECK]; the 8-byte-record
+# form of the matrix in DESIGN.md 9 was -DSCPR_RANS_REC8 at commit 8539980, taken out of the source afterwards), with and without the LDS
+# allocation that leaves one workgroup per CU.
 R=$PWD
 OUT=$R/gpurun_out/r5/rans_matrix
 mkdir -p $OUT
