@@ -1634,7 +1634,7 @@ static int decompress_core(scpr_codec* c, const void* d_packets, const uint32_t*
         const unsigned threads = has_p ? (no_helpers ? 64u : ng <= 256 ? 512u : 256u) : hout ? 128u : 64u;
         hipLaunchKernelGGL(kern, dim3((unsigned)ng), dim3(threads), dyn, st, pk, pk_end, c->decframes.as<DecFrame>(), c->decgops.as<DecGop>(), c->planes.as<u8>(), g,
                            c->decstates.as<DecRec>(), ar, c->f0, c->err.as<u32>(), ring, c->decfixed.as<FixedBlob>(), (int)std::min<u32>(c->prm.high_range_x, 256),
-                           (int)std::min<u32>(c->prm.high_range_y, 256), ndc, dcache_off, hout, pitch);
+                           (int)std::min<u32>(c->prm.high_range_y, 256), ndc, dcache_off, hout, pitch, n - 1);
       }
     }
     stage_end(c, ST_DECODE);

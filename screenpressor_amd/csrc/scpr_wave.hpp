@@ -1687,6 +1687,7 @@ struct DecGop {
 
 // three bytes at p, through L2 (bypasses this CU's vector L1, which may hold lines from before
 // the wave's own stores to the same plane)
+__device__ __forceinline__ u32 lds_peek_w(const u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ u32 ld3_l2(const u8* p) {
   const size_t a = (size_t)p;
   const u32* w = (const u32*)(a & ~(size_t)3);
@@ -1701,11 +1702,17 @@ __device__ __forceinline__ u32 ld3_l2(const u8* p) {
 // pixels indexed by raster position (it always holds the last two rows: the predictors read
 // "previous", "top" and "top-left" from it); every finished row is packed to RGB24 and flushed
 // to HBM four pixels per lane.  The plane in HBM is never read back.
-// rows_word (may be null): an LDS word in which the chain announces how many rows of the plane are complete in HBM, for the
-// workgroup's row streamer (below): the picture crosses PCIe WHILE the chain decodes (a key frame is 110 ms of chain and 8 MB of
-// pixels: 75 MB/s per wave, 22 GB/s for 300 waves) instead of after it.
+// rows_word / taken_word (may be null): two LDS words between the chain and the workgroup's row streamer (below).  The chain
+// announces in rows_word how many rows are complete IN THE RING; the streamer takes them from there, writes them to the caller's
+// picture as RGB32 while the chain decodes (a key frame is 110 ms of chain and 8 MB of pixels) and says in taken_word how many rows
+// it has taken.  The ring holds the last two rows and a little more, so the chain may not run further ahead than that: once per row,
+// `guard` pixels before the row's end, it makes sure the row before has been taken (as a rule it was long ago; the test is one LDS
+// read per row).  write_plane: the RGB24 plane in HBM is still wanted (the frame a later P-frame or the next call starts from) -
+// a batch of key frames for a streamer writes it for its last frame only (round 5: the decode launch's HBM traffic went from
+// plane out + plane back in + picture out, 6.4 GB for the headline's 300 frames, to the pictures alone).
 template <class DEC>
-__device__ __forceinline__ void decode_intra_frame(DEC& D, const Geom& g, u8* __restrict__ dst, u32* ring, int ring_pixels, u32* rows_word = nullptr) {
+__device__ __forceinline__ void decode_intra_frame(DEC& D, const Geom& g, u8* __restrict__ dst, u32* ring, int ring_pixels, u32* rows_word = nullptr, u32* taken_word = nullptr,
+                                                   bool write_plane = true) {
   const int lane = D.lane;
   const u32 pm = (u32)ring_pixels - 1u;
   const int W = g.W, H = g.H, S = g.S, NP = g.NP;
@@ -1715,11 +1722,11 @@ __device__ __forceinline__ void decode_intra_frame(DEC& D, const Geom& g, u8* __
   int flushed = 0, rowbase = 0;  // rowbase = flushed * W: first pixel of the row being decoded
   auto flush_rows = [&](int to) __attribute__((always_inline)) {
     wave_fence();
-    if (rows_word != nullptr) {
-      // the rows flushed before this call have reached L2 by now (a row of chain ago: the wait is for nothing, as a rule) and the
-      // streamer may take them; this call's rows are announced by the next one (the frame's end announces the last)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_store(rows_word, (u32)flushed, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (rows_word != nullptr) __hip_atomic_store(rows_word, (u32)to, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);  // rows [flushed, to) are whole in the ring
+    if (!write_plane) {
+      rowbase += (to - flushed) * W;
+      flushed = to;
+      return;
     }
     for (; flushed < to; flushed++, rowbase += W) {
       const u32 p0 = (u32)rowbase;
@@ -1746,6 +1753,19 @@ __device__ __forceinline__ void decode_intra_frame(DEC& D, const Geom& g, u8* __
   int lim = W + 1;     // where the runs of the current phase must end: the header phase covers pixels 0..W
   int rowend = W + 1;  // the row being decoded ends here (first row: with the header phase, one pixel later)
   int fastend = 0;     // (set with rowend when the header phase is over)
+  // The streamer's share of the ring (see above).  Writing goes on, unchecked, from one guard point to the next: from `guard`
+  // pixels before the end of row r to `guard` pixels before the end of row r + 1, plus the 255 pixels a run may overshoot and
+  // the 64 a pass of the wave scribbles ahead.  Those positions alias rows up to r - 1 as long as 2 W + 319 - guard <= ring, so
+  // at the guard point of row r the rows below r must have been taken (row r - 1 was announced a row ago).
+  const int guard_px = max(0, 2 * W + 319 - ring_pixels);  // (< W: the ring is W + 512 pixels or more)
+  int gpos = 0x7FFFFFFF, gneed = 0;
+  auto guard = [&]() __attribute__((always_inline)) {
+    if (taken_word != nullptr && SCPR_UNLIKELY(p >= gpos)) {
+      while ((int)lds_peek_w(taken_word) < gneed) __builtin_amdgcn_s_sleep(1);
+      gpos = 0x7FFFFFFF;
+      fastend = min(rowend, NP);
+    }
+  };
   // One run: its type (after the header phase), the pixel of a literal, its length, its pixels.  Two instances:
   // the careful one does everything (header phase, coder block ends), the fast one is entered only where neither
   // can occur and leaves the per-symbol block-end test out (a test and a branch per symbol is ~20 cycles).
@@ -1890,15 +1910,22 @@ __device__ __forceinline__ void decode_intra_frame(DEC& D, const Geom& g, u8* __
       flush_rows(done);
       rowend = rowbase + W;
       fastend = min(rowend, NP);  // the fast runs below go on while p < fastend: to the end of the row, never past the frame
+      if (taken_word != nullptr) {  // ... or to this row's guard point
+        gneed = flushed;
+        gpos = rowend - guard_px;
+        fastend = min(gpos, NP);
+      }
     }
   };
   while (SCPR_LIKELY(p < NP)) {
     run(std::false_type{});
+    guard();
     row_end();
     if constexpr (DEC::kFastRuns) {
       if (SCPR_LIKELY(lim == NP)) {
         // as long as the row goes on and the coder block does not end within the next run (both differences negative)
         while (SCPR_LIKELY((int)((u32)(p - fastend) & (u32)(D.ndec - (kBlockEntries - 5))) < 0)) run(std::true_type{});
+        guard();
         row_end();
       }
     }
@@ -2470,27 +2497,25 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
 // screencap.cpp:1711-1725) to the host's buffer (mapped into the device's address space: the stores cross PCIe), four pixels per
 // lane.  Ends when the chain has set bit 31 and everything announced is sent: the chain sets it on every way out.
 constexpr u32 kRowsEnd = 0x80000000u;
-__device__ __forceinline__ void row_streamer(const u32* rows_word, const u8* __restrict__ plane, u8* __restrict__ hdst, int hpitch, const Geom& g) {
+__device__ __forceinline__ void row_streamer(const u32* rows_word, u32* taken_word, const u32* ring, int ring_pixels, u8* __restrict__ hdst, int hpitch, const Geom& g) {
+  // the rows the chain has finished, out of its LDS ring (32-bit pixels by raster position) into the picture as RGB32
   const int lane = lane_id();
-  const int W = g.W, S = g.S;
+  const int W = g.W;
+  const u32 pm = (u32)ring_pixels - 1u;
   const bool h16 = (((size_t)hdst | (size_t)hpitch) & 15) == 0;
   int done = 0;
   for (;;) {
     const u32 r = __hip_atomic_load(rows_word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
     const int upto = min((int)(r & ~kRowsEnd), g.H);
     if (done < upto) {
-      // Nothing stale from this CU's vector L1: a line that holds the end of one row and the start of the next is read when
-      // the first is sent and would be a stale hit when the second is.  The loads go past the L1 (agent scope: the chain's stores
-      // are in L2) rather than invalidating it under the chain's feet.
-#define SCPR_ROW_LD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
       for (; done < upto; done++) {
-        const u32* row = (const u32*)(plane + (size_t)done * S);
+        const u32 q0 = (u32)done * (u32)W;
         u32* ho = (u32*)(hdst + (size_t)done * hpitch);
         for (int gq = lane; gq * 4 < W; gq += 64) {
-          const int room = S - gq * 12, nv = min(4, W - gq * 4);
-          const u32 w0 = SCPR_ROW_LD(&row[gq * 3]), w1 = room > 4 ? SCPR_ROW_LD(&row[gq * 3 + 1]) : 0u, w2 = room > 8 ? SCPR_ROW_LD(&row[gq * 3 + 2]) : 0u;
+          const int nv = min(4, W - gq * 4);
+          const u32 q = q0 + 4u * (u32)gq;
           const u32 A = 0xFF000000u;
-          const u32 p0 = (w0 & 0xFFFFFFu) | A, p1 = ((w0 >> 24) | ((w1 & 0xFFFFu) << 8)) | A, p2 = ((w1 >> 16) | ((w2 & 0xFFu) << 16)) | A, p3 = (w2 >> 8) | A;
+          const u32 p0 = ring[q & pm] | A, p1 = nv > 1 ? ring[(q + 1) & pm] | A : 0u, p2 = nv > 2 ? ring[(q + 2) & pm] | A : 0u, p3 = nv > 3 ? ring[(q + 3) & pm] | A : 0u;
           u32* o = ho + gq * 4;
           if (h16 && nv == 4) {
             *(uint4*)o = make_uint4(p0, p1, p2, p3);
@@ -2501,6 +2526,9 @@ __device__ __forceinline__ void row_streamer(const u32* rows_word, const u8* __r
             if (nv > 3) o[3] = p3;
           }
         }
+        // (the row's pixels are in registers or gone: the chain may have its part of the ring back)
+        wave_fence();
+        __hip_atomic_store(taken_word, (u32)(done + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
       continue;
     }
@@ -2512,7 +2540,7 @@ __device__ __forceinline__ void row_streamer(const u32* rows_word, const u8* __r
 template <bool HAS_P>
 __global__ __launch_bounds__(HAS_P ? 512 : 128) void k_decode_gop_w(const u8* __restrict__ packets, const u8* packets_end, const DecFrame* __restrict__ frames, const DecGop* __restrict__ gops,
                                                      u8* __restrict__ planes, Geom g, DecRec* __restrict__ states, Arena arena, int f0, u32* __restrict__ status, int ring_bytes,
-                                                     FixedBlob* __restrict__ fixedstore, int far_x, int far_y, int ndc, int dcache_off, u8* __restrict__ hout, int hpitch) {
+                                                     FixedBlob* __restrict__ fixedstore, int far_x, int far_y, int ndc, int dcache_off, u8* __restrict__ hout, int hpitch, int keep_slot) {
   __shared__ __attribute__((aligned(16))) u8 Lraw[HAS_P ? sizeof(WaveLds) : offsetof(WaveLds, fp)];
   WaveLds& L = *(WaveLds*)Lraw;
   // ring_bytes = 4 * (power of two >= W + 512) pixels, then (P-frames) one byte per 16x16 block, then (at dcache_off) ndc dense tables
@@ -2523,12 +2551,12 @@ __global__ __launch_bounds__(HAS_P ? 512 : 128) void k_decode_gop_w(const u8* __
   // of this kernel holds one, its first frame; the frames after it can only be flat ones).
   const bool stream_rows = !HAS_P && hout != nullptr && blockDim.x > 64;
   if (!HAS_P && blockDim.x > 64) {
-    if (threadIdx.x == 0) L.hs.rows = (stream_rows && gop.count > 0 && frames[gop.first].kind == 0) ? 0u : kRowsEnd;
+    if (threadIdx.x == 0) L.hs.rows = (stream_rows && gop.count > 0 && frames[gop.first].kind == 0) ? 0u : kRowsEnd, L.hs.pad[0] = 0u;
     __syncthreads();
     if (threadIdx.x >= 64) {
       if (threadIdx.x < 128 && stream_rows) {
         const DecFrame f0 = frames[gop.first];
-        row_streamer(&L.hs.rows, planes + (size_t)f0.slot * g.plane_stride, hout + (size_t)f0.slot * (size_t)hpitch * g.H, hpitch, g);
+        row_streamer(&L.hs.rows, &L.hs.pad[0], (const u32*)pix, ring_bytes >> 2, hout + (size_t)f0.slot * (size_t)hpitch * g.H, hpitch, g);
       }
       return;
     }
@@ -2566,11 +2594,11 @@ __global__ __launch_bounds__(HAS_P ? 512 : 128) void k_decode_gop_w(const u8* __
       D.stream_init(packets + fr.src_off + 1);
       // (stream_rows: the picture goes to the host's buffer row by row, by the workgroup's second wave; whatever way the frame
       // ends, the end is announced - with the rows that are complete: all of them, or what a refused stream left)
-      decode_intra_frame(D, g, dst, (u32*)pix, ring_bytes >> 2, stream_rows && fi == gop.first ? &L.hs.rows : nullptr);
-      if (stream_rows && fi == gop.first) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(&L.hs.rows, kRowsEnd | (D.bad ? 0u : (u32)g.H), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
+      // (the plane itself is written only where somebody will read it: keep_slot, the chunk's last frame - what a P-frame of the
+      // next call starts from - and every frame that is not streamed)
+      const bool streamed = stream_rows && fi == gop.first;
+      decode_intra_frame(D, g, dst, (u32*)pix, ring_bytes >> 2, streamed ? &L.hs.rows : nullptr, streamed ? &L.hs.pad[0] : nullptr, !streamed || fr.slot == keep_slot);
+      if (streamed) __hip_atomic_store(&L.hs.rows, kRowsEnd | (D.bad ? 0u : (u32)g.H), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     } else if (HAS_P && fr.kind == 2) {
       decode_inter_frame(D, g, dst, planes + (size_t)fr.prev_slot * g.plane_stride, packets + fr.src_off, pix + ring_bytes, far_x, far_y);
     }
