@@ -981,3 +981,31 @@ def test_key_frame_rows_written_by_the_row_streamer_stay_inside_their_rows(w, h,
     assert pk2.cpu().numpy().tobytes() == ref[5][0]
     r, out2 = dec.DecompressBatch(pk2, sizes2, fts2)
     assert r == 1 and torch.equal(out2.reshape(1, -1), dev[5:])
+
+
+@pytest.mark.parametrize("w,h", [(1920, 120), (3000, 48), (2047, 40), (700, 90), (4096, 24)])
+def test_rows_that_decode_faster_than_the_streamer_can_take_them(w, h):
+    """The row streamer takes finished rows out of the chain's LDS ring, which holds two rows and a little more (less than two
+    for widths between 1792 and 2048 or above 3584): once per row the chain makes sure it is not about to write over a row that
+    has not been taken.  Rows of a few long runs decode in microseconds - faster than a row can be copied - so here the chain
+    really has to wait: horizontal stripes (one run of 255 after another), a few literal pixels, every shape of ring-to-width
+    ratio; device and host output; the packets are the oracle's and the pictures come back whole."""
+    import torch
+    rng = np.random.default_rng(w)
+    n = 3
+    frames = np.full((n, h, w, 4), 255, np.uint8)
+    for t in range(n):
+        rows = rng.integers(0, 256, (h, 1, 3))
+        frames[t, :, :, :3] = rows  # every row one colour, different from the one above: copies of the previous pixel, 255 at a time
+        ys, xs = rng.integers(0, h, 12), rng.integers(0, w, 12)
+        frames[t, ys, xs, :3] = rng.integers(0, 256, (12, 3))  # a few literals
+    dev = torch.from_numpy(frames).cuda().reshape(n, -1)
+    ora = O.OracleCodec(w, h, 32)
+    want = [ora.compress(f, key=True)[0] for f in frames]
+    enc, dec = _codec(w, h), _codec(w, h)
+    pk, sizes, fts = enc.CompressBatch(dev, [0] * n)
+    assert pk.cpu().numpy().tobytes() == b"".join(want)
+    r, out = dec.DecompressBatch(pk, sizes, fts)
+    assert r == n and torch.equal(out.reshape(n, -1), dev)
+    r, hout = dec.DecompressBatchHost(pk.cpu().numpy(), sizes, fts)
+    assert r == n and np.array_equal(hout.reshape(frames.shape), frames)
