@@ -1535,7 +1535,8 @@ static int decompress_core(scpr_codec* c, const void* d_packets, const uint32_t*
     // SIMD each, the decode launch takes what it took (114.9 ms) and k_unpack32's 0.8 ms behind it are gone (headline 133.1 ->
     // 132.1 ms).  With three workgroups on a CU (more than 512 chains in the chunk) streamers share SIMDs with chains and cost
     // more than the kernel they spare (2400 key frames: 449.8 ms against 422.9 + 6.1): those chunks are unpacked afterwards.
-    rows_by_streamer = out_is_host || (dev_streamer && ng <= 512);
+    static const size_t dev_streamer_max = getenv("SCPR_DEV_STREAMER_MAX") ? (size_t)atoi(getenv("SCPR_DEV_STREAMER_MAX")) : 512;  // (A/B timing)
+    rows_by_streamer = out_is_host || (dev_streamer && ng <= dev_streamer_max);
     if (ng) {
       HIPCHK(c->decframes.reserve(fr.size() * sizeof(DecFrame)));
       HIPCHK(c->decgops.reserve(ng * sizeof(DecGop)));
