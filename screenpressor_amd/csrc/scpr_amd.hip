@@ -1492,6 +1492,7 @@ static int decompress_core(scpr_codec* c, const void* d_packets, const uint32_t*
     const u32 host_flat_rgb = c->last_flat_rgb, host_frames_done = c->frames_done;
     u32 errv[8] = {0};
     bool rows_by_streamer = out_is_host;  // (decided per chunk, below)
+    bool streamed_rgb24 = false;          // ... and whether a chunk of RGB24 output went out that way (nothing left to copy then)
     for (int attempt = 0;; attempt++) {
     c->crashed = host_crashed, c->last_flat = host_flat, c->last_flat_rgb = host_flat_rgb, c->frames_done = host_frames_done;
     std::vector<DecFrame> fr;
@@ -1537,6 +1538,7 @@ static int decompress_core(scpr_codec* c, const void* d_packets, const uint32_t*
     // more than the kernel they spare (2400 key frames: 449.8 ms against 422.9 + 6.1): those chunks are unpacked afterwards.
     static const size_t dev_streamer_max = getenv("SCPR_DEV_STREAMER_MAX") ? (size_t)atoi(getenv("SCPR_DEV_STREAMER_MAX")) : 512;  // (A/B timing)
     rows_by_streamer = out_is_host || (dev_streamer && ng <= dev_streamer_max);
+    streamed_rgb24 = false;
     if (ng) {
       HIPCHK(c->decframes.reserve(fr.size() * sizeof(DecFrame)));
       HIPCHK(c->decgops.reserve(ng * sizeof(DecGop)));
@@ -1618,7 +1620,12 @@ static int decompress_core(scpr_codec* c, const void* d_packets, const uint32_t*
       const u8* pk = (const u8*)d_packets;
       const u8* pk_end = pk + offs[nframes];  // nothing is read at or past this address (the reader supplies 0xFF there)
       // the chunk's frames in the host's buffer, for the chains to send their rows to (RGB32 of version 3 / 4 streams)
-      u8* hout = (rows_by_streamer && c->bpp == 4 && !v2) ? (u8*)d_frames_out + (size_t)f0 * pitch * g.H : nullptr;
+      // (RGB24 output in the plane's own layout - pitch = stride, the k_copy_planes case - is streamed too when the chunk is nothing
+      // but coded key frames and stays on the device: BASELINE configs[4])
+      bool all_coded_keys = true;
+      for (int i = 0; i < n; i++) all_coded_keys &= !ftypes[f0 + i] && (heads[f0 + i] & 15) != 1;
+      streamed_rgb24 = rows_by_streamer && !out_is_host && !v2 && c->bpp == 3 && pitch == g.S && ((size_t)d_frames_out & 3) == 0 && all_coded_keys;
+      u8* hout = (rows_by_streamer && !v2 && (c->bpp == 4 || streamed_rgb24)) ? (u8*)d_frames_out + (size_t)f0 * pitch * g.H : nullptr;
       if (v2) {
         auto kern = has_p ? k_decode_gop_v2<true> : k_decode_gop_v2<false>;
         HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
@@ -1635,7 +1642,7 @@ static int decompress_core(scpr_codec* c, const void* d_packets, const uint32_t*
         const unsigned threads = has_p ? (no_helpers ? 64u : ng <= 256 ? 512u : 256u) : hout ? 128u : 64u;
         hipLaunchKernelGGL(kern, dim3((unsigned)ng), dim3(threads), dyn, st, pk, pk_end, c->decframes.as<DecFrame>(), c->decgops.as<DecGop>(), c->planes.as<u8>(), g,
                            c->decstates.as<DecRec>(), ar, c->f0, c->err.as<u32>(), ring, c->decfixed.as<FixedBlob>(), (int)std::min<u32>(c->prm.high_range_x, 256),
-                           (int)std::min<u32>(c->prm.high_range_y, 256), ndc, dcache_off, hout, pitch, n - 1);
+                           (int)std::min<u32>(c->prm.high_range_y, 256), ndc, dcache_off, hout, pitch, n - 1, c->bpp);
       }
     }
     stage_end(c, ST_DECODE);
@@ -1694,6 +1701,8 @@ static int decompress_core(scpr_codec* c, const void* d_packets, const uint32_t*
     } else if (c->bpp == 4) {
       dim3 gr((g.H * ((g.W + 3) >> 2) + 256 * PACK_ITEMS - 1) / (256 * PACK_ITEMS), n);
       hipLaunchKernelGGL(k_unpack32, gr, dim3(256), 0, st, c->planes.as<u8>(), out, g, pitch);
+    } else if (c->bpp == 3 && streamed_rgb24) {
+      // (the chains' row streamers wrote every picture of the chunk)
     } else if (c->bpp == 3 && pitch == g.S && ((size_t)out & 3) == 0) {
       dim3 gr((unsigned)(((size_t)g.H * g.S / 4 + 256 * PACK_ITEMS - 1) / (256 * PACK_ITEMS)), n);
       hipLaunchKernelGGL(k_copy_planes, gr, dim3(256), 0, st, c->planes.as<u8>(), out, g);

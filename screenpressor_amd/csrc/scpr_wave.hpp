@@ -2497,8 +2497,9 @@ __device__ __forceinline__ void decode_inter_frame(DEC& D, const Geom& g, u8* __
 // screencap.cpp:1711-1725) to the host's buffer (mapped into the device's address space: the stores cross PCIe), four pixels per
 // lane.  Ends when the chain has set bit 31 and everything announced is sent: the chain sets it on every way out.
 constexpr u32 kRowsEnd = 0x80000000u;
-__device__ __forceinline__ void row_streamer(const u32* rows_word, u32* taken_word, const u32* ring, int ring_pixels, u8* __restrict__ hdst, int hpitch, const Geom& g) {
-  // the rows the chain has finished, out of its LDS ring (32-bit pixels by raster position) into the picture as RGB32
+__device__ __forceinline__ void row_streamer(const u32* rows_word, u32* taken_word, const u32* ring, int ring_pixels, u8* __restrict__ hdst, int hpitch, int hbpp, const Geom& g) {
+  // the rows the chain has finished, out of its LDS ring (32-bit pixels by raster position) into the picture: RGB32, or (hbpp 3,
+  // hpitch = the plane's own stride) RGB24 rows exactly as the chain would have packed them into the plane
   const int lane = lane_id();
   const int W = g.W;
   const u32 pm = (u32)ring_pixels - 1u;
@@ -2511,6 +2512,17 @@ __device__ __forceinline__ void row_streamer(const u32* rows_word, u32* taken_wo
       for (; done < upto; done++) {
         const u32 q0 = (u32)done * (u32)W;
         u32* ho = (u32*)(hdst + (size_t)done * hpitch);
+        if (hbpp == 3) {
+          for (int gq = lane; gq * 4 < W; gq += 64) {
+            const int nv = min(4, W - gq * 4), room = hpitch - gq * 12;
+            const u32 q = q0 + 4u * (u32)gq;
+            const u32 a = ring[q & pm], b = nv > 1 ? ring[(q + 1) & pm] : 0u, c = nv > 2 ? ring[(q + 2) & pm] : 0u, d = nv > 3 ? ring[(q + 3) & pm] : 0u;
+            u32* o = ho + gq * 3;
+            o[0] = a | (b << 24);
+            if (room > 4) o[1] = (b >> 8) | (c << 16);
+            if (room > 8) o[2] = (c >> 16) | (d << 8);
+          }
+        } else
         for (int gq = lane; gq * 4 < W; gq += 64) {
           const int nv = min(4, W - gq * 4);
           const u32 q = q0 + 4u * (u32)gq;
@@ -2540,7 +2552,7 @@ __device__ __forceinline__ void row_streamer(const u32* rows_word, u32* taken_wo
 template <bool HAS_P>
 __global__ __launch_bounds__(HAS_P ? 512 : 128) void k_decode_gop_w(const u8* __restrict__ packets, const u8* packets_end, const DecFrame* __restrict__ frames, const DecGop* __restrict__ gops,
                                                      u8* __restrict__ planes, Geom g, DecRec* __restrict__ states, Arena arena, int f0, u32* __restrict__ status, int ring_bytes,
-                                                     FixedBlob* __restrict__ fixedstore, int far_x, int far_y, int ndc, int dcache_off, u8* __restrict__ hout, int hpitch, int keep_slot) {
+                                                     FixedBlob* __restrict__ fixedstore, int far_x, int far_y, int ndc, int dcache_off, u8* __restrict__ hout, int hpitch, int keep_slot, int hbpp) {
   __shared__ __attribute__((aligned(16))) u8 Lraw[HAS_P ? sizeof(WaveLds) : offsetof(WaveLds, fp)];
   WaveLds& L = *(WaveLds*)Lraw;
   // ring_bytes = 4 * (power of two >= W + 512) pixels, then (P-frames) one byte per 16x16 block, then (at dcache_off) ndc dense tables
@@ -2556,7 +2568,7 @@ __global__ __launch_bounds__(HAS_P ? 512 : 128) void k_decode_gop_w(const u8* __
     if (threadIdx.x >= 64) {
       if (threadIdx.x < 128 && stream_rows) {
         const DecFrame f0 = frames[gop.first];
-        row_streamer(&L.hs.rows, &L.hs.pad[0], (const u32*)pix, ring_bytes >> 2, hout + (size_t)f0.slot * (size_t)hpitch * g.H, hpitch, g);
+        row_streamer(&L.hs.rows, &L.hs.pad[0], (const u32*)pix, ring_bytes >> 2, hout + (size_t)f0.slot * (size_t)hpitch * g.H, hpitch, hbpp, g);
       }
       return;
     }

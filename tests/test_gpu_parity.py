@@ -1009,3 +1009,30 @@ def test_rows_that_decode_faster_than_the_streamer_can_take_them(w, h):
     assert r == n and torch.equal(out.reshape(n, -1), dev)
     r, hout = dec.DecompressBatchHost(pk.cpu().numpy(), sizes, fts)
     assert r == n and np.array_equal(hout.reshape(frames.shape), frames)
+
+
+@pytest.mark.parametrize("w,h", [(100, 37), (33, 50), (98, 41), (1919, 24)])
+def test_rgb24_key_frame_rows_written_by_the_row_streamer(w, h):
+    """RGB24 pictures that stay on the device in the plane's own layout (rows padded to 4 bytes): a chunk of nothing but coded key
+    frames is written by the row streamers, 12 bytes per 4 pixels as the chain would have packed them, padding zero; a chunk with
+    a flat frame in it goes the old way (plane, then copy) - same bytes either way, and the oracle's decoder agrees."""
+    import torch
+    seq = DesktopSequence(w, h, seed=31, sparkles=25)
+    pitch = (w * 3 + 3) & ~3
+    frames = np.stack([pack24(seq.frame24(t)).reshape(h, pitch) for t in range(5)])
+    flat = np.zeros((h, pitch), np.uint8)
+    flat[:, : w * 3] = np.tile(np.array([9, 90, 200], np.uint8), w)
+    ora = O.OracleCodec(w, h, 24)
+    for variant in ("keys", "with_flat"):
+        fr = frames if variant == "keys" else np.concatenate([frames[:2], flat[None], frames[2:]])
+        n = len(fr)
+        dev = torch.from_numpy(np.ascontiguousarray(fr)).cuda().reshape(n, -1)
+        enc, dec = _codec(w, h, 24), _codec(w, h, 24)
+        pk, sizes, fts = enc.CompressBatch(dev, [0] * n)
+        ref = [O.OracleCodec(w, h, 24).compress(f, key=True) for f in fr]
+        assert pk.cpu().numpy().tobytes() == b"".join(p for p, _ in ref)
+        out = torch.full((n * pitch * h,), 0x5A, dtype=torch.uint8, device="cuda")
+        r, out = dec.DecompressBatch(pk, sizes, fts, out=out)
+        got = out.cpu().numpy().reshape(n, h, pitch)
+        assert r == n and np.array_equal(got[:, :, : w * 3], fr[:, :, : w * 3]), variant
+        assert np.all(got[:, :, w * 3:] == 0), variant  # (row padding comes out as the plane holds it: zero)
