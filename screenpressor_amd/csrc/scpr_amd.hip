@@ -787,7 +787,10 @@ static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int n
   // 17.5 (k_fixed_chain2's waves wait for each other within their window and cost the partition beside them 0.9 ms); a higher
   // stream priority for the main stream changes nothing (tools/r5/enc_stages.sh).
   const int buf_in = c->live_buf, buf_out = ngens > 1 ? 1 - c->live_buf : c->live_buf;
-  {
+  // Where exactly: behind the colour partition's FIRST pass (tools/r5/fork_ab.sh, 1080p encode: in front of the partition 17.35 ms,
+  // behind its first pass 17.05, behind both 17.75; 4K key frames 34.6 / 34.4 / 35.6).  SCPR_FORK_AT = 0 / 1 / 2 for A/B timing.
+  static const int fork_at = getenv("SCPR_FORK_AT") ? atoi(getenv("SCPR_FORK_AT")) : 1;
+  auto fork_fixed_branch = [&]() -> int {
     hipStream_t s2 = getenv("SCPR_SERIAL_CHAINS") ? st : c->stream2;  // (design aid: the two chain stages one after the other, to time each alone)
     HIPCHK(hipEventRecord(c->ev_fork, st));
     HIPCHK(hipStreamWaitEvent(s2, c->ev_fork, 0));
@@ -807,6 +810,11 @@ static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int n
     }
     stage_end(c, ST_FIXED, s2);
     HIPCHK(hipEventRecord(c->ev_join, s2));
+    return SCPR_OK;
+  };
+  if (fork_at == 0 || Ctot == 0) {
+    const int rc = fork_fixed_branch();
+    if (rc != SCPR_OK) return rc;
   }
   stage_begin(c, ST_SORT);
   {
@@ -824,10 +832,18 @@ static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int n
       hipLaunchKernelGGL(k_cs_scan, dim3(nsg), dim3(64), 0, st, c->cssegs.as<CsSeg>(), c->cscnt.as<u32>(), c->csoff.as<u32>());
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cs_scatter<8>), dim3(nsb), dim3(256), 0, st, c->keys[0].as<u32>(), c->vals[0].as<u32>(), c->csblocks.as<CsBlock>(), c->csoff.as<u32>(),
                          c->keys[1].as<u32>(), c->vals[1].as<u32>());
+      if (fork_at == 1) {
+        const int rc = fork_fixed_branch();
+        if (rc != SCPR_OK) return rc;
+      }
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cs_count<14>), dim3(nsb), dim3(256), 0, st, c->keys[1].as<u32>(), c->csblocks.as<CsBlock>(), c->cscnt.as<u32>());
       hipLaunchKernelGGL(k_cs_scan, dim3(nsg), dim3(64), 0, st, c->cssegs.as<CsSeg>(), c->cscnt.as<u32>(), c->csoff.as<u32>());
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cs_scatter<14>), dim3(nsb), dim3(256), 0, st, c->keys[1].as<u32>(), c->vals[1].as<u32>(), c->csblocks.as<CsBlock>(), c->csoff.as<u32>(),
                          c->keys[0].as<u32>(), c->vals[0].as<u32>());
+      if (fork_at >= 2) {
+        const int rc = fork_fixed_branch();
+        if (rc != SCPR_OK) return rc;
+      }
     }
     // (tests: two keys of the partitioned array change places - the order proof below must end the call)
     if (c->dbg_inject == 2 && Ctot > 1) {
