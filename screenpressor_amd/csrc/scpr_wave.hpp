@@ -646,7 +646,7 @@ struct WaveModel {
       bits |= (pf || j == c) ? 1u << q : 0u;
     }
     wave_fence();
-    lds_st_if(&r[4 + lane], 0u, lane < 8);
+    lds_st_if(&r[4 + lane], 0u, lane < 12);  // the set's eight words, and words 12 .. 15: the decoder keeps a dense table's widest symbol in 12 / 13 (WaveDec::colour)
     wave_fence();
     lds_or_if(&r[4 + (lane >> 3)], bits << ((lane & 7) * 4), true);
     wave_fence();
@@ -655,6 +655,7 @@ struct WaveModel {
     const int sum = write_table(tab_of(h.dense, true), fr, cn);
     h.kind = 6;
     h.fshift = s2;
+    h.fmax = 0;  // (a dense context's header has no top-entry count there: the decoder counts the widest symbol's unsettled hits in it)
     h.d = d + 1;
     h.total = ((256 - (d + 1)) << (s2 > 0 ? s2 - 1 : 0)) + sum;
     wave_fence();
@@ -710,6 +711,20 @@ struct WaveModel {
     ocf = rdl(selc, own);
     int cn[4] = {(int)(cq.x & 0xFFFF), (int)(cq.x >> 16), (int)(cq.y & 0xFFFF), (int)(cq.y >> 16)};
     int fr[4] = {(int)(fq.x & 0xFFFF), (int)(fq.x >> 16), (int)(fq.y & 0xFFFF), (int)(fq.y >> 16)};
+    if constexpr (DEC) {
+      // The decoder's shortcut for the table's widest symbol (WaveDec::colour) counts its hits in the header (h.fmax) and leaves
+      // the table alone: they are owed to that symbol's count before anything here looks at the counts, and the symbol is
+      // forgotten - this is the way on which intervals change (and a symbol that is not met yet changes nothing, but comes by
+      // rarely: the next wide symbol that is looked up the long way is remembered again).
+      const u32 t13 = rfl(r[13]);
+      if (t13 >> 31) {
+        const int tj = (int)(t13 & 255u), owed = h.fmax * (h.kind == 6 ? kStepHash << h.fshift : kStepDense);
+#pragma unroll
+        for (int q = 0; q < 4; q++) cn[q] += (lane == (tj >> 2) && q == (tj & 3)) ? owed : 0;
+        h.fmax = 0;
+        r[13] = 0u;  // (every lane the same word)
+      }
+    }
     const u32 bits = h.kind == 6 ? set_bits4(r) : 15u;
     u32 nbits = bits;
     int step = kStepDense;
@@ -805,6 +820,11 @@ __device__ u64 g_cprof[32];  // colour symbols by class: [2k] s_memtime ticks, [
 __device__ u32 g_chainrec[8192][8];
 __device__ u32 g_chainrec_n;
 #endif
+#ifdef SCPR_NO_DTOP
+constexpr bool kDenseTop = false;  // (A/B builds)
+#else
+constexpr bool kDenseTop = true;
+#endif
 struct WaveDec : WaveModel {
   WaveLds& L;
   // input stream
@@ -835,6 +855,7 @@ struct WaveDec : WaveModel {
   u32 crec_ea = 0;  // LDS offset of the record cache + 4 * (lane & 15): a slot's `ea` is this + 80 * slot
   // what a hit on a small table's top entry adds to the record's second word (total | top count << 16), in lane 0; nothing elsewhere
   u32 ktop = 0;
+  u32 kl0 = 0;   // all ones in lane 0, nothing in the others (a value for lane 0's address alone, by one `and`)
   // models
   DecRec* gstates;
   bool bad = false;
@@ -842,6 +863,7 @@ struct WaveDec : WaveModel {
 
   __device__ __forceinline__ WaveDec(WaveLds& l, const u8* s, const u8* e, DecRec* gs, Arena a, int f0_) : WaveModel(l.tmp, a, f0_), L(l), src(s), src_end(e), gstates(gs) {
     ktop = lane_id() == 0 ? (u32)kStepSmall * 0x10001u : 0u;
+    kl0 = lane_id() == 0 ? 0xFFFFFFFFu : 0u;
     crec_ea = (u32)(size_t)&l.crec[0][0] + 4u * (u32)(lane_id() & 15);
     asm volatile("" : "+v"(ktop), "+v"(crec_ea));  // (kept in registers: not made afresh for every symbol)
   }
@@ -890,6 +912,7 @@ struct WaveDec : WaveModel {
   // colour symbols by class (0 top entry of a small table, 1 another entry, 2 small table's general path, 3 dense hit, 4 dense
   // general path, 5 raw, 6 record-cache miss [the miss alone, also inside its symbol's class], 7 dense-table cache miss [likewise])
   u64 cprof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, cls_t0 = 0;
+  u64 xprof[4] = {0, 0, 0, 0};  // P-frames, dense tables: symbols, answered from the record (the widest symbol), widest symbols learnt, forgotten
   u64 rprof[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // P-frame runs through the general fills: all, literal, left, above, previous frame, above-left / gradient, longer than 64, their pixels
   __device__ __forceinline__ void cls_begin() { cls_t0 = __builtin_readcyclecounter(); }
   template <int K>
@@ -1574,25 +1597,65 @@ struct WaveDec : WaveModel {
       wave_fence();
       if constexpr (MODE == 0) count<CHK>();
     };
-    if (SCPR_LIKELY((int)h0 < 0)) {  // sign bit: a small table (kind 4 or 5)
-      u32 dd;
-      const int tt = top_test(h1, hz, (int)v, fr, cf, dd);
-      if (SCPR_LIKELY(tt < 0)) {
-        // A hit on the top entry changes two numbers, both in the header's second word: the total and the top entry's count
-        // go up by the same step (the table itself hears of it later: small_settle).  One LDS add, nothing unpacked, nothing
-        // packed: lane 0's address is the record (its ea), the other lanes add nothing to words further on.
-        c = (int)(hz & 255u);
-        event<17>();
-        if constexpr (MODE == 0) advance(0u, fr, dd);  // (dd = v - cf: the test has it already)
-        else pend[0] = 0u, pend[1] = fr, pend[2] = dd;
-        wave_fence();
-        // (an add by all lanes, four to a word, in front of the next read costs 5 cycles more than a plain write - and
-        // 9 less than switching exec for lane 0 alone, tools/lds_bench.hip)
-asm volatile("ds_add_u32 %0, %1 offset:4" ::"v"(ea), "v"(ktop) : "memory");
-        wave_fence();
-        if constexpr (MODE == 0) count<CHK>();
-        cls_end<0>();
-      } else {  // another entry, an unmet symbol, or a rescale is due
+    // The hit that needs no table - the top entry of a small table, and in P-frames the widest symbol of a dense one - is ONE
+    // block for both (two copies of it were two more joins at which the compiler copies the packet block's register, behind a
+    // wait for every load and store in flight: the dense copy measured no gain at all that way, 10.42 against 10.40 ms per P-frame).
+    const bool small = (int)h0 < 0;  // sign bit: a small table (kind 4 or 5)
+    int tt = 0;
+    u32 dd = 0, hitc = 0, hitadd = 0;
+    if (SCPR_LIKELY(small)) {
+      tt = top_test(h1, hz, (int)v, fr, cf, dd);
+      hitc = hz;
+      hitadd = ktop;
+    } else if constexpr (PF && kDenseTop) {
+      // A dense table's widest symbol (round 5).  The intervals of a dense table are FROZEN between its rebuilds - a symbol only
+      // adds to its count (Cx7::incrCnt / Cx6, ans_contexts.h:954-981, :742-796) - and the contexts that go dense in a P-frame are
+      // not noise: 68-72 % of their symbols are the table's widest one, 2750 of 4096 wide on average (tools/r5/prof_dense_top.py).
+      // The record remembers that symbol (words 12 / 13: start | width << 16, number | 1 << 31; learnt below from the first
+      // lookup that meets a symbol at least half the scale wide - then the widest -, forgotten on the way that rebuilds:
+      // dense_impl), and a value inside its interval needs no table: no second LDS round trip, no search.  Its hits are
+      // counted in the header's spare half word (where a small table keeps its top entry's count) and owed to the table's
+      // count until the long way comes by, with one LDS add like the top entry of a small table.
+      const u32 t13 = rdl(w, 9), t12 = rdl(w, 8);
+      const u32 tcf = t12 & 0xFFFFu;
+      const u32 stp = (h0 & 1u) ? (u32)kStepDense : (u32)kStepHash << ((h0 >> 16) & 15u);
+      fr = t12 >> 16;
+      dd = v - tcf;
+      // (sign bits and-ed together: kind 6 or 7 - bits 1 and 2 of the kind, no other kind on this side has both -, the symbol is
+      // known, the value is not below its interval and not at or above its end, no rebuild is due after it)
+      tt = (int)(((h0 << 29) & (h0 << 30)) & t13 & ~dd & (dd - fr) & ((h1 & 0xFFFFu) + 2u * stp - (u32)kProbScale - 1u));
+      hitc = t13;
+      hitadd = kl0 & (stp + 0x10000u);  // lane 0: the total and the owed hits, one add; the other lanes' words get nothing
+#ifdef SCPR_PROFILE
+      xprof[0] += (h0 & 0xFEu) == 6u;
+      xprof[1] += tt < 0;
+#endif
+    }
+    if (SCPR_LIKELY(tt < 0)) {
+      // A hit on the top entry changes two numbers, both in the header's second word: the total and the top entry's count
+      // go up by the same step (the table itself hears of it later: small_settle).  One LDS add, nothing unpacked, nothing
+      // packed: lane 0's address is the record (its ea), the other lanes add nothing to words further on.
+      c = (int)(hitc & 255u);
+#ifdef SCPR_PROFILE
+      if (small) event<17>();
+      else event<10>();
+#endif
+      if constexpr (MODE == 0) advance(0u, fr, dd);  // (dd = v - cf: the test has it already)
+      else pend[0] = 0u, pend[1] = fr, pend[2] = dd;
+      wave_fence();
+      // (an add by all lanes, four to a word, in front of the next read costs 5 cycles more than a plain write - and
+      // 9 less than switching exec for lane 0 alone, tools/lds_bench.hip)
+      asm volatile("ds_add_u32 %0, %1 offset:4" ::"v"(ea), "v"(hitadd) : "memory");
+      wave_fence();
+      if constexpr (MODE == 0) count<CHK>();
+#ifdef SCPR_PROFILE
+      if (small) cls_end<0>();
+      else cls_end<3>();
+#else
+      cls_end<0>();
+#endif
+    } else if (small) {
+      {  // another entry, an unmet symbol, or a rescale is due
         header();
         h.top = hz;
         small_settle(h, w);
@@ -1649,6 +1712,17 @@ asm volatile("ds_add_u32 %0, %1 offset:4" ::"v"(ea), "v"(ktop) : "memory");
       } else {
         event<10>();
         const int t = PF ? dense_hit_p(h, w, (int)v, c, fr, cf) : dense_hit(h, w, (int)v, c, fr, cf);
+        if constexpr (PF && kDenseTop) {
+          if (SCPR_UNLIKELY((t < 0) & (fr >= (u32)kProbScale / 2u))) {  // at least half the scale: this table's widest symbol until its next rebuild
+#ifdef SCPR_PROFILE
+            xprof[2]++;
+#endif
+            u32x2 nt;
+            nt.x = cf | (fr << 16);
+            nt.y = (u32)c | 0x80000000u;
+            asm volatile("ds_write_b64 %0, %1 offset:48" ::"v"(ra), "v"(nt) : "memory");  // words 12 / 13, from all lanes alike
+          }
+        }
         if (SCPR_UNLIKELY(t >= 0)) {
 #ifdef SCPR_PROFILE
           const u64 tm0 = __builtin_readcyclecounter();
@@ -2627,6 +2701,7 @@ __global__ __launch_bounds__(HAS_P ? 512 : 128) void k_decode_gop_w(const u8* __
     D.cprof[14] += D.dmiss_ticks, D.cprof[15] += D.dmiss;
     for (int i = 0; i < 16; i++) atomicAdd((unsigned long long*)&g_cprof[i], (unsigned long long)D.cprof[i]);
     for (int i = 0; i < 8; i++) atomicAdd((unsigned long long*)&g_cprof[16 + i], (unsigned long long)D.rprof[i]);
+    for (int i = 0; i < 4; i++) atomicAdd((unsigned long long*)&g_cprof[24 + i], (unsigned long long)D.xprof[i]);
   }
 #endif
 }

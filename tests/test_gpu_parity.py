@@ -1036,3 +1036,38 @@ def test_rgb24_key_frame_rows_written_by_the_row_streamer(w, h):
         got = out.cpu().numpy().reshape(n, h, pitch)
         assert r == n and np.array_equal(got[:, :, : w * 3], fr[:, :, : w * 3]), variant
         assert np.all(got[:, :, w * 3:] == 0), variant  # (row padding comes out as the plane holds it: zero)
+
+
+def test_dense_tables_widest_symbol_in_p_frames_across_calls_and_rebuilds():
+    """A P-frame's dense colour tables answer their widest symbol from the context's record (WaveDec::colour: words 12 / 13
+    of the record, hits owed to the table in the header's spare half word until the long way settles them).  A 1080p GOP
+    of 40 frames has ~4000 dense-table symbols per P-frame, two in three of them such hits, and tables that rebuild with hits
+    owed; decoded in one call, frame by frame (every call stores and loads the records with what they owe) and in uneven
+    calls it must be the frames that went in - and the encoder's packets are the oracle's for the first frames."""
+    import torch
+    w, h, n = 1920, 1080, 40
+    seq = DesktopSequence(w, h, seed=1)
+    frames = np.stack([seq.frame(t) for t in range(n)])
+    dev = torch.from_numpy(frames).cuda().reshape(n, -1)
+    pk, sizes, fts = _codec(w, h).CompressBatch(dev, [0] + [1] * (n - 1))
+    ora = O.OracleCodec(w, h, 32)
+    off = 0
+    for t in range(3):
+        want, ft = ora.compress(frames[t], key=t == 0)
+        assert pk[off:off + int(sizes[t])].cpu().numpy().tobytes() == want and fts[t] == ft
+        off += int(sizes[t])
+    r, out = _codec(w, h).DecompressBatch(pk, sizes, fts)
+    assert r == n and torch.equal(out.reshape(n, -1), dev)
+    host = pk.cpu().numpy()
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    d = _codec(w, h)
+    for t in range(n):  # frame by frame
+        r, o = d.DecompressFrame(host[offs[t]:offs[t + 1]].tobytes(), fts[t])
+        assert r == 1 and np.array_equal(o, frames[t].reshape(-1)), t
+    d = _codec(w, h)
+    t = 0
+    for m in (1, 2, 5, 1, 11, 3, 17):  # uneven calls
+        r, o = d.DecompressBatch(pk[offs[t]:offs[t + m]].clone(), sizes[t:t + m], fts[t:t + m])
+        assert r == m and torch.equal(o.reshape(m, -1), dev[t:t + m]), t
+        t += m
+    assert t == n
