@@ -340,8 +340,7 @@ __device__ __forceinline__ int block_excl_scan(int v, int* tot, int* wsum /*shar
 __global__ __launch_bounds__(256) void k_tiles(const u8* __restrict__ planes, Geom g, const int* __restrict__ slots, u8* __restrict__ exitmap, u8* __restrict__ tnmap, u8* __restrict__ nlong) {
   __shared__ u64 fm[4][24];
   __shared__ u8 ty[TILE];
-  __shared__ u32 lp[2][TILE];  // successor | last run start << 16, one word per doubling step
-  __shared__ u32 more[2][4];
+  __shared__ u32 lp[TILE];  // a pixel's way out of its quarter of the tile: successor | start of the run it sits in << 16
   // Workgroups go round the eight XCDs in launch order, and every XCD has its own L2: tile t reads the row above its pixels,
   // which tile t - W / 1024 (the one before the last, at 1080p) has just read.  The launch order is therefore remapped so
   // that each XCD gets one contiguous eighth of the (frame, tile) space - neighbouring tiles meet in the same L2 instead
@@ -378,8 +377,21 @@ __global__ __launch_bounds__(256) void k_tiles(const u8* __restrict__ planes, Ge
     }
   }
   __syncthreads();
+  // Where does the path that ENTERS the tile at offset e < HALO leave it, and in a run that began where?  Every pixel r has a
+  // successor j(r) in (r, r + 255] - the start of the next run if a run started at r.  Rounds 1-4 squared the successor function
+  // over the whole tile (pointer doubling in LDS: two arrays of 1024 words, up to ten rounds of four gathers and a barrier; it
+  // was most of this kernel).  Successors only point FORWARD, so the tile is resolved from its end instead: wave w owns the
+  // quarter [256 w, 256 w + 256), in four blocks of 64 pixels held in registers, last block first -
+  //  * inside a block the paths are squared with lane permutes (no memory, no barrier; a path has left its block of 64 after
+  //    three or four rounds as a rule, six at most),
+  //  * what lands in a later block of the quarter takes that block's finished answer with one more permute,
+  // and the quarters are chained through LDS afterwards: an entry point is in quarter 0, a run is at most 255 long, so its
+  // path visits each later quarter once - three gathers.  One barrier, a third of the LDS operations.
+  const int lane = lane_id(), wv = tid >> 6;
+  u32 vq[4];  // block b of my quarter, pixel 256 wv + 64 b + lane: successor | start of the run it sits in << 16
+#pragma unroll
   for (int k = 0; k < 4; k++) {
-    const int r = k * 256 + tid, p = tstart + r;
+    const int r = wv * 256 + k * 64 + lane, p = tstart + r;
     int j = EXITED;
     if (p < g.NP) {
       int n = ones_from(fm[fit_bit_of_type(ty[r])], r + 1, HALO - 1);
@@ -390,30 +402,38 @@ __global__ __launch_bounds__(256) void k_tiles(const u8* __restrict__ planes, Ge
       tnmap[at] = (u8)((u32)ty[r] | ((u32)min(n, 31) << 3));
       if (n >= 31) nlong[at] = (u8)n;
     }
-    lp[0][r] = (u32)j | ((u32)r << 16);
+    vq[k] = (u32)j | ((u32)r << 16);
   }
-  __syncthreads();
-  int cur = 0;
-  for (int it = 0; it < 10; it++) {  // (2^10 steps: every path has left the tile)
-    u32 v0 = 0;
-    for (int k = 0; k < 4; k++) {
-      const int r = k * 256 + tid;
-      u32 v = lp[cur][r];
-      const u32 j = v & 0xFFFFu;
-      if (j < TILE) v = lp[cur][j];  // jump: the successor's successor, and the start of the run it sits in
-      lp[cur ^ 1][r] = v;
-      if (k == 0) v0 = v;
+#pragma unroll
+  for (int b = 3; b >= 0; b--) {
+    const int bstart = wv * 256 + b * 64, bend = bstart + 64;
+    u32 v = vq[b];
+    for (int it = 0; it < 7; it++) {  // (six squarings cover 64 pixels)
+      const int j = (int)(v & 0xFFFFu);
+      const bool in = j < bend;  // (j > r >= bstart)
+      if (__ballot(in) == 0) break;
+      const u32 t = (u32)__builtin_amdgcn_ds_bpermute(((in ? j - bstart : lane) & 63) << 2, (int)v);
+      v = in ? t : v;
     }
-    // only the paths from the HALO possible entry points are asked for: ~110 runs per tile, seven steps as a rule
-    // (the verdict rides on the iteration's own barrier: one flag per wave, two sets in turn)
-    const u64 live = __ballot(tid < HALO && (v0 & 0xFFFFu) < (u32)TILE);
-    if (lane_id() == 0) more[it & 1][tid >> 6] = live != 0;
-    __syncthreads();
-    cur ^= 1;
-    if (!(more[it & 1][0] | more[it & 1][1] | more[it & 1][2] | more[it & 1][3])) break;
+#pragma unroll
+    for (int b2 = b + 1; b2 < 4; b2++) {  // a later block of my quarter: its answers are final (they point past the quarter)
+      const int idx = (int)(v & 0xFFFFu) - (wv * 256 + b2 * 64);
+      const bool in = idx >= 0 && idx < 64;
+      const u32 t = (u32)__builtin_amdgcn_ds_bpermute((idx & 63) << 2, (int)vq[b2]);
+      v = in ? t : v;
+    }
+    vq[b] = v;
   }
+#pragma unroll
+  for (int k = 0; k < 4; k++) lp[wv * 256 + k * 64 + lane] = vq[k];
+  __syncthreads();
   if (tid < HALO) {
-    const u32 v = lp[cur][tid];
+    u32 v = lp[tid];
+#pragma unroll
+    for (int q = 0; q < 3; q++) {  // quarters 1, 2, 3
+      const u32 j = v & 0xFFFFu;
+      if (j < (u32)TILE) v = lp[j];
+    }
     const int j = (int)(v & 0xFFFFu);
     u8* row = exitmap + ((size_t)slot * g.ntiles + tile) * 512;
     row[2 * tid] = (u8)(j == EXITED ? 255 : j - TILE);  // 255: the path ended inside this tile (frame end)
