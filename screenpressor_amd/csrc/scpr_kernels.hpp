@@ -339,8 +339,9 @@ __device__ __forceinline__ int block_excl_scan(int v, int* tot, int* wsum /*shar
 // tilecnt: {runs, literal runs} per tile.   runrec: rel_start | type<<10 | n<<16
 __global__ __launch_bounds__(256) void k_tiles(const u8* __restrict__ planes, Geom g, const int* __restrict__ slots, u8* __restrict__ exitmap, u8* __restrict__ tnmap, u8* __restrict__ nlong) {
   __shared__ u64 fm[4][24];
-  __shared__ u8 ty[TILE];
-  __shared__ u32 lp[TILE];  // a pixel's way out of its quarter of the tile: successor | start of the run it sits in << 16
+  __shared__ __attribute__((aligned(4))) u8 ty[TILE];
+  __shared__ u16 nzw[4][26];
+  __shared__ __attribute__((aligned(16))) u32 lp[TILE];  // a pixel's way out of its quarter of the tile: successor << 16 | start of the run it sits in
   // Workgroups go round the eight XCDs in launch order, and every XCD has its own L2: tile t reads the row above its pixels,
   // which tile t - W / 1024 (the one before the last, at 1080p) has just read.  The launch order is therefore remapped so
   // that each XCD gets one contiguous eighth of the (frame, tile) space - neighbouring tiles meet in the same L2 instead
@@ -357,6 +358,46 @@ __global__ __launch_bounds__(256) void k_tiles(const u8* __restrict__ planes, Ge
   const int ty0 = __builtin_amdgcn_readfirstlane(tstart / g.W), tx0 = __builtin_amdgcn_readfirstlane(tstart - ty0 * g.W);
   if (tid < 4 * 24) ((u64*)fm)[tid] = 0;
   __syncthreads();
+  if (g.S == 3 * g.W && g.workers == 1) {
+    // Rows without padding (every width that is a multiple of four): the plane IS the raster - pixel p at byte 3 p, its left
+    // neighbour the pixel before it also in column 0 (the last one of the row above, :881), the row above W pixels back - so
+    // a lane takes FOUR pixels from two 16-byte loads (they and the one before them; the same above) with no row or column in
+    // sight, and adds its four bits per predictor to the maps with one LDS `or` each.  36 instructions per pixel; the
+    // pixel-at-a-time form below (any stride, worker bands) is 95, and this loop was 60 % of the kernel.
+    for (int k = 0; k < 2; k++) {
+      const int q = k * 256 + tid, r0 = 4 * q, p = tstart + r0;  // pixels r0 .. r0 + 3 of the tile (and its halo)
+      if (q < (TILE + HALO + 4) / 4 && p < g.NP) {  // (a lane's last pixels may lie past the frame: their loads stay inside the plane's slack, their bits are dropped)
+        u32 e[4], a[4];
+        __builtin_memcpy(e, plane + (size_t)p * 3 - 3, 16);
+        __builtin_memcpy(a, plane + (size_t)(p - g.W) * 3 - 3, 16);
+        const u32 M = 0xFFFFFFu;
+        const u32 c[5] = {e[0] & M, __builtin_amdgcn_alignbit(e[1], e[0], 24) & M, __builtin_amdgcn_alignbit(e[2], e[1], 16) & M, e[2] >> 8, e[3] & M};
+        const u32 t[5] = {a[0] & M, __builtin_amdgcn_alignbit(a[1], a[0], 24) & M, __builtin_amdgcn_alignbit(a[2], a[1], 16) & M, a[2] >> 8, a[3] & M};
+        u32 nl = 0, nt = 0, ng = 0, ntl = 0, types = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const u32 vc = c[i + 1], vl = c[i], vt = t[i + 1], vtl = t[i];
+          const bool in = p + i < g.NP;
+          const bool e_l = in && vc == vl, e_t = in && vc == vt, e_tl = in && vc == vtl;
+          bool gr = in;
+#pragma unroll
+          for (int b = 0; b < 24; b += 8) gr &= (int)((vc >> b) & 255) == (int)((vl >> b) & 255) + (int)((vt >> b) & 255) - (int)((vtl >> b) & 255);
+          nl |= e_l ? 1u << i : 0u;
+          nt |= e_t ? 1u << i : 0u;
+          ng |= gr ? 1u << i : 0u;
+          ntl |= e_tl ? 1u << i : 0u;
+          types |= (u32)(e_l ? 1 : e_tl ? 5 : e_t ? 2 : gr ? 4 : 0) << (8 * i);
+        }
+        if (r0 < TILE) ((u32*)ty)[q] = types;
+        const int sh = (q & 7) * 4;  // bits r0 .. r0 + 3 of the map: word r0 >> 5
+        u32* f32 = (u32*)fm;
+        atomicOr(&f32[0 * 48 + (q >> 3)], nl << sh);
+        atomicOr(&f32[1 * 48 + (q >> 3)], nt << sh);
+        atomicOr(&f32[2 * 48 + (q >> 3)], ng << sh);
+        atomicOr(&f32[3 * 48 + (q >> 3)], ntl << sh);
+      }
+    }
+  } else
   for (int k = 0; k < 5; k++) {
     const int r = k * 256 + tid, p = tstart + r;
     int type = 0, fits = 0;
@@ -377,6 +418,21 @@ __global__ __launch_bounds__(256) void k_tiles(const u8* __restrict__ planes, Ge
     }
   }
   __syncthreads();
+  // The first pixel at or after the start of map word w that does NOT fit predictor b (the next five words are enough: a run is at
+  // most 255 pixels): with it the length of the run that would start at a pixel is its own word's trailing ones or, if those reach
+  // the word's end, a difference - no loop over words, whose trip count differed from lane to lane (a wave went round it as often
+  // as its longest run needed, most waves at least once).
+  if (tid < 4 * 25) {
+    const int b = tid / 25, w = tid - b * 25;
+    int pos = 64 * 24;
+#pragma unroll
+    for (int k = 4; k >= 0; k--) {
+      const u64 m = w + k < 24 ? ~fm[b][w + k] : 0ull;
+      pos = m ? 64 * (w + k) + __builtin_ctzll(m) : pos;
+    }
+    nzw[b][w] = (u16)pos;
+  }
+  __syncthreads();
   // Where does the path that ENTERS the tile at offset e < HALO leave it, and in a run that began where?  Every pixel r has a
   // successor j(r) in (r, r + 255] - the start of the next run if a run started at r.  Rounds 1-4 squared the successor function
   // over the whole tile (pointer doubling in LDS: two arrays of 1024 words, up to ten rounds of four gathers and a barrier; it
@@ -388,39 +444,58 @@ __global__ __launch_bounds__(256) void k_tiles(const u8* __restrict__ planes, Ge
   // and the quarters are chained through LDS afterwards: an entry point is in quarter 0, a run is at most 255 long, so its
   // path visits each later quarter once - three gathers.  One barrier, a third of the LDS operations.
   const int lane = lane_id(), wv = tid >> 6;
-  u32 vq[4];  // block b of my quarter, pixel 256 wv + 64 b + lane: successor | start of the run it sits in << 16
+  u32 vq[4];  // block b of my quarter, pixel 256 wv + 64 b + lane: successor << 16 | start of the run it sits in
+  {
+    // the successors: a lane takes four pixels in a row (their types one word, their byte for k_runs one store) and hands them
+    // to the block order below through the wave's own quarter of `lp`
+    const int r0 = wv * 256 + 4 * lane, p0 = tstart + r0;
+    u32 jv[4] = {((u32)EXITED << 16) | (u32)r0, ((u32)EXITED << 16) | (u32)(r0 + 1), ((u32)EXITED << 16) | (u32)(r0 + 2), ((u32)EXITED << 16) | (u32)(r0 + 3)};
+    if (p0 < g.NP) {
+      const u32 types = ((const u32*)ty)[r0 >> 2];
+      const size_t at = ((size_t)slot * g.ntiles + tile) * TILE + r0;
+      u32 tn = 0;
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const int r = wv * 256 + k * 64 + lane, p = tstart + r;
-    int j = EXITED;
-    if (p < g.NP) {
-      int n = ones_from(fm[fit_bit_of_type(ty[r])], r + 1, HALO - 1);
-      j = (p + 1 + n >= g.NP) ? EXITED : r + 1 + n;
-      // for k_runs: type and length of the run that would start here (it never looks at a pixel again) - one byte,
-      // type | min(n, 31) << 3; the few lengths from 31 up are in a second array that is written (and read) only there
-      const size_t at = ((size_t)slot * g.ntiles + tile) * TILE + r;
-      tnmap[at] = (u8)((u32)ty[r] | ((u32)min(n, 31) << 3));
-      if (n >= 31) nlong[at] = (u8)n;
+      for (int i = 0; i < 4; i++) {
+        const u32 t = (types >> (8 * i)) & 255u;
+        // for k_runs: type and length of the run that would start here (it never looks at a pixel again) - one byte,
+        // type | min(n, 31) << 3; the few lengths from 31 up are in a second array that is written (and read) only there
+        // (the map of the predictor the type goes by, fit_bit_of_type as a table in a constant: types differ from lane to lane)
+        const u32 pb = (0x320100u >> (4u * t)) & 3u;
+        const int st = r0 + i + 1, w = st >> 6, o = st & 63;
+        const u64 inv = ~(fm[pb][w] >> o);
+        const int z = inv ? __builtin_ctzll(inv) : 64;
+        const int n = min(z < 64 - o ? z : (int)nzw[pb][w + 1] - st, HALO - 1);
+        if (p0 + i < g.NP) {
+          jv[i] = ((u32)((p0 + i + 1 + n >= g.NP) ? EXITED : r0 + i + 1 + n) << 16) | (u32)(r0 + i);
+          if (n >= 31) nlong[at + i] = (u8)n;
+        }
+        tn |= (t | ((u32)min(n, 31) << 3)) << (8 * i);
+      }
+      *(u32*)(tnmap + at) = tn;  // (bytes of pixels past the frame's end are never read)
     }
-    vq[k] = (u32)j | ((u32)r << 16);
+    *(uint4*)&lp[r0] = make_uint4(jv[0], jv[1], jv[2], jv[3]);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (LDS is served in order within a wave: what other lanes wrote is there)
+#pragma unroll
+    for (int k = 0; k < 4; k++) vq[k] = lp[wv * 256 + k * 64 + lane];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (the quarter is rewritten below, after the reads)
   }
+  // (the word is successor << 16 | run start: "has not left the block" is one unsigned compare of the whole word, and the lane to
+  // ask is bits 16..21 - `ds_bpermute` takes a byte address and uses bits 2..7 of it, so word >> 14 is the address as it stands)
 #pragma unroll
   for (int b = 3; b >= 0; b--) {
-    const int bstart = wv * 256 + b * 64, bend = bstart + 64;
+    const u32 bend = (u32)(wv * 256 + b * 64 + 64) << 16;
     u32 v = vq[b];
     for (int it = 0; it < 7; it++) {  // (six squarings cover 64 pixels)
-      const int j = (int)(v & 0xFFFFu);
-      const bool in = j < bend;  // (j > r >= bstart)
+      const bool in = v < bend;  // (successor > pixel >= the block's first)
       if (__ballot(in) == 0) break;
-      const u32 t = (u32)__builtin_amdgcn_ds_bpermute(((in ? j - bstart : lane) & 63) << 2, (int)v);
+      const u32 t = (u32)__builtin_amdgcn_ds_bpermute((int)(v >> 14), (int)v);
       v = in ? t : v;
     }
+    const u32 blk = v >> 22, at = v >> 14;  // successor / 64: the block it lies in
 #pragma unroll
     for (int b2 = b + 1; b2 < 4; b2++) {  // a later block of my quarter: its answers are final (they point past the quarter)
-      const int idx = (int)(v & 0xFFFFu) - (wv * 256 + b2 * 64);
-      const bool in = idx >= 0 && idx < 64;
-      const u32 t = (u32)__builtin_amdgcn_ds_bpermute((idx & 63) << 2, (int)vq[b2]);
-      v = in ? t : v;
+      const u32 t = (u32)__builtin_amdgcn_ds_bpermute((int)at, (int)vq[b2]);
+      v = blk == (u32)(wv * 4 + b2) ? t : v;
     }
     vq[b] = v;
   }
@@ -431,13 +506,13 @@ __global__ __launch_bounds__(256) void k_tiles(const u8* __restrict__ planes, Ge
     u32 v = lp[tid];
 #pragma unroll
     for (int q = 0; q < 3; q++) {  // quarters 1, 2, 3
-      const u32 j = v & 0xFFFFu;
+      const u32 j = v >> 16;
       if (j < (u32)TILE) v = lp[j];
     }
-    const int j = (int)(v & 0xFFFFu);
+    const int j = (int)(v >> 16);
     u8* row = exitmap + ((size_t)slot * g.ntiles + tile) * 512;
-    row[2 * tid] = (u8)(j == EXITED ? 255 : j - TILE);  // 255: the path ended inside this tile (frame end)
-    row[2 * tid + 1] = ty[v >> 16];
+    // 255: the path ended inside this tile (frame end); the type of the run that crosses the border
+    *(u16*)(row + 2 * tid) = (u16)((u32)(u8)(j == EXITED ? 255 : j - TILE) | ((u32)ty[v & 0xFFFFu] << 8));
   }
 }
 
