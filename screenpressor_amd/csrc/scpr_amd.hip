@@ -308,7 +308,7 @@ static int ensure_enc_scratch(scpr_codec* c, size_t n) {
   const Geom& g = c->g;
   const size_t ns = n + 1;
   HIPCHK(c->exitmap.reserve(ns * g.ntiles * 512));
-  c->tn_half = ns * g.ntiles * TILE;  // type | short length per pixel, then (same size, written only where needed) the long lengths
+  c->tn_half = ns * g.ntiles * TILE;  // type | length of the run that would start at a pixel: 16 bits per pixel
   HIPCHK(c->tnmap.reserve(c->tn_half * 2));
   HIPCHK(c->entry.reserve(ns * g.ntiles * 2));
   HIPCHK(c->runrec.reserve(ns * g.ntiles * TILE * 4));
@@ -623,15 +623,15 @@ static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int n
     HIPCHK(h2d(c, c->genlist.p, igens.data(), ni * 4, st));
     HIPCHK(h2d(c, c->fidx.p, ifidx.data(), ni * 4, st));
     stage_begin(c, ST_CLASSIFY);
-    hipLaunchKernelGGL(k_tiles, dim3(g.ntiles, ni), dim3(256), 0, st, planes, g, d_slots, c->exitmap.as<u8>(), c->tnmap.as<u8>(), c->tnmap.as<u8>() + (size_t)c->tn_half);
+    hipLaunchKernelGGL(k_tiles, dim3(g.ntiles, ni), dim3(256), 0, st, planes, g, d_slots, c->exitmap.as<u8>(), c->tnmap.as<u16>());
     hipLaunchKernelGGL(k_entries, dim3(ni), dim3(64), 0, st, c->exitmap.as<u8>(), c->entry.as<u8>(), g, d_slots);
-    // k_runs walks one tile per lane, a cache line of the type/length map at a time: with every CU full of its waves the lines
-    // in use (8 MB per XCD) do not fit the XCD's 4 MB L2 and are fetched three times over.  Two workgroups per CU, each taking
-    // its pairs grid-stride: each line comes in once (profiles/: FETCH_SIZE 1.98 GB -> 0.40 GB per launch, +0.2 ms).
-    static const int runs_per_cu = getenv("SCPR_RUNS_PER_CU") ? atoi(getenv("SCPR_RUNS_PER_CU")) : 2;
+    // k_runs walks one tile per lane, a cache line of the type/length map at a time, its (frame, group of 256 tiles) pairs taken
+    // grid-stride by a fixed number of workgroups: with every CU full of its waves the lines in use did not fit the XCD's L2
+    // and were fetched three times over (round 3: two per CU).  Round 5, 16-bit map: 2 / 4 / 8 per CU = 1.59 / 1.45 / 1.50 ms.
+    static const int runs_per_cu = getenv("SCPR_RUNS_PER_CU") ? atoi(getenv("SCPR_RUNS_PER_CU")) : 4;
     const int run_groups = ((g.ntiles + 255) / 256) * ni;
-    hipLaunchKernelGGL(k_runs, dim3((unsigned)std::max(1, std::min(run_groups, runs_per_cu * c->ncu))), dim3(256), 0, st, g, d_slots, ni, c->entry.as<u8>(), c->tnmap.as<u8>(),
-                       c->tnmap.as<u8>() + (size_t)c->tn_half, c->runrec.as<u32>(), c->tilecnt.as<u32>());
+    hipLaunchKernelGGL(k_runs, dim3((unsigned)std::max(1, std::min(run_groups, runs_per_cu * c->ncu))), dim3(256), 0, st, g, d_slots, ni, c->entry.as<u8>(), c->tnmap.as<u16>(),
+                       c->runrec.as<u32>(), c->tilecnt.as<u32>());
     hipLaunchKernelGGL(k_header, dim3(ni), dim3(64), 0, st, planes, g, d_slots, c->hdrrec.as<u32>(), c->hdrcnt.as<u32>());
     stage_end(c, ST_CLASSIFY);
     stage_begin(c, ST_SCAN);

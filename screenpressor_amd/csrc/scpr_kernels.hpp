@@ -337,7 +337,7 @@ __device__ __forceinline__ int block_excl_scan(int v, int* tot, int* wsum /*shar
 // exit map row: for every entry offset e < 255: [2e] = offset at which the path
 // leaves into the next tile, [2e+1] = type of the run that crosses the border.
 // tilecnt: {runs, literal runs} per tile.   runrec: rel_start | type<<10 | n<<16
-__global__ __launch_bounds__(256) void k_tiles(const u8* __restrict__ planes, Geom g, const int* __restrict__ slots, u8* __restrict__ exitmap, u8* __restrict__ tnmap, u8* __restrict__ nlong) {
+__global__ __launch_bounds__(256) void k_tiles(const u8* __restrict__ planes, Geom g, const int* __restrict__ slots, u8* __restrict__ exitmap, u16* __restrict__ tnmap) {
   __shared__ u64 fm[4][24];
   __shared__ __attribute__((aligned(4))) u8 ty[TILE];
   __shared__ u16 nzw[4][26];
@@ -453,25 +453,23 @@ __global__ __launch_bounds__(256) void k_tiles(const u8* __restrict__ planes, Ge
     if (p0 < g.NP) {
       const u32 types = ((const u32*)ty)[r0 >> 2];
       const size_t at = ((size_t)slot * g.ntiles + tile) * TILE + r0;
-      u32 tn = 0;
+      u32 tn[4];
 #pragma unroll
       for (int i = 0; i < 4; i++) {
         const u32 t = (types >> (8 * i)) & 255u;
-        // for k_runs: type and length of the run that would start here (it never looks at a pixel again) - one byte,
-        // type | min(n, 31) << 3; the few lengths from 31 up are in a second array that is written (and read) only there
+        // for k_runs: type and length of the run that would start here (it never looks at a pixel again) - type | n << 3, 16 bits
+        // (rounds 2-4: one byte with the length cut at 31 and a second, sparse array for the longer ones - whose scattered byte
+        // writes cost as much traffic as the second byte does, and whose reads were a trip to memory inside k_runs' walk)
         // (the map of the predictor the type goes by, fit_bit_of_type as a table in a constant: types differ from lane to lane)
         const u32 pb = (0x320100u >> (4u * t)) & 3u;
         const int st = r0 + i + 1, w = st >> 6, o = st & 63;
         const u64 inv = ~(fm[pb][w] >> o);
         const int z = inv ? __builtin_ctzll(inv) : 64;
         const int n = min(z < 64 - o ? z : (int)nzw[pb][w + 1] - st, HALO - 1);
-        if (p0 + i < g.NP) {
-          jv[i] = ((u32)((p0 + i + 1 + n >= g.NP) ? EXITED : r0 + i + 1 + n) << 16) | (u32)(r0 + i);
-          if (n >= 31) nlong[at + i] = (u8)n;
-        }
-        tn |= (t | ((u32)min(n, 31) << 3)) << (8 * i);
+        if (p0 + i < g.NP) jv[i] = ((u32)((p0 + i + 1 + n >= g.NP) ? EXITED : r0 + i + 1 + n) << 16) | (u32)(r0 + i);
+        tn[i] = t | ((u32)n << 3);
       }
-      *(u32*)(tnmap + at) = tn;  // (bytes of pixels past the frame's end are never read)
+      *(uint2*)(tnmap + at) = make_uint2(tn[0] | (tn[1] << 16), tn[2] | (tn[3] << 16));  // (entries of pixels past the frame's end are never read)
     }
     *(uint4*)&lp[r0] = make_uint4(jv[0], jv[1], jv[2], jv[3]);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (LDS is served in order within a wave: what other lanes wrote is there)
@@ -545,23 +543,26 @@ __global__ __launch_bounds__(64) void k_entries(const u8* __restrict__ exitmap, 
 }
 
 // The runs of every tile, from where k_entries says the frame's path enters it: one LANE per tile walks the path (the type and
-// the length of the run that would start at any pixel were written by the first pass: one byte load per step),
-// ~110 steps on average, and writes the tile's run records in order.  The tiles of a frame are independent once their entry
-// points are known, and a frame has 2000 of them: the walk needs no pointer doubling (the second k_tiles pass it replaces
-// re-classified every pixel and squared the successor function nine times to mark the same path).
+// the length of the run that would start at any pixel were written by the first pass: one byte per step), ~110 steps on average,
+// and writes the tile's run records in order.  The tiles of a frame are independent once their entry points are known, and a
+// frame has 2000 of them: the walk needs no pointer doubling (the second k_tiles pass it replaces re-classified every pixel and
+// squared the successor function nine times to mark the same path).
 // tilecnt: {runs, literal runs} per tile.   runrec: rel_start | type<<10 | n<<16
 // A fixed number of workgroups (two per CU: the host's choice) take the (frame, group of 256 tiles) pairs in launch order,
 // grid-stride: the lines of the type/length map being walked at any moment are those of ~512 pairs and stay in the L2.  (The
 // first form bought the same limit with 65 000 bytes of LDS it never touched - and starved beside another kernel that holds LDS.)
-__global__ __launch_bounds__(256) void k_runs(Geom g, const int* __restrict__ slots, int nslots, const u8* __restrict__ entry, const u8* __restrict__ tnmap, const u8* __restrict__ nlong,
-                                              u32* __restrict__ runrec, u32* __restrict__ tilecnt) {
+// Round 5: the map is 16 bits per pixel (type | length << 3); rounds 2-4 had a byte with the length cut at 31 and a second, sparse
+// array for the longer ones, i.e. a second dependent load in the walk for every run of 32 pixels or more.  (Also tried this
+// round: the maps of 32 tiles copied into LDS and walked there by 32 lanes - 4.6 ms instead of 1.8: the walk is ~45 instructions
+// per step on lanes that finish at very different times, and LDS holds a sixth of the tiles that registers and the L2 keep in flight.)
+__global__ __launch_bounds__(256) void k_runs(Geom g, const int* __restrict__ slots, int nslots, const u8* __restrict__ entry, const u16* __restrict__ tnmap, u32* __restrict__ runrec,
+                                              u32* __restrict__ tilecnt) {
  const int groups = (g.ntiles + 255) / 256;
  for (int wk = blockIdx.x; wk < groups * nslots; wk += gridDim.x) {
   const int slot = slots[wk / groups], tile = (wk % groups) * 256 + threadIdx.x;
   if (tile >= g.ntiles) continue;
   const size_t ti = (size_t)slot * g.ntiles + tile;
-  const u8* tn = tnmap + ti * TILE;
-  const u8* nl = nlong + ti * TILE;
+  const u16* tn = tnmap + ti * TILE;
   u32* rec = runrec + ti * TILE;
   const int tstart = g.p0 + tile * TILE;
   int r = entry[ti * 2], cnt = 0, lit = 0;  // 255: a run from an earlier tile already reached the frame end
@@ -570,8 +571,7 @@ __global__ __launch_bounds__(256) void k_runs(Geom g, const int* __restrict__ sl
     while (r < TILE && tstart + r < g.NP) {
       const u32 v = tn[r];
       const int t = (int)(v & 7u);
-      int n = (int)(v >> 3);
-      if (n == 31) n = nl[r];
+      const int n = (int)(v >> 3);
       int j = r + 1 + n;
       int len = j - r;
       if (tstart + j >= g.NP) {  // the run reaches the end of the frame
