@@ -852,7 +852,7 @@ static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int n
     }
     // chain starts from the sorted keys - and the proof that they ARE sorted: a pair out of order sets bit 5 of the error word, which
     // keeps the chain kernels from following chain lengths made of garbage (k_colour_chain_w, k_chain_lists) and ends the call
-    hipLaunchKernelGGL(k_chain_starts, dim3((unsigned)((Ctot + 256) / 256)), dim3(256), 0, st, c->keys[0].as<u32>(), (u32)Ctot, (u32)nchains, c->cstart.as<u32>(), c->err.as<u32>());
+    hipLaunchKernelGGL(k_chain_starts, dim3((unsigned)((Ctot + 1024) / 1024)), dim3(256), 0, st, c->keys[0].as<u32>(), (u32)Ctot, (u32)nchains, c->cstart.as<u32>(), c->err.as<u32>());
   }
   stage_end(c, ST_SORT);
   if (getenv("SCPR_DEBUG_KEYS") && Ctot) {

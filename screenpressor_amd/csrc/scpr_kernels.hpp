@@ -744,17 +744,39 @@ __device__ __forceinline__ void emit_colour(u32 gen, u32 pix, u32 prev_g, u32 pr
 // which has returned unsorted output, and the proof stayed when scpr_ctxsort.hpp took over): a key below its predecessor - or
 // one that names no chain of this call - sets bit 5 of *err and writes nothing.
 __global__ __launch_bounds__(256) void k_chain_starts(const u32* __restrict__ skeys, u32 n, u32 nchains, u32* __restrict__ cstart, u32* __restrict__ err) {
-  const u32 i = blockIdx.x * 256 + threadIdx.x;
-  if (i > n) return;
+  // four positions per thread (one 16-byte load and the key before them); position n is the sentinel
+  const u32 i0 = (blockIdx.x * 256 + threadIdx.x) * 4;
   auto chain = [](u32 key) { return (key >> 22) * (u32)NCOLCTX + ((key >> 8) & 0x3FFFu); };
-  const u32 ki = i < n ? skeys[i] : 0u, kp = i > 0 ? skeys[i - 1] : 0u;
-  const u32 qi = i < n ? chain(ki) : nchains;
-  const u32 q0 = i > 0 ? chain(kp) + 1 : 0u;
-  if ((i > 0 && i < n && (ki >> 8) < (kp >> 8)) || qi > nchains) {
-    atomicOr(err, 32u);
-    return;
+  u32 k[5] = {0u, 0u, 0u, 0u, 0u};  // keys i0 - 1 .. i0 + 3
+  if (i0 + 4 <= n) {
+    const uint4 v = *(const uint4*)(skeys + i0);
+    k[1] = v.x, k[2] = v.y, k[3] = v.z, k[4] = v.w;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; j++) k[1 + j] = i0 + j < n ? skeys[i0 + j] : 0u;
   }
-  for (u32 q = q0; q <= qi; q++) cstart[q] = i;
+  if (i0 > 0 && i0 <= n) k[0] = skeys[i0 - 1];
+  const int lane = threadIdx.x & 63;
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const u32 i = i0 + (u32)j;
+    const bool live = i <= n;
+    const u32 qi = i < n ? chain(k[1 + j]) : nchains;
+    const u32 q0 = i > 0 ? chain(k[j]) + 1 : 0u;
+    const bool b = (i > 0 && i < n && (k[1 + j] >> 8) < (k[j] >> 8)) || qi > nchains;
+    bad |= b && live;
+    // the gaps are filled by the whole wave, one boundary after the other (a lane by itself went round a loop of thousands of
+    // empty chains wherever two used contexts lie far apart, with 63 lanes waiting for it)
+    u64 todo = __ballot(live && !b && q0 <= qi);
+    while (todo) {
+      const int l = __builtin_ctzll(todo);
+      todo &= todo - 1;
+      const u32 a = (u32)__builtin_amdgcn_readlane((int)q0, l), e = (u32)__builtin_amdgcn_readlane((int)qi, l), at = (u32)__builtin_amdgcn_readlane((int)i, l);
+      for (u32 q = a + (u32)lane; q <= e; q += 64) cstart[q] = at;
+    }
+  }
+  if (bad) atomicOr(err, 32u);
 }
 __global__ void k_debug_swap(u32* a, u32 i, u32 j) {  // scpr_debug_inject(2)
   const u32 t = a[i];
