@@ -787,9 +787,11 @@ static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int n
   // 17.5 (k_fixed_chain2's waves wait for each other within their window and cost the partition beside them 0.9 ms); a higher
   // stream priority for the main stream changes nothing (tools/r5/enc_stages.sh).
   const int buf_in = c->live_buf, buf_out = ngens > 1 ? 1 - c->live_buf : c->live_buf;
-  // Where exactly: behind the colour partition's FIRST pass (tools/r5/fork_ab.sh, 1080p encode: in front of the partition 17.35 ms,
-  // behind its first pass 17.05, behind both 17.75; 4K key frames 34.6 / 34.4 / 35.6).  SCPR_FORK_AT = 0 / 1 / 2 for A/B timing.
-  static const int fork_at = getenv("SCPR_FORK_AT") ? atoi(getenv("SCPR_FORK_AT")) : 1;
+  // Where exactly: in FRONT of the colour partition since its passes and k_chain_starts got faster (tools/r5/fork_ab.sh, 1080p encode:
+  // in front of the partition 15.2 ms, behind its first pass 15.6-15.7, behind both 15.7; 4K key frames 40.7 / 40.1 / 40.9 GPix/s;
+  // with the slower partition of earlier in the round the middle position had been the best: 17.35 / 17.05 / 17.75 ms).
+  // SCPR_FORK_AT = 0 / 1 / 2 for A/B timing.
+  static const int fork_at = getenv("SCPR_FORK_AT") ? atoi(getenv("SCPR_FORK_AT")) : 0;
   auto fork_fixed_branch = [&]() -> int {
     hipStream_t s2 = getenv("SCPR_SERIAL_CHAINS") ? st : c->stream2;  // (design aid: the two chain stages one after the other, to time each alone)
     HIPCHK(hipEventRecord(c->ev_fork, st));

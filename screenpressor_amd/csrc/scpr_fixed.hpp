@@ -114,15 +114,22 @@ constexpr int SCAN_T = 1024;
 __global__ __launch_bounds__(SCAN_T) void k_part_scan(const u32* __restrict__ blkcnt, u32* __restrict__ blkoff, u32 nblk, u32* __restrict__ ctotal) {
   // tiles of SCAN_T counts, read and written side by side (round 5: a thread used to walk its own run of ~32 counts, 128 bytes
   // apart from its neighbour's - 0.46 ms for the headline's 33 000 blocks per model, on the longer of the encoder's two branches)
+  // (eight counts per thread and round: the headline's 33 000 blocks per model are five rounds - each round is a trip to memory
+  // and two barriers, and the kernel runs beside the colour partition, which leaves it little of the machine)
+  constexpr int V = 8;
   __shared__ u32 wtot[SCAN_T / 64];
   const int c = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
   const u32* in = blkcnt + (size_t)c * (nblk + 1);
   u32* out = blkoff + (size_t)c * (nblk + 1);
   u32 carry = 0;
-  for (u32 base = 0; base < nblk; base += SCAN_T) {
-    const u32 i = base + (u32)t;
-    const u32 v = i < nblk ? in[i] : 0u;
-    const u32 incl = (u32)wave_incl_scan((int)v);
+  for (u32 base = 0; base < nblk; base += SCAN_T * V) {
+    const u32 i0 = base + (u32)t * V;
+    u32 v[V], sum = 0;
+#pragma unroll
+    for (int k = 0; k < V; k++) v[k] = i0 + k < nblk ? in[i0 + k] : 0u;
+#pragma unroll
+    for (int k = 0; k < V; k++) sum += v[k];
+    const u32 incl = (u32)wave_incl_scan((int)sum);
     if (lane == 63) wtot[w] = incl;
     __syncthreads();
     u32 before = 0, all = 0;
@@ -132,7 +139,12 @@ __global__ __launch_bounds__(SCAN_T) void k_part_scan(const u32* __restrict__ bl
       before += q < w ? x : 0u;
       all += x;
     }
-    if (i < nblk) out[i] = carry + before + incl - v;
+    u32 run = carry + before + incl - sum;
+#pragma unroll
+    for (int k = 0; k < V; k++) {
+      if (i0 + k < nblk) out[i0 + k] = run;
+      run += v[k];
+    }
     carry += all;
     __syncthreads();
   }
