@@ -624,7 +624,7 @@ static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int n
     HIPCHK(h2d(c, c->fidx.p, ifidx.data(), ni * 4, st));
     stage_begin(c, ST_CLASSIFY);
     hipLaunchKernelGGL(k_tiles, dim3(g.ntiles, ni), dim3(256), 0, st, planes, g, d_slots, c->exitmap.as<u8>(), c->tnmap.as<u16>());
-    hipLaunchKernelGGL(k_entries, dim3(ni), dim3(64), 0, st, c->exitmap.as<u8>(), c->entry.as<u8>(), g, d_slots);
+    hipLaunchKernelGGL(k_entries, dim3(ni), dim3(256), 0, st, c->exitmap.as<u8>(), c->entry.as<u8>(), g, d_slots);
     // k_runs walks one tile per lane, a cache line of the type/length map at a time, its (frame, group of 256 tiles) pairs taken
     // grid-stride by a fixed number of workgroups: with every CU full of its waves the lines in use did not fit the XCD's L2
     // and were fetched three times over (round 3: two per CU).  Round 5, 16-bit map: 2 / 4 / 8 per CU = 1.59 / 1.45 / 1.50 ms.

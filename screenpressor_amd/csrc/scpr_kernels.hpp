@@ -516,25 +516,25 @@ __global__ __launch_bounds__(256) void k_tiles(const u8* __restrict__ planes, Ge
 
 // one wave per frame walks its tiles: entry[tile] = {offset of the first run
 // start inside the tile, type of the run active when the tile begins}
-__global__ __launch_bounds__(64) void k_entries(const u8* __restrict__ exitmap, u8* __restrict__ entry, Geom g, const int* __restrict__ slots) {
-  __shared__ u32 buf[64 * 128];
-  const int slot = slots[blockIdx.x], lane = threadIdx.x;
+__global__ __launch_bounds__(256) void k_entries(const u8* __restrict__ exitmap, u8* __restrict__ entry, Geom g, const int* __restrict__ slots) {
+  // (the exit maps of 64 tiles, 32 KB, are brought in by the whole workgroup with 16-byte loads - one wave with 4-byte loads took
+  // 0.2 of this kernel's 0.3 ms for them, between k_tiles and k_runs on the encoder's critical path - and walked by one lane)
+  __shared__ __attribute__((aligned(16))) u32 buf[64 * 128];
+  const int slot = slots[blockIdx.x], tid = threadIdx.x;
   int e = 0, tin = 0;
   for (int base = 0; base < g.ntiles; base += 64) {
     const int n = min(64, g.ntiles - base);
-    const u32* srcw = (const u32*)(exitmap + ((size_t)slot * g.ntiles + base) * 512);
-    for (int i = lane; i < n * 128; i += 64) buf[i] = srcw[i];
+    const uint4* srcw = (const uint4*)(exitmap + ((size_t)slot * g.ntiles + base) * 512);
+    for (int i = tid; i < n * 32; i += 256) ((uint4*)buf)[i] = srcw[i];
     __syncthreads();
-    if (lane == 0) {
+    if (tid == 0) {
       const u8* b8 = (const u8*)buf;
       for (int k = 0; k < n; k++) {
-        u8* o = entry + ((size_t)slot * g.ntiles + base + k) * 2;
-        o[0] = (u8)e;
-        o[1] = (u8)tin;
+        *(u16*)(entry + ((size_t)slot * g.ntiles + base + k) * 2) = (u16)((u32)e | ((u32)tin << 8));
         if (e < HALO) {
-          int ne = b8[k * 512 + 2 * e], nt = b8[k * 512 + 2 * e + 1];
-          e = ne;
-          tin = nt;
+          const u32 nx = ((const u16*)b8)[k * 256 + e];  // exit | type of the run that crosses << 8
+          e = (int)(nx & 255u);
+          tin = (int)(nx >> 8);
         }
       }
     }
