@@ -920,7 +920,12 @@ scpr_codec* scpr_create(int device) {
     int v = 0;
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0) c->ncu = v;
   }
-  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
+  // (SCPR_S2_PRIORITY, design aid: the fixed models' branch on a stream of another priority - -1 high, 1 low, as far as the device
+  // has them.  Measured, tools/r5/s2prio_ab.sh: 1080p encode 39.4-40.5 / 40.1-40.7 / 40.1-40.8 GPix/s, 4K 40.2 / 40.0 / 39.7: nothing.)
+  int s2prio = getenv("SCPR_S2_PRIORITY") ? atoi(getenv("SCPR_S2_PRIORITY")) : 0, plo = 0, phi = 0;
+  (void)hipDeviceGetStreamPriorityRange(&plo, &phi);
+  s2prio = s2prio < 0 ? phi : s2prio > 0 ? plo : 0;
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, s2prio) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
     delete c;
     return nullptr;
