@@ -625,13 +625,14 @@ static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int n
     stage_begin(c, ST_CLASSIFY);
     hipLaunchKernelGGL(k_tiles, dim3(g.ntiles, ni), dim3(256), 0, st, planes, g, d_slots, c->exitmap.as<u8>(), c->tnmap.as<u16>());
     hipLaunchKernelGGL(k_entries, dim3(ni), dim3(256), 0, st, c->exitmap.as<u8>(), c->entry.as<u8>(), g, d_slots);
-    // k_runs walks one tile per lane, a cache line of the type/length map at a time, its (frame, group of 256 tiles) pairs taken
-    // grid-stride by a fixed number of workgroups: with every CU full of its waves the lines in use did not fit the XCD's L2
-    // and were fetched three times over (round 3: two per CU).  Round 5, 16-bit map: 2 / 4 / 8 per CU = 1.59 / 1.45 / 1.50 ms.
-    static const int runs_per_cu = getenv("SCPR_RUNS_PER_CU") ? atoi(getenv("SCPR_RUNS_PER_CU")) : 4;
-    const int run_groups = ((g.ntiles + 255) / 256) * ni;
+    // k_runs walks one tile per lane, a cache line of the type/length map at a time; a fixed number of workgroups take the groups
+    // of 256 tiles grid-stride and hand their tiles to their lanes one at a time (scpr_kernels.hpp).  Workgroups per CU, 1080p x 300:
+    // 2 / 4 / 8 = 1.49 / 1.37 / 1.28 ms (tiles fixed to lanes, the form before: 1.59 / 1.45 / 1.50); classify stage 3.65 -> 3.52 ms.
+    static const int runs_per_cu = getenv("SCPR_RUNS_PER_CU") ? atoi(getenv("SCPR_RUNS_PER_CU")) : 8;
+    if (ni > KRUNS_MAXSLOTS) return SCPR_E_PARAM;  // (a chunk holds at most kMaxChunkGens generations)
+    const int run_groups = (int)(((size_t)g.ntiles * ni + 255) / 256);
     hipLaunchKernelGGL(k_runs, dim3((unsigned)std::max(1, std::min(run_groups, runs_per_cu * c->ncu))), dim3(256), 0, st, g, d_slots, ni, c->entry.as<u8>(), c->tnmap.as<u16>(),
-                       c->runrec.as<u32>(), c->tilecnt.as<u32>());
+                       c->runrec.as<u32>(), c->tilecnt.as<u32>(), (u32)std::min<unsigned long long>((0x100000000ull + (u32)g.ntiles - 1u) / (u32)g.ntiles, 0xFFFFFFFFull));
     hipLaunchKernelGGL(k_header, dim3(ni), dim3(64), 0, st, planes, g, d_slots, c->hdrrec.as<u32>(), c->hdrcnt.as<u32>());
     stage_end(c, ST_CLASSIFY);
     stage_begin(c, ST_SCAN);

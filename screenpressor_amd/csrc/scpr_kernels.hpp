@@ -555,20 +555,59 @@ __global__ __launch_bounds__(256) void k_entries(const u8* __restrict__ exitmap,
 // array for the longer ones, i.e. a second dependent load in the walk for every run of 32 pixels or more.  (Also tried this
 // round: the maps of 32 tiles copied into LDS and walked there by 32 lanes - 4.6 ms instead of 1.8: the walk is ~45 instructions
 // per step on lanes that finish at very different times, and LDS holds a sixth of the tiles that registers and the L2 keep in flight.)
+// (Round 5, second form) Tiles are handed out ONE AT A TIME: a frame's tiles hold anything from two runs to five hundred (flat
+// areas and text: median 20, mean 112, the busiest of 64 neighbours 308), and with a tile fixed to a lane a wave lasted as long as
+// its busiest tile, 2.8 times the average.  The loop below is flat - every round a lane either takes a step of its walk or, if its
+// tile is finished, writes the tile's tail and moves to its next one.  A workgroup owns the groups of 256 tiles b, b + nWG, ...
+// of the call (as before) and hands their tiles to its lanes in order from a counter in LDS; a lane's next tile was drawn two
+// moves ago and its entry point asked for one move ago, so that a move waits for LDS only (the frame list sits there too).
+// (First attempt: a global counter and the frame list in memory - a move then waits for two loads and an atomic, and with 64
+// lanes some lane moves in almost every round: 5.1 ms.)
+constexpr int KRUNS_MAXSLOTS = 4096;
 __global__ __launch_bounds__(256) void k_runs(Geom g, const int* __restrict__ slots, int nslots, const u8* __restrict__ entry, const u16* __restrict__ tnmap, u32* __restrict__ runrec,
-                                              u32* __restrict__ tilecnt) {
- const int groups = (g.ntiles + 255) / 256;
- for (int wk = blockIdx.x; wk < groups * nslots; wk += gridDim.x) {
-  const int slot = slots[wk / groups], tile = (wk % groups) * 256 + threadIdx.x;
-  if (tile >= g.ntiles) continue;
-  const size_t ti = (size_t)slot * g.ntiles + tile;
-  const u16* tn = tnmap + ti * TILE;
-  u32* rec = runrec + ti * TILE;
-  const int tstart = g.p0 + tile * TILE;
-  int r = entry[ti * 2], cnt = 0, lit = 0;  // 255: a run from an earlier tile already reached the frame end
+                                              u32* __restrict__ tilecnt, u32 rcp_ntiles) {
+  __shared__ int s_slots[KRUNS_MAXSLOTS];
+  __shared__ u32 s_ticket;
+  for (int i = threadIdx.x; i < nslots; i += 256) s_slots[i] = slots[i];
+  if (threadIdx.x == 0) s_ticket = 768u;
+  __syncthreads();
+  const u32 total = (u32)nslots * (u32)g.ntiles, nwg = gridDim.x, wg = blockIdx.x;
+  auto tile_of = [&](u32 t) -> u32 { return ((t >> 8) * nwg + wg) * 256u + (t & 255u); };  // the workgroup's t-th tile (>= total: none left)
+  auto index_of = [&](u32 T, int& tile) -> size_t {  // tile T of the call (frame T / ntiles of the list) -> its index in the maps
+    u32 fi = __umulhi(T, rcp_ntiles);
+    fi -= (fi * (u32)g.ntiles > T) ? 1u : 0u;        // (the reciprocal is rounded up ...
+    fi += ((fi + 1u) * (u32)g.ntiles <= T) ? 1u : 0u;  // ... or, for one tile per frame, cut to 32 bits)
+    tile = (int)(T - fi * (u32)g.ntiles);
+    return (size_t)s_slots[fi] * g.ntiles + (size_t)tile;
+  };
+  u32 T = tile_of(threadIdx.x), Tn = tile_of(256u + threadIdx.x), Tnn = tile_of(512u + threadIdx.x);
+  u32 en = 255u;  // entry point of tile Tn (255: a run from an earlier tile already reached the frame end - or no such tile)
+  size_t tin = 0;
+  int tilen = 0;
+  if (Tn < total) {
+    tin = index_of(Tn, tilen);
+    en = entry[tin * 2];
+  }
+  size_t ti = 0;
+  const u16* tn = nullptr;
+  u32* rec = nullptr;
+  int tstart = 0, r = TILE, cnt = 0, lit = 0;
   u32 q0 = 0, q1 = 0, q2 = 0;  // records leave four at a time (16-byte stores: a quarter of the partial-line writes)
-  if (r < HALO) {
-    while (r < TILE && tstart + r < g.NP) {
+  auto begin = [&](size_t idx, int tile, u32 e) __attribute__((always_inline)) {
+    ti = idx;
+    tn = tnmap + ti * TILE;
+    rec = runrec + ti * TILE;
+    tstart = g.p0 + tile * TILE;
+    r = e < (u32)HALO ? (int)e : TILE;
+    cnt = 0, lit = 0;
+  };
+  if (T < total) {
+    int tile0;
+    const size_t idx = index_of(T, tile0);
+    begin(idx, tile0, entry[idx * 2]);
+  }
+  while (T < total) {
+    if (r < TILE && tstart + r < g.NP) {
       const u32 v = tn[r];
       const int t = (int)(v & 7u);
       const int n = (int)(v >> 3);
@@ -587,17 +626,26 @@ __global__ __launch_bounds__(256) void k_runs(Geom g, const int* __restrict__ sl
       cnt++;
       lit += t == 0;
       r = j;
+    } else {
+      {  // the last, partial group of records
+        const int k = cnt & 3, base = cnt & ~3;
+        if (k > 0) rec[base] = q0;
+        if (k > 1) rec[base + 1] = q1;
+        if (k > 2) rec[base + 2] = q2;
+      }
+      tilecnt[ti * 2] = (u32)cnt;
+      tilecnt[ti * 2 + 1] = (u32)lit;
+      T = Tn;
+      if (T < total) begin(tin, tilen, en);
+      Tn = Tnn;
+      en = 255u;
+      if (Tn < total) {
+        tin = index_of(Tn, tilen);
+        en = entry[tin * 2];
+      }
+      Tnn = tile_of(atomicAdd(&s_ticket, 1u));
     }
   }
-  {  // the last, partial group of records
-    const int k = cnt & 3, base = cnt & ~3;
-    if (k > 0) rec[base] = q0;
-    if (k > 1) rec[base + 1] = q1;
-    if (k > 2) rec[base + 2] = q2;
-  }
-  tilecnt[ti * 2] = (u32)cnt;
-  tilecnt[ti * 2 + 1] = (u32)lit;
- }
 }
 
 // runs of identical pixels over raster pixels 0..W (first row and pixel (0,1)):
