@@ -153,6 +153,7 @@ __global__ __launch_bounds__(512) void k_rans_s(const u32* __restrict__ entries,
     return i >= 0 ? e[i] : 0xFFFFFFFFu;
   };
   if (!writer) {
+    __builtin_amdgcn_s_setprio(3);  // the chains in front of the writers at their SIMD's issue: 5.30 -> 5.21 ms with two blocks to a SIMD (tools/exp_rans.py), nothing with one
     rans_rec_t* const r0 = rec + (size_t)(none ? 0 : b) * (RANS_S_RING * RANS_S_TRIP);
     auto slot = [&](int t) { return r0 + (size_t)(t & (RANS_S_RING - 1)) * RANS_S_TRIP; };
     // the records of trips 0 and 1 before anything is coded; from then on trip t lays the records of trip t + 2 (their
