@@ -627,8 +627,9 @@ static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int n
     hipLaunchKernelGGL(k_entries, dim3(ni), dim3(256), 0, st, c->exitmap.as<u8>(), c->entry.as<u8>(), g, d_slots);
     // k_runs walks one tile per lane, a cache line of the type/length map at a time; a fixed number of workgroups take the groups
     // of 256 tiles grid-stride and hand their tiles to their lanes one at a time (scpr_kernels.hpp).  Workgroups per CU, 1080p x 300:
-    // 2 / 4 / 8 = 1.49 / 1.37 / 1.28 ms (tiles fixed to lanes, the form before: 1.59 / 1.45 / 1.50); classify stage 3.65 -> 3.52 ms.
-    static const int runs_per_cu = getenv("SCPR_RUNS_PER_CU") ? atoi(getenv("SCPR_RUNS_PER_CU")) : 8;
+    // 2 / 4 / 8 = 1.49 / 1.37 / 1.28 ms (tiles fixed to lanes, the form before: 1.59 / 1.45 / 1.50).  Four: with eight the map's lines
+    // in use no longer fit the L2 and the kernel fetches 3.9 GB instead of 1.8 for its 0.1 ms.
+    static const int runs_per_cu = getenv("SCPR_RUNS_PER_CU") ? atoi(getenv("SCPR_RUNS_PER_CU")) : 4;
     if (ni > KRUNS_MAXSLOTS) return SCPR_E_PARAM;  // (a chunk holds at most kMaxChunkGens generations)
     const int run_groups = (int)(((size_t)g.ntiles * ni + 255) / 256);
     hipLaunchKernelGGL(k_runs, dim3((unsigned)std::max(1, std::min(run_groups, runs_per_cu * c->ncu))), dim3(256), 0, st, g, d_slots, ni, c->entry.as<u8>(), c->tnmap.as<u16>(),
