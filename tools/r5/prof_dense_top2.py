@@ -1,0 +1,27 @@
+import ctypes as C, os, sys
+sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
+import numpy as np, torch
+from screenpressor_amd import codec as K
+from screenpressor_amd.synth import DesktopSequence
+K._LIB_PATH = os.path.join(os.environ["GRAFT_REPO_ROOT"], "screenpressor_amd", "variants", "libscpr_profx.so")
+W, H = 1920, 1080
+n, skip = int(sys.argv[1]), int(sys.argv[2])
+seq = DesktopSequence(W, H, seed=1)
+frames = torch.from_numpy(seq.frames(n)).cuda().reshape(n, -1)
+c = K.ScreenCodec(); c.Init(W, H, 32)
+pk, sizes, ft = c.CompressBatch(frames, [0] + [1] * (n - 1))
+L = K.load_library()
+off = int(np.sum(sizes[:skip + 1]))
+d = K.ScreenCodec(); d.Init(W, H, 32)
+d.DecompressBatch(pk[:off], sizes[:skip + 1], ft[:skip + 1])
+cp = (C.c_ulonglong * 32)()
+L.scpr_debug_cprof(cp)
+out = (C.c_ulonglong * 24)()
+L.scpr_debug_profile(out)
+r, dec = d.DecompressBatch(pk[off:].clone(), sizes[skip + 1:], ft[skip + 1:])
+torch.cuda.synchronize()
+L.scpr_debug_cprof(cp)
+L.scpr_debug_profile(out)
+o = list(cp); ev = list(out)[8:16]
+nf = n - skip - 1
+print("age %d..%d: per frame colour symbols %.0f, dense-table symbols %.0f; answered from the record %.0f; learnt %.0f; misses on a symbol 1024..2047 wide %.0f" % (skip + 1, n - 1, ev[0] / nf, o[24] / nf, o[25] / nf, o[26] / nf, o[27] / nf))
