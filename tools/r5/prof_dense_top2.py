@@ -1,3 +1,8 @@
+"""Design tool (GPU box): a P-frame's dense-table colour symbols at a given GOP age - how many the record answers, and how many
+miss on a symbol 1024..2047 wide (the count behind tools/experiments/r5_dense_top_quarter.patch).  Wants a PROFILE build with one
+more counter than the tree's, as screenpressor_amd/variants/libscpr_profx.so:
+    in WaveDec::colour, in front of the learning test:   xprof[3] += (t < 0) & (fr >= 1024u) & (fr < 2048u);
+usage: prof_dense_top2.py frames skip   (50 25: ages 26..49; 300 240: ages 241..299)"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
 import numpy as np, torch
