@@ -364,9 +364,11 @@ __global__ __launch_bounds__(256) void k_tiles(const u8* __restrict__ planes, Ge
     // a lane takes FOUR pixels from two 16-byte loads (they and the one before them; the same above) with no row or column in
     // sight, and adds its four bits per predictor to the maps with one LDS `or` each.  36 instructions per pixel; the
     // pixel-at-a-time form below (any stride, worker bands) is 95, and this loop was 60 % of the kernel.
-    for (int k = 0; k < 2; k++) {
-      const int q = k * 256 + tid, r0 = 4 * q, p = tstart + r0;  // pixels r0 .. r0 + 3 of the tile (and its halo)
-      if (q < (TILE + HALO + 4) / 4 && p < g.NP) {  // (a lane's last pixels may lie past the frame: their loads stay inside the plane's slack, their bits are dropped)
+    // The tile's 1024 pixels are one such round for every lane; the 255 pixels of the halo are ONE more pixel per lane (bits by
+    // ballot, as below) - as a second round of four they were the first wave's alone, and a workgroup's first waves share a SIMD.
+    {
+      const int q = tid, r0 = 4 * q, p = tstart + r0;  // pixels r0 .. r0 + 3 of the tile
+      if (p < g.NP) {  // (a lane's last pixels may lie past the frame: their loads stay inside the plane's slack, their bits are dropped)
         u32 e[4], a[4];
         __builtin_memcpy(e, plane + (size_t)p * 3 - 3, 16);
         __builtin_memcpy(a, plane + (size_t)(p - g.W) * 3 - 3, 16);
@@ -388,13 +390,32 @@ __global__ __launch_bounds__(256) void k_tiles(const u8* __restrict__ planes, Ge
           ntl |= e_tl ? 1u << i : 0u;
           types |= (u32)(e_l ? 1 : e_tl ? 5 : e_t ? 2 : gr ? 4 : 0) << (8 * i);
         }
-        if (r0 < TILE) ((u32*)ty)[q] = types;
+        ((u32*)ty)[q] = types;
         const int sh = (q & 7) * 4;  // bits r0 .. r0 + 3 of the map: word r0 >> 5
         u32* f32 = (u32*)fm;
         atomicOr(&f32[0 * 48 + (q >> 3)], nl << sh);
         atomicOr(&f32[1 * 48 + (q >> 3)], nt << sh);
         atomicOr(&f32[2 * 48 + (q >> 3)], ng << sh);
         atomicOr(&f32[3 * 48 + (q >> 3)], ntl << sh);
+      }
+    }
+    {
+      const int p = tstart + TILE + tid;  // halo pixel TILE + tid
+      bool e_l = false, e_t = false, e_tl = false, gr = false;
+      if (tid < HALO && p < g.NP) {
+        u64 wc, wt;
+        __builtin_memcpy(&wc, plane + (size_t)p * 3 - 3, 8);
+        __builtin_memcpy(&wt, plane + (size_t)(p - g.W) * 3 - 3, 8);
+        const u32 vc = (u32)(wc >> 24) & 0xFFFFFFu, vl = (u32)wc & 0xFFFFFFu, vt = (u32)(wt >> 24) & 0xFFFFFFu, vtl = (u32)wt & 0xFFFFFFu;
+        e_l = vc == vl, e_t = vc == vt, e_tl = vc == vtl;
+        gr = true;
+#pragma unroll
+        for (int b = 0; b < 24; b += 8) gr &= (int)((vc >> b) & 255) == (int)((vl >> b) & 255) + (int)((vt >> b) & 255) - (int)((vtl >> b) & 255);
+      }
+      const u64 ml = __ballot(e_l), mt = __ballot(e_t), mg = __ballot(gr), mtl = __ballot(e_tl);
+      if (lane_id() == 0) {
+        const int w = (TILE >> 6) + (tid >> 6);  // map word of pixels TILE + 64 wave ..
+        fm[0][w] = ml, fm[1][w] = mt, fm[2][w] = mg, fm[3][w] = mtl;
       }
     }
   } else
