@@ -539,17 +539,25 @@ __global__ __launch_bounds__(256) void k_tiles(const u8* __restrict__ planes, Ge
 // start inside the tile, type of the run active when the tile begins}
 __global__ __launch_bounds__(256) void k_entries(const u8* __restrict__ exitmap, u8* __restrict__ entry, Geom g, const int* __restrict__ slots) {
   // (the exit maps of 64 tiles, 32 KB, are brought in by the whole workgroup with 16-byte loads - one wave with 4-byte loads took
-  // 0.2 of this kernel's 0.3 ms for them, between k_tiles and k_runs on the encoder's critical path - and walked by one lane)
-  __shared__ __attribute__((aligned(16))) u32 buf[64 * 128];
+  // 0.2 of this kernel's 0.3 ms for them, between k_tiles and k_runs on the encoder's critical path - and walked by one lane,
+  // while the other waves bring in the next 64: two buffers)
+  __shared__ __attribute__((aligned(16))) u32 buf[2][64 * 128];
   const int slot = slots[blockIdx.x], tid = threadIdx.x;
-  int e = 0, tin = 0;
-  for (int base = 0; base < g.ntiles; base += 64) {
+  const uint4* const src0 = (const uint4*)(exitmap + (size_t)slot * g.ntiles * 512);
+  auto stage = [&](int base, int which, int first, int step) {
     const int n = min(64, g.ntiles - base);
-    const uint4* srcw = (const uint4*)(exitmap + ((size_t)slot * g.ntiles + base) * 512);
-    for (int i = tid; i < n * 32; i += 256) ((uint4*)buf)[i] = srcw[i];
-    __syncthreads();
-    if (tid == 0) {
-      const u8* b8 = (const u8*)buf;
+    const uint4* srcw = src0 + (size_t)base * 32;
+    for (int i = first; i < n * 32; i += step) ((uint4*)buf[which])[i] = srcw[i];
+  };
+  stage(0, 0, tid, 256);
+  __syncthreads();
+  int e = 0, tin = 0, which = 0;
+  for (int base = 0; base < g.ntiles; base += 64, which ^= 1) {
+    const int n = min(64, g.ntiles - base);
+    if (tid >= 64) {
+      if (base + 64 < g.ntiles) stage(base + 64, which ^ 1, tid - 64, 192);  // the next batch, by the waves that do not walk
+    } else if (tid == 0) {
+      const u8* b8 = (const u8*)buf[which];
       for (int k = 0; k < n; k++) {
         *(u16*)(entry + ((size_t)slot * g.ntiles + base + k) * 2) = (u16)((u32)e | ((u32)tin << 8));
         if (e < HALO) {
