@@ -669,6 +669,8 @@ static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int n
   // writes its literals behind those of the generation's earlier frames.  pad0 = the frame's first pair, pad1 = L.
   std::vector<CsSeg> segs;
   std::vector<CsBlock> cblocks;
+  segs.reserve((size_t)3 * ngens);
+  cblocks.reserve((size_t)tot[2] / CS_B + (size_t)3 * ngens + 8);  // (this sits between a read-back and k_symbols on the critical path)
   {
     std::vector<u32> gbase(ngens, 0), glit(ngens, 0);
     std::vector<bool> seen(ngens, false);
