@@ -540,7 +540,7 @@ static int motion_stage(scpr_codec* c, const std::vector<PFrame>& pfr) {
 // The fixed-alphabet chains over one list (scpr_fixed.hpp): partition by model, then one workgroup per generation, one wave per model.
 template <class SRC, int MAXSYM>
 static int fixed_chains(scpr_codec* c, hipStream_t s2, FixBufs& fb, const u32* el, const u32* elpos, size_t n, const uint2* ranges, int ngens, bool load_first,
-                        const FixedPersist* pin, FixedPersist* pout) {
+                        const FixedPersist* pin, FixedPersist* pout, int phase = 0) {  // phase 1: the partition only, 2: the chains only (0: both)
   constexpr int NC = SRC::NCLS;
   const u32 nblk = (u32)((n + PART_B - 1) / PART_B);
   HIPCHK(fb.cnt.reserve((size_t)NC * (nblk + 1) * 4));
@@ -549,10 +549,13 @@ static int fixed_chains(scpr_codec* c, hipStream_t s2, FixBufs& fb, const u32* e
   HIPCHK(fb.sym.reserve((2 * n + 64) * 2));
   HIPCHK(fb.pos.reserve((2 * n + 16) * 4));
   HIPCHK(fb.gen.reserve((size_t)NC * ngens * 2 * 4));
+  if (phase != 2) {
   if (nblk) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_part_count<SRC>), dim3(nblk), dim3(256), 0, s2, el, (u32)n, fb.cnt.as<u32>(), nblk);
   hipLaunchKernelGGL(k_part_scan, dim3(NC), dim3(SCAN_T), 0, s2, fb.cnt.as<u32>(), fb.off.as<u32>(), nblk, fb.tot.as<u32>());
   if (nblk) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_part_scatter<SRC>), dim3(nblk), dim3(256), 0, s2, el, elpos, (u32)n, fb.off.as<u32>(), nblk, fb.tot.as<u32>(), fb.sym.as<u16>(), fb.pos.as<u32>());
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_part_genstart<SRC>), dim3(ngens), dim3(64), 0, s2, el, (u32)n, ranges, ngens, fb.off.as<u32>(), nblk, fb.tot.as<u32>(), fb.gen.as<u32>());
+  }
+  if (phase == 1) return SCPR_OK;
   // How far apart (in coder entries) a generation's model waves may be, scpr_fixed.hpp.  Measured on the headline batch (300
   // generations), bytes written by the kernel / its time: no window 3.74 GB / 2.16 ms, 16384 entries 1.56 / -, 4096 0.95 / 1.28,
   // 2048 0.84 GB / 1.28 ms - 0.83 GB is every 32-byte sector of the entry array written once (the colour entries between the
@@ -796,30 +799,36 @@ static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int n
   // with the slower partition of earlier in the round the middle position had been the best: 17.35 / 17.05 / 17.75 ms).
   // SCPR_FORK_AT = 0 / 1 / 2 for A/B timing.
   static const int fork_at = getenv("SCPR_FORK_AT") ? atoi(getenv("SCPR_FORK_AT")) : 0;
-  auto fork_fixed_branch = [&]() -> int {
+  // The fixed models' PARTITION runs at the fork, their CHAINS are launched only behind the colour partition: k_fixed_chain2's waves
+  // (twelve to a workgroup, waiting for each other within their window) beside the colour partition cost it 0.7 ms (its two
+  // scatters 0.9 + 0.7 instead of 0.33 + 0.6), beside the colour chains they cost less.  1080p encode 41.1-41.7 -> 41.6-42.5 GPix/s,
+  // 4K 40.1-40.7 -> 40.7-40.8, I+P unchanged.  SCPR_FIXED_GATE=0: the whole branch at the fork.
+  static const bool fixed_gate = !(getenv("SCPR_FIXED_GATE") && atoi(getenv("SCPR_FIXED_GATE")) == 0);
+  auto fork_fixed_branch = [&](int phase = 0) -> int {
     hipStream_t s2 = getenv("SCPR_SERIAL_CHAINS") ? st : c->stream2;  // (design aid: the two chain stages one after the other, to time each alone)
     HIPCHK(hipEventRecord(c->ev_fork, st));
     HIPCHK(hipStreamWaitEvent(s2, c->ev_fork, 0));
-    stage_begin(c, ST_FIXED, s2);
+    if (phase != 2) stage_begin(c, ST_FIXED, s2);
     // the run list, then the list of P-frame symbols: partitioned by model (scpr_fixed.hpp), one wave per (generation, model)
     {
       int rc = fixed_chains<RunItems, 256>(c, s2, c->fixr, c->runs.as<u32>(), c->runpos.as<u32>(), Rtot, (const uint2*)c->ranges.p, ngens, load_first,
-                                           c->fixed_persist.as<FixedPersist>() + buf_in * 12, c->fixed_persist.as<FixedPersist>() + buf_out * 12);
+                                           c->fixed_persist.as<FixedPersist>() + buf_in * 12, c->fixed_persist.as<FixedPersist>() + buf_out * 12, phase);
       if (rc != SCPR_OK) return rc;
       if (Mtot) {
         rc = fixed_chains<MiscItems, 512>(c, s2, c->fixm, c->misc.as<u32>(), c->miscpos.as<u32>(), Mtot, (const uint2*)c->miscranges.p, ngens, load_first,
-                                          c->misc_persist.as<FixedPersist>() + buf_in * MC_COUNT, c->misc_persist.as<FixedPersist>() + buf_out * MC_COUNT);
+                                          c->misc_persist.as<FixedPersist>() + buf_in * MC_COUNT, c->misc_persist.as<FixedPersist>() + buf_out * MC_COUNT, phase);
         if (rc != SCPR_OK) return rc;
-      } else if (!(load_first && ngens == 1)) {  // a new generation without any P-frame symbol: its P-frame models are the renewed ones, not the kept ones
+      } else if (phase != 1 && !(load_first && ngens == 1)) {  // a new generation without any P-frame symbol: its P-frame models are the renewed ones, not the kept ones
         HIPCHK(hipMemsetAsync(c->misc_persist.as<FixedPersist>() + buf_out * MC_COUNT, 0, MC_COUNT * sizeof(FixedPersist), s2));
       }
     }
+    if (phase == 1) return SCPR_OK;
     stage_end(c, ST_FIXED, s2);
     HIPCHK(hipEventRecord(c->ev_join, s2));
     return SCPR_OK;
   };
   if (fork_at == 0 || Ctot == 0) {
-    const int rc = fork_fixed_branch();
+    const int rc = fork_fixed_branch(fixed_gate && Ctot ? 1 : 0);
     if (rc != SCPR_OK) return rc;
   }
   stage_begin(c, ST_SORT);
@@ -846,8 +855,8 @@ static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int n
       hipLaunchKernelGGL(k_cs_scan, dim3(nsg), dim3(64), 0, st, c->cssegs.as<CsSeg>(), c->cscnt.as<u32>(), c->csoff.as<u32>());
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cs_scatter<14>), dim3(nsb), dim3(256), 0, st, c->keys[1].as<u32>(), c->vals[1].as<u32>(), c->csblocks.as<CsBlock>(), c->csoff.as<u32>(),
                          c->keys[0].as<u32>(), c->vals[0].as<u32>());
-      if (fork_at >= 2) {
-        const int rc = fork_fixed_branch();
+      if (fork_at >= 2 || (fork_at == 0 && fixed_gate)) {
+        const int rc = fork_fixed_branch(fork_at == 0 ? 2 : 0);
         if (rc != SCPR_OK) return rc;
       }
     }
