@@ -734,7 +734,7 @@ static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int n
 
   stage_begin(c, ST_SYMBOLS);
   if (ni)
-    hipLaunchKernelGGL(k_symbols, dim3(g.ntiles + 1, ni), dim3(256), 0, st, planes, g, d_slots, c->genlist.as<int>(), c->fidx.as<int>(), c->bases.as<FrameBase>(), c->runrec.as<u32>(),
+    hipLaunchKernelGGL(k_symbols, dim3((g.ntiles + 3) / 4 + 1, ni), dim3(256), 0, st, planes, g, d_slots, c->genlist.as<int>(), c->fidx.as<int>(), c->bases.as<FrameBase>(), c->runrec.as<u32>(),
                        c->tilecnt.as<u32>(), c->tileoff.as<u32>(), c->entry.as<u8>(), c->hdrrec.as<u32>(), c->runs.as<u32>(), c->runpos.as<u32>(), c->keys[0].as<u32>(),
                        c->vals[0].as<u32>());
   if (np) {

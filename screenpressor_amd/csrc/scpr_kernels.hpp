@@ -878,19 +878,19 @@ __global__ void k_debug_swap(u32* a, u32 i, u32 j) {  // scpr_debug_inject(2)
   a[j] = t;
 }
 
-// unified run list + colour symbols.  grid = (ntiles + 1, frames); the extra
+// unified run list + colour symbols.  grid = (ceil(ntiles / 4) + 1, frames): four tiles to a workgroup, the extra
 // block handles the header runs.
 __global__ __launch_bounds__(256) void k_symbols(const u8* __restrict__ planes, Geom g, const int* __restrict__ slots, const int* __restrict__ gens, const int* __restrict__ fidx,
                                                  const FrameBase* __restrict__ bases, const u32* __restrict__ runrec, const u32* __restrict__ tilecnt,
                                                  const u32* __restrict__ tileoff, const u8* __restrict__ entry, const u32* __restrict__ hdrrec,
                                                  u32* __restrict__ runs, u32* __restrict__ runpos, u32* __restrict__ keys, u32* __restrict__ vals) {
-  __shared__ int wsum[5];
   const int fi = blockIdx.y, slot = slots[fi], tid = threadIdx.x;
   const u32 gen = (u32)gens[fi];
   const FrameBase fb = bases[fidx[fi]];
   const u8* plane = planes + (size_t)slot * g.plane_stride;
   const u32 Hr = fb.hdr_runs;
-  if ((int)blockIdx.x == g.ntiles) {  // header runs: C C C N each, no pixel-type symbol
+  const int tgroups = (g.ntiles + 3) >> 2;
+  if ((int)blockIdx.x == tgroups) {  // header runs: C C C N each, no pixel-type symbol
     const u32* rec = hdrrec + (size_t)slot * (g.W + 2);
     for (u32 j = tid; j < Hr; j += 256) {
       u32 r = rec[j], start = r & 0xFFFF, n = r >> 16;
@@ -908,15 +908,19 @@ __global__ __launch_bounds__(256) void k_symbols(const u8* __restrict__ planes, 
     }
     return;
   }
-  const int tile = blockIdx.x;
+  // One WAVE per tile, four tiles to a workgroup: half of a frame's tiles hold 20 runs or fewer (flat areas), and a workgroup of
+  // 256 threads with two barriers per round spent most of its lanes and its time on nothing (round 5: 1.0 -> 0.61 ms).  A
+  // literal's rank among the literals of its round is a ballot.
+  const int lane = lane_id(), tile = (int)blockIdx.x * 4 + (tid >> 6);
+  if (tile >= g.ntiles) return;
   const size_t ti = (size_t)slot * g.ntiles + tile;
   const int cnt = (int)tilecnt[ti * 2];
   const u32 run_off = tileoff[ti * 2], lit_off = tileoff[ti * 2 + 1];
   const u32* rec = runrec + ti * TILE;
   const int tstart = g.p0 + tile * TILE;
-  int lit_run = 0;  // literals in earlier chunks of this tile
-  for (int base = 0; base < cnt; base += 256) {
-    const int i = base + tid;
+  int lit_run = 0;  // literals in earlier rounds of this tile
+  for (int base = 0; base < cnt; base += 64) {
+    const int i = base + lane;
     u32 r = 0;
     int type = -1, lastt = 0;
     if (i < cnt) {
@@ -924,9 +928,8 @@ __global__ __launch_bounds__(256) void k_symbols(const u8* __restrict__ planes, 
       type = (r >> 10) & 7;
       lastt = i > 0 ? (int)((rec[i - 1] >> 10) & 7) : (int)entry[ti * 2 + 1];
     }
-    int tl = 0;
-    int lrank = block_excl_scan(type == 0 ? 1 : 0, &tl, wsum);
-    __syncthreads();
+    const u64 lm = __ballot(type == 0);
+    const int lrank = __popcll(lm & lanemask_lt()), tl = __popcll(lm);
     if (i < cnt) {
       const u32 n = r >> 16, rel = r & 1023;
       const u32 litidx = lit_off + lit_run + lrank;
