@@ -115,7 +115,7 @@ struct scpr_codec {
   FixBufs fixr, fixm;  // run list / P-frame symbol list
   // P-frame buffers
   DevBuf mvdict, mvpre, gmask;
-  DevBuf kinds, pidx, fidx, pframes, pflag, binfo, smv, btype, bmv, bcnt, boff, bflag, pinfo, ptot, pbase, misc, miscpos, miscranges;
+  DevBuf kinds, pidx, fidx, pframes, pflag, binfo, smv, btype, bmv, bcnt, boff, bflag, pinfo, ptot, pbase, misc, miscpos, miscranges, plist;
   // state of the live generation, carried between calls (models are reset only by key frames, screencap.cpp:1118)
   DevBuf mvs, mvs_keep, fixed_persist, misc_persist, colour_persist;
   bool live_valid = false;   // a generation is live (a key frame or flat frame has been coded)
@@ -648,12 +648,16 @@ static int encode_chunk(scpr_codec* c, int n, std::vector<ChunkFrame>& cf, int n
     HIPCHK(c->bcnt.reserve(pb * 4));
     HIPCHK(c->boff.reserve(pb * sizeof(BOff)));
     HIPCHK(c->bflag.reserve(pb * 4));
+    HIPCHK(c->plist.reserve(pb * 4 + 64));  // the chunk's pixel-coded blocks, behind their number (k_pactive; k_pcount walks it)
     stage_begin(c, ST_INTER);
     {
       int rc = motion_stage(c, pfr);
       if (rc != SCPR_OK) return rc;
     }
-    hipLaunchKernelGGL(k_pcount, dim3((nblocks + 63) / 64, np), dim3(64), 0, st, planes, g, c->pframes.as<PFrame>(), c->binfo.as<u32>(), c->btype.as<u8>(), c->bcnt.as<u32>());
+    HIPCHK(hipMemsetAsync(c->plist.p, 0, 4, st));
+    hipLaunchKernelGGL(k_pactive, dim3((nblocks + 1023) / 1024, np), dim3(1024), 0, st, nblocks, c->btype.as<u8>(), c->plist.as<u32>(), c->bcnt.as<u32>());
+    hipLaunchKernelGGL(k_pcount, dim3((unsigned)std::min<size_t>((pb + 63) / 64, 4096)), dim3(64), 0, st, planes, g, c->pframes.as<PFrame>(), c->binfo.as<u32>(), c->plist.as<u32>(),
+                       c->bcnt.as<u32>());
     hipLaunchKernelGGL(k_pscan, dim3(np), dim3(64), 0, st, g, np, c->btype.as<u8>(), c->bmv.as<u32>(), c->bcnt.as<u32>(), c->pinfo.as<int>(), c->boff.as<BOff>(),
                        c->bflag.as<u32>(), c->ptot.as<u32>());
     stage_end(c, ST_INTER);
@@ -1007,7 +1011,7 @@ void scpr_destroy(scpr_codec* c) {
   DevBuf* all[] = {&c->hb_frames, &c->hb_packets, &c->hb_list, &c->snap_mvs, &c->snap_state, &c->planes, &c->tnmap, &c->exitmap, &c->entry, &c->runrec, &c->tilecnt, &c->tileoff, &c->hdrrec, &c->hdrcnt, &c->frametot, &c->flags, &c->slotlist, &c->genlist,
                    &c->bases, &c->totals, &c->runs, &c->runpos, &c->keys[0], &c->keys[1], &c->vals[0], &c->vals[1], &c->cstart, &c->csblocks, &c->cssegs, &c->cscnt, &c->csoff,
                    &c->entries, &c->ranges, &c->rblocks, &c->rscratch, &c->rrec, &c->rsize, &c->packets, &c->pktoff, &c->blkdst, &c->outsizes, &c->total64, &c->arena,
-                   &c->arena_top, &c->err, &c->rcp, &c->decframes, &c->decstates, &c->hoststage_in, &c->hoststage_out, &c->chainlists, &c->chaincounts, &c->fixr.cnt, &c->fixr.off, &c->fixr.tot, &c->fixr.sym, &c->fixr.pos, &c->fixr.gen, &c->fixm.cnt, &c->fixm.off, &c->fixm.tot, &c->fixm.sym, &c->fixm.pos, &c->fixm.gen, &c->kinds, &c->pidx, &c->fidx, &c->pframes, &c->pflag, &c->binfo, &c->smv, &c->btype, &c->bmv, &c->bcnt, &c->boff, &c->bflag, &c->pinfo, &c->ptot, &c->pbase, &c->misc, &c->miscpos, &c->miscranges, &c->mvs, &c->mvs_keep, &c->fixed_persist, &c->misc_persist, &c->colour_persist, &c->decgops, &c->decfixed, &c->dec_fixed_persist, &c->dec_colour_persist, &c->dec_arena, &c->dec_arena2, &c->arena2, &c->dec_arena_top, &c->mvdict, &c->mvpre, &c->gmask};
+                   &c->arena_top, &c->err, &c->rcp, &c->decframes, &c->decstates, &c->hoststage_in, &c->hoststage_out, &c->chainlists, &c->chaincounts, &c->fixr.cnt, &c->fixr.off, &c->fixr.tot, &c->fixr.sym, &c->fixr.pos, &c->fixr.gen, &c->fixm.cnt, &c->fixm.off, &c->fixm.tot, &c->fixm.sym, &c->fixm.pos, &c->fixm.gen, &c->kinds, &c->pidx, &c->fidx, &c->pframes, &c->pflag, &c->binfo, &c->smv, &c->btype, &c->bmv, &c->bcnt, &c->boff, &c->bflag, &c->plist, &c->pinfo, &c->ptot, &c->pbase, &c->misc, &c->miscpos, &c->miscranges, &c->mvs, &c->mvs_keep, &c->fixed_persist, &c->misc_persist, &c->colour_persist, &c->decgops, &c->decfixed, &c->dec_fixed_persist, &c->dec_colour_persist, &c->dec_arena, &c->dec_arena2, &c->arena2, &c->dec_arena_top, &c->mvdict, &c->mvpre, &c->gmask};
   for (DevBuf* b : all) b->release();
   for (int s = 0; s < ST_COUNT + 1; s++)
     for (int k = 0; k < 2; k++) (void)hipEventDestroy(c->ev[s][k]);

@@ -681,26 +681,52 @@ __device__ __forceinline__ void walk_rect_runs(const u8* cur, const u8* prv, int
 }
 
 // bcnt[b] = runs | literal runs << 16 for pixel-coded blocks
-__global__ __launch_bounds__(64) void k_pcount(const u8* __restrict__ planes, Geom g, const PFrame* __restrict__ pf, const u32* __restrict__ binfo, const u8* __restrict__ btype,
+// Two kernels since round 5: a P-frame has ~330 pixel-coded blocks among its 8160, and with a lane per block a wave of 64
+// neighbours walked two or three rects - one lane each, pixel by pixel - while the rest of it waited (2.6 ms for 294 frames).
+// k_pactive lists the pixel-coded blocks of the chunk (list[0] = their number, zeroed by the host; the others' counts are 0;
+// one atomic per workgroup of 1024 blocks), k_pcount walks the list with every lane at work: 0.1 + 1.0 ms.
+// (k_pemit's pixel runs were moved to the same list as well - and cost more than they saved, 1.1 + 1.3 ms against 2.1: what is
+// left of k_pemit is one thread per frame walking the block types, and the list's 1500 waves do not fill the card.)
+__global__ __launch_bounds__(1024) void k_pactive(int nblocks, const u8* __restrict__ btype, u32* __restrict__ list, u32* __restrict__ bcnt) {
+  __shared__ u32 wcnt[16], wbase;
+  const int pi = blockIdx.y, b = blockIdx.x * 1024 + threadIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const size_t at = (size_t)pi * nblocks + b;
+  const int type = b < nblocks ? (int)btype[at] : 0;
+  const bool act = type == 1 || type == 2;
+  if (b < nblocks && !act) bcnt[at] = 0;
+  const u64 m = __ballot(act);
+  if (lane == 0) wcnt[w] = (u32)__popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u32 tot = 0;
+    for (int k = 0; k < 16; k++) tot += wcnt[k];
+    wbase = tot ? atomicAdd(&list[0], tot) : 0u;
+  }
+  __syncthreads();
+  if (act) {
+    u32 before = 0;
+    for (int k = 0; k < w; k++) before += wcnt[k];
+    list[1 + wbase + before + (u32)__popcll(m & ((1ull << lane) - 1ull))] = (u32)at;
+  }
+}
+__global__ __launch_bounds__(64) void k_pcount(const u8* __restrict__ planes, Geom g, const PFrame* __restrict__ pf, const u32* __restrict__ binfo, const u32* __restrict__ list,
                                                u32* __restrict__ bcnt) {
-  const int pi = blockIdx.y, b = blockIdx.x * 64 + threadIdx.x;
   const int nbx = (g.W + 15) >> 4, nby = (g.H + 15) >> 4, nblocks = nbx * nby;
-  if (b >= nblocks) return;
-  const int type = btype[(size_t)pi * nblocks + b];
-  u32 out = 0;
-  if (type == 1 || type == 2) {
+  const u32 n = list[0];
+  for (u32 i = blockIdx.x * 64 + threadIdx.x; i < n; i += gridDim.x * 64) {
+    const u32 at = list[1 + i];
+    const int pi = (int)(at / (u32)nblocks), b = (int)(at - (u32)pi * (u32)nblocks);
     const u8* cur = planes + (size_t)pf[pi].slot * g.plane_stride;
     const u8* prv = planes + (size_t)pf[pi].prev_slot * g.plane_stride;
     const int by = b / nbx, bx = b - by * nbx;
-    const Rect r = binfo_rect(binfo[(size_t)pi * nblocks + b], bx, by);
+    const Rect r = binfo_rect(binfo[at], bx, by);
     int nr = 0, nl = 0;
     walk_rect_runs(cur, prv, g.S, r, [&](int t, int, int, int) {
       nr++;
       nl += t == 0;
     });
-    out = (u32)nr | ((u32)nl << 16);
+    bcnt[at] = (u32)nr | ((u32)nl << 16);
   }
-  bcnt[(size_t)pi * nblocks + b] = out;
 }
 
 // Per frame, one WAVE walks the blocks in raster order, 64 at a time (prefix sums over the lanes; a block's flags need the
@@ -813,30 +839,42 @@ __global__ __launch_bounds__(64) void k_pemit(const u8* __restrict__ planes, Geo
   if (xx2 < xx1) return;
   const u8* bt = btype + (size_t)pi * nblocks;
   if ((int)blockIdx.x == (nblocks + 63) / 64) {
-    if (threadIdx.x != 0) return;
-    u32 k = fb.misc_base, pos = fb.sym_base;
-    auto put = [&](int ctx, int v) {
-      misc[k] = ((u32)ctx << 16) | (u32)v;
-      miscpos[k] = pos;
-      k++;
-      pos++;
+    // the frame's head: the corner blocks' indices (:1145-1150) and the block types between them as (type, length) pairs, a run
+    // of equal types cut at 255 (:1155-1169) - symbol 4 + 2 k is the type of piece k, 4 + 2 k + 1 its length.  One wave, 64
+    // blocks a round, the pieces found as in k_pscan (one thread walking the 8160 blocks was 1.1 of this kernel's 2.1 ms).
+    const int lane = threadIdx.x;
+    const u64 below = (1ull << lane) - 1ull;
+    auto put_at = [&](u32 idx, int ctx, int v) {
+      misc[fb.misc_base + idx] = ((u32)ctx << 16) | (u32)v;
+      miscpos[fb.misc_base + idx] = fb.sym_base + idx;
     };
-    put(MC_X, xx1 & 255);  // :1145-1150
-    put(MC_X, (xx1 >> 8) & 255);
-    put(MC_X, xx2 & 255);
-    put(MC_X, (xx2 >> 8) & 255);
-    int oldt = -1, n = -1;
-    for (int x = xx1; x <= xx2; x++) {  // :1155-1169
-      if (bt[x] == oldt && n < 255)
-        n++;
-      else {
-        if (n > 0) put(MC_BN, n);
-        put(MC_BT, bt[x]);
-        oldt = bt[x];
-        n = 1;
+    if (lane < 4) put_at((u32)lane, MC_X, ((lane < 2 ? xx1 : xx2) >> (8 * (lane & 1))) & 255);
+    int carry = xx1, lastb = xx1;  // start of the run that reaches into the round at hand; the last piece's first block
+    u32 pieces = 0;
+    for (int x0 = xx1; x0 <= xx2; x0 += 64) {
+      const int x = x0 + lane;
+      const bool in = x <= xx2;
+      const int t = in ? (int)bt[x] : -1, tp = (in && x > xx1) ? (int)bt[x - 1] : -2;
+      int rs = (in && (x == xx1 || t != tp)) ? x : (lane == 0 ? carry : -1);  // start of the run the block lies in: a running maximum
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(rs, d);
+        if (lane >= d) rs = max(rs, o);
       }
+      const bool first = in && (x - rs) % 255 == 0;  // the block starts a piece
+      const u64 fm = __ballot(first);
+      if (first) {
+        const u64 fb4 = fm & below;
+        const u32 k = pieces + (u32)__builtin_popcountll(fb4);
+        const int prevb = fb4 ? x0 + (63 - __builtin_clzll(fb4)) : lastb;
+        if (k > 0) put_at(4u + 2u * (k - 1u) + 1u, MC_BN, x - prevb);  // the piece before ends here
+        put_at(4u + 2u * k, MC_BT, t);
+      }
+      if (fm) lastb = x0 + (63 - __builtin_clzll(fm));
+      pieces += (u32)__builtin_popcountll(fm);
+      carry = __shfl(rs, 63);
     }
-    put(MC_BN, n);
+    if (lane == 0) put_at(4u + 2u * (pieces - 1u) + 1u, MC_BN, xx2 + 1 - lastb);
     return;
   }
   const int b = blockIdx.x * 64 + threadIdx.x;
